@@ -1,0 +1,175 @@
+// extern "C" entry points of libseedvr2_hip.so (see include/seedvr2_hip.h for the contract).
+#include "svr_common.h"
+#include "../../include/seedvr2_hip.h"
+#include <cstdio>
+#include <cstring>
+
+// single translation unit: the kernel sources are included here so one hipcc call builds the library
+#include "svr_gemm.hip"
+#include "svr_attn.hip"
+#include "svr_elementwise.hip"
+
+using namespace svr;
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return -1;
+}
+static int check(int hip_status, const char* what) {
+    if (hip_status == 0) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString((hipError_t)hip_status));
+    return hip_status;
+}
+static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+extern "C" {
+
+const char* svr_last_error(void) { return g_err; }
+int svr_abi_version(void) { return SVR_ABI_VERSION; }
+
+int svr_device_info(char* buf, int32_t buflen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail("svr_device_info: no HIP device");
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return fail("svr_device_info: hipGetDeviceProperties failed");
+    if (buf && buflen > 0)
+        snprintf(buf, buflen, "%s arch=%s CUs=%d LDS/block=%zu mem=%.1fGB", p.name, p.gcnArchName,
+                 p.multiProcessorCount, (size_t)p.maxSharedMemoryPerMultiProcessor, p.totalGlobalMem / 1e9);
+    return strstr(p.gcnArchName, "gfx950") ? 0 : fail("svr_device_info: current device is not gfx950");
+}
+
+int svr_gemm_bf16(const svr_gemm_args* args, void* stream) {
+    if (!args) return fail("svr_gemm_bf16: null args");
+    const char* why = nullptr;
+    const int rc = gemm_dispatch(*args, (hipStream_t)stream, &why);
+    if (why) return fail(why);
+    return check(rc, "svr_gemm_bf16");
+}
+
+int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps, const float* w, const float* scale,
+                    const float* shift, void* stream) {
+    if (rows <= 0) return 0;
+    if (dim % 8 || dim > 64 * 8 * 8) return fail("svr_rmsnorm_mod: dim must be a multiple of 8 and <= 4096");
+    hipLaunchKernelGGL(rmsnorm_mod_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, rows, dim, eps, w, scale, shift);
+    return check(hipGetLastError(), "svr_rmsnorm_mod");
+}
+
+int svr_ada_combine(const void* emb, const void* params, const int32_t* slot, float* out, int32_t n_vec, int32_t dim,
+                    void* stream) {
+    if (n_vec <= 0) return 0;
+    hipLaunchKernelGGL(ada_combine_kernel, dim3(blocks_for(dim, 256), n_vec), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)emb, (const bf16_t*)params, slot, out, n_vec, dim);
+    return check(hipGetLastError(), "svr_ada_combine");
+}
+
+int svr_qknorm_rope(void* qkv, int64_t rows, int32_t heads, const int16_t* pos, int32_t t_offset, const float* cos_tab,
+                    const float* sin_tab, int32_t n_pos, int32_t n_freq, const float* wq, const float* wk, float eps,
+                    void* stream) {
+    if (rows <= 0) return 0;
+    if (n_freq * 3 > 64) return fail("svr_qknorm_rope: at most 21 frequencies per axis (head_dim 128)");
+    hipLaunchKernelGGL(qknorm_rope_kernel, dim3(blocks_for(rows * heads, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)qkv, rows, heads, pos, t_offset, cos_tab, sin_tab, n_pos, n_freq, wq, wk, eps);
+    return check(hipGetLastError(), "svr_qknorm_rope");
+}
+
+int svr_attn_varlen(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,
+                    const int32_t* out_rows, const int32_t* cu, int32_t n_seq, int32_t max_len, int32_t heads,
+                    int32_t head_dim, float scale, void* stream) {
+    const char* why = nullptr;
+    const int rc = attn_dispatch(qkv, ld_qkv, out, ld_out, seq_rows, out_rows, cu, n_seq, max_len, heads, head_dim,
+                                 scale, (hipStream_t)stream, &why);
+    if (why) return fail(why);
+    return check(rc, "svr_attn_varlen");
+}
+
+int svr_rows_mean(const void* src, void* dst, int32_t n_groups, int32_t rows_per_group, int32_t dim, void* stream) {
+    if (n_groups <= 0 || rows_per_group <= 0) return 0;
+    if (dim % 8) return fail("svr_rows_mean: dim must be a multiple of 8");
+    hipLaunchKernelGGL(rows_mean_kernel, dim3(blocks_for(dim / 8, 64), rows_per_group), dim3(64), 0,
+                       (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, n_groups, rows_per_group, dim);
+    return check(hipGetLastError(), "svr_rows_mean");
+}
+
+int svr_patchify(const void* in, void* out, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kpad, void* stream) {
+    if ((H & 1) || (W & 1) || kpad < 4 * C) return fail("svr_patchify: H, W must be even and kpad >= 4*C");
+    const int64_t total = (int64_t)T * (H / 2) * (W / 2) * kpad;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(patchify_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, (bf16_t*)out, T, H, W, C, kpad);
+    return check(hipGetLastError(), "svr_patchify");
+}
+
+int svr_unpatchify_euler(const void* pred, int64_t ldp, const void* x_t, void* out, int32_t T, int32_t H, int32_t W,
+                         int32_t C, void* stream) {
+    if ((H & 1) || (W & 1)) return fail("svr_unpatchify_euler: H, W must be even");
+    const int64_t total = (int64_t)T * H * W * C;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(unpatchify_euler_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)pred, ldp, (const bf16_t*)x_t, (bf16_t*)out, T, H, W, C);
+    return check(hipGetLastError(), "svr_unpatchify_euler");
+}
+
+int svr_groupnorm_stats(const void* x, double* stats, int32_t T, int64_t HW, int32_t C, int32_t groups, void* stream) {
+    if (T <= 0 || HW <= 0) return 0;
+    if (C % 8 || C > 512 || (C / groups) % 4 || (256 % (C / 8)))
+        return fail("svr_groupnorm_stats: need C in {128,256,512}-like (C%8==0, C<=512, (C/groups)%4==0)");
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(blocks_for(HW, 2048), T), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, stats, HW, C, groups);
+    return check(hipGetLastError(), "svr_groupnorm_stats");
+}
+
+int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float* gamma, const float* beta, int32_t T,
+                        int64_t HW, int32_t C, int32_t groups, float eps, int32_t apply_silu, void* stream) {
+    if (T <= 0 || HW <= 0) return 0;
+    if (C % 8 || C > 512) return fail("svr_groupnorm_apply: C must be a multiple of 8 and <= 512");
+    const int64_t nchunks = HW * (C / 8);
+    unsigned gx = blocks_for(nchunks, 256 * 4);
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
+    return check(hipGetLastError(), "svr_groupnorm_apply");
+}
+
+int svr_im2col_causal(const void* in, void* out, const svr_conv_geom* g, int32_t kpad, void* stream) {
+    if (!g) return fail("svr_im2col_causal: null geometry");
+    if (g->Cin % 4 || kpad % g->Cin || kpad < g->kt * g->kh * g->kw * g->Cin)
+        return fail("svr_im2col_causal: Cin % 4 == 0 and kpad a multiple of Cin covering all taps required");
+    const int64_t total = (int64_t)g->To * g->Ho * g->Wo * (kpad / g->Cin);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(im2col_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, (bf16_t*)out, *g, kpad);
+    return check(hipGetLastError(), "svr_im2col_causal");
+}
+
+int svr_blend_accumulate(const void* tile, float* acc, float* cnt, const float* wy, const float* wx, int32_t T,
+                         int32_t h, int32_t w, int32_t C, int32_t H, int32_t W, int32_t y0, int32_t x0, void* stream) {
+    const int64_t total = (int64_t)T * h * w * C;
+    if (total <= 0) return 0;
+    if (y0 < 0 || x0 < 0 || y0 + h > H || x0 + w > W) return fail("svr_blend_accumulate: tile outside the canvas");
+    hipLaunchKernelGGL(blend_accumulate_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)tile, acc, cnt, wy, wx, T, h, w, C, H, W, y0, x0);
+    return check(hipGetLastError(), "svr_blend_accumulate");
+}
+
+int svr_blend_finalize(const float* acc, const float* cnt, void* out, int32_t T, int64_t HW, int32_t C, int32_t c_take,
+                       float scale, float shift, void* stream) {
+    const int64_t total = (int64_t)T * HW * c_take;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(blend_finalize_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, acc, cnt,
+                       (bf16_t*)out, T, HW, C, c_take, scale, shift);
+    return check(hipGetLastError(), "svr_blend_finalize");
+}
+
+int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int32_t c_out, float scale, float shift,
+                     void* stream) {
+    if (rows <= 0) return 0;
+    if (c_out > c_in) return fail("svr_affine_slice: c_out > c_in");
+    hipLaunchKernelGGL(affine_slice_kernel, dim3(blocks_for(rows * c_out, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, (bf16_t*)out, rows, c_in, c_out, scale, shift);
+    return check(hipGetLastError(), "svr_affine_slice");
+}
+
+}  // extern "C"

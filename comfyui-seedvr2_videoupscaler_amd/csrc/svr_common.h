@@ -1,0 +1,65 @@
+// Common device helpers for the SeedVR2 gfx950 (CDNA4) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace svr {
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define SVR_DEVICE __device__ __forceinline__
+
+SVR_DEVICE float bf2f(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+
+// round-to-nearest-even, NaN preserved (quiet)
+SVR_DEVICE bf16_t f2bf(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    const uint32_t r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    const uint32_t n = (u >> 16) | 0x40u;
+    return (bf16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? n : r);   // branch-free select
+}
+
+SVR_DEVICE uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// v_exp_f32 (2^x) without the denormal-range fix-up code of exp2f()
+SVR_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+SVR_DEVICE float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// 8 bf16 (one 16-byte chunk) -> 8 floats
+SVR_DEVICE void unpack8(const uint4& v, float* o) {
+    o[0] = __builtin_bit_cast(float, v.x << 16); o[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+    o[2] = __builtin_bit_cast(float, v.y << 16); o[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+    o[4] = __builtin_bit_cast(float, v.z << 16); o[5] = __builtin_bit_cast(float, v.z & 0xffff0000u);
+    o[6] = __builtin_bit_cast(float, v.w << 16); o[7] = __builtin_bit_cast(float, v.w & 0xffff0000u);
+}
+
+SVR_DEVICE uint4 pack8(const float* o) {
+    uint4 v;
+    v.x = pack2bf(o[0], o[1]); v.y = pack2bf(o[2], o[3]);
+    v.z = pack2bf(o[4], o[5]); v.w = pack2bf(o[6], o[7]);
+    return v;
+}
+
+// wave64 all-reduce helpers (ds_bpermute based shuffles; fine off the MFMA critical path)
+SVR_DEVICE float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+SVR_DEVICE float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// async 16-byte global -> LDS copy (LDS destination = wave-uniform base + lane*16)
+SVR_DEVICE void glds16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+}  // namespace svr

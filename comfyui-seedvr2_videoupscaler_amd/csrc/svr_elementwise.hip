@@ -1,0 +1,329 @@
+// HBM-bound side kernels of the SeedVR2 hot path (gfx950): normalisation, modulation, RoPE,
+// patch (un)folding, GroupNorm, im2col for thin convs, tile blending.  All loads/stores are
+// 16-byte (8 x bf16) per lane where the layout allows; reductions are wave shuffles + LDS.
+#include "svr_common.h"
+#include "../../include/seedvr2_hip.h"
+
+namespace svr {
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm (+ optional affine weight) + AdaLN "in" modulation.  One wave per row.
+// normalization.py:88-109, modulation.py:110.
+// ------------------------------------------------------------------------------------------------
+constexpr int RMS_MAXC = 8;   // 16-byte chunks per lane -> dim <= 4096
+
+__global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                          int64_t rows, int dim, float eps,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = dim >> 3;
+    const uint4* xp = (const uint4*)(x + row * dim);
+    uint4 v[RMS_MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < RMS_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            v[i] = xp[c];
+            float f[8];
+            unpack8(v[i], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+        }
+    }
+    ss = wave_sum(ss);
+    const float inv = rsqrtf(ss / (float)dim + eps);
+    uint4* yp = (uint4*)(y + row * dim);
+#pragma unroll
+    for (int i = 0; i < RMS_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            float f[8];
+            unpack8(v[i], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = f[e] * inv;
+                const int ch = c * 8 + e;
+                if (w) t *= w[ch];
+                if (scale) t *= scale[ch];
+                if (shift) t += shift[ch];
+                f[e] = t;
+            }
+            yp[c] = pack8(f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdaSingle vectors: out[v][i] = emb[i*6 + slot[v]] + params[v][i].  modulation.py:76,88-113
+// ------------------------------------------------------------------------------------------------
+__global__ void ada_combine_kernel(const bf16_t* __restrict__ emb, const bf16_t* __restrict__ params,
+                                   const int32_t* __restrict__ slot, float* __restrict__ out, int n_vec, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y;
+    if (i >= dim || v >= n_vec) return;
+    out[(int64_t)v * dim + i] = bf2f(emb[(int64_t)i * 6 + slot[v]]) + bf2f(params[(int64_t)v * dim + i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// q/k RMSNorm(128, affine) + interleaved-pair RoPE on 126 of 128 dims, in place.  One wave per
+// (row, head); lane l owns the pair (2l, 2l+1).  mmattn.py:207-208, rope.py:118-126.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16_t* __restrict__ qkv, int64_t rows, int heads,
+                                                          const int16_t* __restrict__ pos, int t_offset,
+                                                          const float* __restrict__ cos_tab,
+                                                          const float* __restrict__ sin_tab, int n_pos, int n_freq,
+                                                          const float* __restrict__ wq, const float* __restrict__ wk,
+                                                          float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= rows * heads) return;
+    const int64_t row = item / heads;
+    const int head = (int)(item - row * heads);
+    const int64_t ld = (int64_t)3 * heads * 128;
+    uint32_t* qp = (uint32_t*)(qkv + row * ld + (int64_t)head * 128) + lane;
+    uint32_t* kp = (uint32_t*)(qkv + row * ld + (int64_t)(heads + head) * 128) + lane;
+    const uint32_t qraw = *qp, kraw = *kp;
+    float q0 = bf2f((bf16_t)(qraw & 0xffff)), q1 = bf2f((bf16_t)(qraw >> 16));
+    float k0 = bf2f((bf16_t)(kraw & 0xffff)), k1 = bf2f((bf16_t)(kraw >> 16));
+    const float qs = wave_sum(q0 * q0 + q1 * q1);
+    const float ks = wave_sum(k0 * k0 + k1 * k1);
+    const float qi = rsqrtf(qs * (1.0f / 128.0f) + eps), ki = rsqrtf(ks * (1.0f / 128.0f) + eps);
+    q0 = q0 * qi * wq[2 * lane]; q1 = q1 * qi * wq[2 * lane + 1];
+    k0 = k0 * ki * wk[2 * lane]; k1 = k1 * ki * wk[2 * lane + 1];
+    const int axis = lane / n_freq;
+    if (axis < 3) {
+        const int fi = lane - axis * n_freq;
+        int p = pos[row * 3 + axis] + (axis == 0 ? t_offset : 0);
+        p = min(max(p, 0), n_pos - 1);
+        const float c = cos_tab[p * n_freq + fi], s = sin_tab[p * n_freq + fi];
+        const float nq0 = q0 * c - q1 * s, nq1 = q1 * c + q0 * s;
+        const float nk0 = k0 * c - k1 * s, nk1 = k1 * c + k0 * s;
+        q0 = nq0; q1 = nq1; k0 = nk0; k1 = nk1;
+    }
+    *qp = pack2bf(q0, q1);
+    *kp = pack2bf(k0, k1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dst[j] = mean_g src[g * rows_per_group + j]    (na.py:411-417 text coalescing)
+// ------------------------------------------------------------------------------------------------
+__global__ void rows_mean_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int n_groups,
+                                 int rows_per_group, int dim) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;      // 16-byte chunk
+    const int j = blockIdx.y;
+    if (c * 8 >= dim) return;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int gidx = 0; gidx < n_groups; ++gidx) {
+        const uint4 v = *(const uint4*)(src + ((int64_t)gidx * rows_per_group + j) * dim + c * 8);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += f[e];
+    }
+    const float inv = 1.0f / (float)n_groups;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    *(uint4*)(dst + (int64_t)j * dim + c * 8) = pack8(acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// patchify (1,2,2): out[(t, hp, wp)][(dh*2 + dw)*C + c] = in[t][2hp+dh][2wp+dw][c], zero pad to kpad
+// ------------------------------------------------------------------------------------------------
+__global__ void patchify_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int T, int H, int W, int C,
+                                int kpad) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)T * (H / 2) * (W / 2) * kpad;
+    if (idx >= total) return;
+    const int k = (int)(idx % kpad);
+    const int64_t tokn = idx / kpad;
+    bf16_t v = 0;
+    if (k < 4 * C) {
+        const int c = k % C, hw = k / C, dh = hw >> 1, dw = hw & 1;
+        const int wp = (int)(tokn % (W / 2));
+        const int64_t r = tokn / (W / 2);
+        const int hp = (int)(r % (H / 2));
+        const int t = (int)(r / (H / 2));
+        v = in[(((int64_t)t * H + 2 * hp + dh) * W + 2 * wp + dw) * C + c];
+    }
+    out[idx] = v;
+}
+
+// un-patchify + Euler endpoint: out[t][y][x][c] = x_t[...] - pred[token][(dh*2+dw)*C + c]
+__global__ void unpatchify_euler_kernel(const bf16_t* __restrict__ pred, int64_t ldp, const bf16_t* __restrict__ x_t,
+                                        bf16_t* __restrict__ out, int T, int H, int W, int C) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)T * H * W * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    int64_t r = idx / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int t = (int)(r / H);
+    const int64_t tokn = ((int64_t)t * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1);
+    const float p = bf2f(pred[tokn * ldp + ((y & 1) * 2 + (x & 1)) * C + c]);
+    out[idx] = x_t ? f2bf(bf2f(x_t[idx]) - p) : f2bf(p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-frame GroupNorm over NDHWC.  Statistics in fp32 per thread, fp64 across threads/blocks.
+// ------------------------------------------------------------------------------------------------
+constexpr int GN_ROWS_PER_BLOCK = 2048;
+
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x, double* __restrict__ stats,
+                                                              int64_t HW, int C, int groups) {
+    __shared__ float lsum[256], lsq[256];           // indexed by 4-channel quad (C/4 <= 256)
+    const int t = blockIdx.y;
+    const int cchunks = C >> 3;                     // 16-byte chunks per row
+    const int tid = threadIdx.x;
+    const int cc = tid % cchunks;
+    const int rstep = 256 / cchunks;
+    const int64_t r0 = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK;
+    const int64_t r1 = min(r0 + GN_ROWS_PER_BLOCK, HW);
+    if (tid < 256) { lsum[tid] = 0.f; lsq[tid] = 0.f; }
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    const bf16_t* base = x + ((int64_t)t * HW) * C + cc * 8;
+    for (int64_t r = r0 + tid / cchunks; r < r1; r += rstep) {
+        const uint4 v = *(const uint4*)(base + r * C);
+        float f[8];
+        unpack8(v, f);
+        s0 += f[0] + f[1] + f[2] + f[3];
+        q0 += f[0] * f[0] + f[1] * f[1] + f[2] * f[2] + f[3] * f[3];
+        s1 += f[4] + f[5] + f[6] + f[7];
+        q1 += f[4] * f[4] + f[5] * f[5] + f[6] * f[6] + f[7] * f[7];
+    }
+    atomicAdd(&lsum[cc * 2], s0); atomicAdd(&lsq[cc * 2], q0);
+    atomicAdd(&lsum[cc * 2 + 1], s1); atomicAdd(&lsq[cc * 2 + 1], q1);
+    __syncthreads();
+    const int quads_per_group = (C / groups) >> 2;  // channels per group / 4 (>= 1)
+    if (tid < groups) {
+        double s = 0.0, q = 0.0;
+        for (int i = 0; i < quads_per_group; ++i) {
+            s += (double)lsum[tid * quads_per_group + i];
+            q += (double)lsq[tid * quads_per_group + i];
+        }
+        atomicAdd(&stats[((int64_t)t * groups + tid) * 2], s);
+        atomicAdd(&stats[((int64_t)t * groups + tid) * 2 + 1], q);
+    }
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                              const double* __restrict__ stats,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int64_t HW, int C,
+                                                              int groups, float eps, int apply_silu) {
+    __shared__ float a_s[512], b_s[512];            // per-channel scale / offset (C <= 512)
+    const int t = blockIdx.y;
+    const int cpg = C / groups;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int gidx = c / cpg;
+        const double n = (double)HW * (double)cpg;
+        const double mean = stats[((int64_t)t * groups + gidx) * 2] / n;
+        double var = stats[((int64_t)t * groups + gidx) * 2 + 1] / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float ga = gamma[c] * rstd;
+        a_s[c] = ga;
+        b_s[c] = beta[c] - (float)mean * ga;
+    }
+    __syncthreads();
+    const int cchunks = C >> 3;
+    const int64_t nchunks = HW * cchunks;
+    const bf16_t* xb = x + (int64_t)t * HW * C;
+    bf16_t* yb = y + (int64_t)t * HW * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % cchunks) * 8;
+        const uint4 v = *(const uint4*)(xb + i * 8);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float u = f[e] * a_s[c0 + e] + b_s[c0 + e];
+            f[e] = apply_silu ? silu(u) : u;
+        }
+        *(uint4*)(yb + i * 8) = pack8(f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2col for thin causal convs (Cin = 4 (RGB padded) / 16): one thread per (voxel, tap), 8-byte units
+// ------------------------------------------------------------------------------------------------
+__global__ void im2col_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, svr_conv_geom g, int kpad) {
+    const int taps = g.kt * g.kh * g.kw;
+    const int slots = kpad / g.Cin;                 // tap slots per output row (>= taps), rest zero
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t M = (int64_t)g.To * g.Ho * g.Wo;
+    if (idx >= M * slots) return;
+    const int tap = (int)(idx % slots);
+    const int64_t m = idx / slots;
+    uint2* dst = (uint2*)(out + m * kpad + (int64_t)tap * g.Cin);
+    const int units = g.Cin >> 2;
+    const uint2* src = nullptr;
+    if (tap < taps) {
+        const int xo = (int)(m % g.Wo);
+        const int64_t r = m / g.Wo;
+        const int yo = (int)(r % g.Ho), to = (int)(r / g.Ho);
+        const int dx = tap % g.kw, r2 = tap / g.kw, dy = r2 % g.kh, dt = r2 / g.kh;
+        int ts = to * g.st - g.pt + dt;
+        const int ys = yo * g.sh - g.ph + dy, xs = xo * g.sw - g.pw + dx;
+        if ((unsigned)ys < (unsigned)g.H && (unsigned)xs < (unsigned)g.W) {
+            const bf16_t* basep = in;
+            if (ts < 0) {
+                if (g.halo) { basep = (const bf16_t*)g.halo; ts += g.halo_frames; }
+                else ts = 0;
+            }
+            src = (const uint2*)(basep + (((int64_t)ts * g.H + ys) * g.W + xs) * g.Cin);
+        }
+    }
+    for (int u = 0; u < units; ++u) dst[u] = src ? src[u] : make_uint2(0u, 0u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile blending (tiled_encode / tiled_decode): fp32 accumulate with separable cosine ramps.
+// ------------------------------------------------------------------------------------------------
+__global__ void blend_accumulate_kernel(const bf16_t* __restrict__ tile, float* __restrict__ acc,
+                                        float* __restrict__ cnt, const float* __restrict__ wy,
+                                        const float* __restrict__ wx, int T, int h, int w, int C, int H, int W,
+                                        int y0, int x0) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over T*h*w*C
+    const int64_t total = (int64_t)T * h * w * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    int64_t r = idx / C;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h);
+    const int t = (int)(r / h);
+    const float wgt = wy[y] * wx[x];
+    acc[(((int64_t)t * H + y0 + y) * W + x0 + x) * C + c] += bf2f(tile[idx]) * wgt;
+    if (t == 0 && c == 0) cnt[(int64_t)(y0 + y) * W + x0 + x] += wgt;
+}
+
+__global__ void blend_finalize_kernel(const float* __restrict__ acc, const float* __restrict__ cnt,
+                                      bf16_t* __restrict__ out, int T, int64_t HW, int C, int c_take, float scale,
+                                      float shift) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over T*HW*c_take
+    const int64_t total = (int64_t)T * HW * c_take;
+    if (idx >= total) return;
+    const int c = (int)(idx % c_take);
+    const int64_t vox = idx / c_take;
+    const int64_t p = vox % HW;
+    const float v = acc[vox * C + c] / fmaxf(cnt[p], 1e-6f);
+    out[idx] = f2bf((v - shift) * scale);
+}
+
+// out[r][:c_out] = (in[r][:c_out] - shift) * scale      (latent scaling, infer.py:188 / :236)
+__global__ void affine_slice_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int64_t rows, int c_in,
+                                    int c_out, float scale, float shift) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * c_out) return;
+    const int c = (int)(idx % c_out);
+    const int64_t r = idx / c_out;
+    out[idx] = f2bf((bf2f(in[r * c_in + c]) - shift) * scale);
+}
+
+}  // namespace svr

@@ -1,0 +1,305 @@
+// bf16 MFMA GEMM / implicit-GEMM causal Conv3d for gfx950 (MI355X).
+//
+//   C[M, N] = A[M, K] * W[N, K]^T  (+ fused epilogue)
+//
+// One kernel serves every nn.Linear of the NaDiT (mmattn.py:173,269; mlp.py:60-61; ...) and,
+// in "conv" mode, InflatedCausalConv3d (causal_inflation_lib.py:213-305) as an implicit GEMM over
+// NDHWC activations: row m is an output voxel, the K axis runs tap-major / channel-minor, and the A
+// tile is gathered straight from the input tensor (spatial zero padding reads a zero page, the
+// causal temporal head reads the previous slice's tail frames or replicates frame 0).
+//
+// Structure (CDNA4): 512 threads = 8 waves, block tile BM x BN x 64, v_mfma_f32_16x16x32_bf16,
+// both operands streamed HBM/L2 -> LDS with 16-byte global_load_lds (no VGPR round trip), two LDS
+// stages, one barrier per K tile.  LDS rows are 128 B (64 bf16); the 16-byte chunk index is XORed
+// with (row & 7) on the *source* address and on the ds_read_b128 side (the LDS-DMA destination must
+// stay lane-linear), which makes every ds_read_b128 lane group hit 16 distinct bank slots.
+// Operands are issued swapped (mfma(Wfrag, Afrag)) so each lane ends up with 4 consecutive output
+// columns of one row -> 8-byte bf16 stores and float4 bias/gate loads in the epilogue.
+// Block ids are remapped so every XCD works on a contiguous band of tiles (own L2), swept in
+// groups of 4 row-panels x all column panels.
+#include "svr_common.h"
+#include "../../include/seedvr2_hip.h"
+
+namespace svr {
+
+constexpr int BK = 64;
+constexpr int THREADS = 512;
+
+struct RowSrc {           // per-thread description of one A-tile row it stages
+    const char* base;     // plain: row pointer;  conv: unused
+    int t, y, x;          // conv: top-left-front input coordinate of the receptive field
+};
+
+// One lane's 4 consecutive output columns of row m (n .. n+3): fused epilogue + store.
+SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f32x4 u, int m, int n) {
+    float v[4] = {accv[0], accv[1], accv[2], accv[3]};
+    const int epi = a.epilogue;
+    if (epi == SVR_EPI_SWIGLU) {
+        // n = 32*hb + 4g (gate block of hidden block hb) -> hidden index 16*hb + 4g
+        const int hid = ((n >> 5) << 4) + (n & 15);
+        uint2 o;
+        o.x = pack2bf(silu(v[0]) * u[0], silu(v[1]) * u[1]);
+        o.y = pack2bf(silu(v[2]) * u[2], silu(v[3]) * u[3]);
+        *(uint2*)((char*)a.C + ((int64_t)m * a.ldc + hid) * 2) = o;
+        return;
+    }
+    const bool full = (n + 3 < a.N);
+    if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += a.bias[n + r];
+    }
+    if (epi == SVR_EPI_BIAS_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
+    } else if (epi == SVR_EPI_RESID_GATE) {
+        if (a.gate) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] *= a.gate[n + r];
+        }
+        if (a.resid) {
+            const bf16_t* rp = (const bf16_t*)a.resid + (int64_t)m * a.ldr + n;
+            if (full) {
+                const uint2 rr = *(const uint2*)rp;
+                v[0] += bf2f((bf16_t)(rr.x & 0xffff)); v[1] += bf2f((bf16_t)(rr.x >> 16));
+                v[2] += bf2f((bf16_t)(rr.y & 0xffff)); v[3] += bf2f((bf16_t)(rr.y >> 16));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += bf2f(rp[r]);
+            }
+        }
+    }
+    int64_t off;   // element offset of v[0] in C
+    if (a.ps.enabled) {
+        const int pw = m % a.ps.W;
+        const int r2 = m / a.ps.W;
+        const int ph = r2 % a.ps.H;
+        const int pf = r2 / a.ps.H;
+        const int C = a.ps.C;
+        const int blk = n / C, c = n - blk * C;           // blk = (x*2 + y)*rz + z
+        const int z = blk % a.ps.rz;
+        const int xy = blk / a.ps.rz;
+        int fo = pf * a.ps.rz + z;
+        if (a.ps.drop_first) {
+            if (fo == 1) return;                          // duplicated head frame (remove_head)
+            if (fo > 1) fo -= 1;
+        }
+        const int yo = ph * 2 + (xy >> 1), xo = pw * 2 + (xy & 1);
+        off = (((int64_t)fo * (2 * a.ps.H) + yo) * (2 * a.ps.W) + xo) * C + c;
+    } else {
+        off = (int64_t)m * a.ldc + n;
+    }
+    if (a.out_f32) {
+        float* cp = (float*)a.C + off;
+        if (full) *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < a.N) cp[r] = v[r];
+        }
+    } else {
+        bf16_t* cp = (bf16_t*)a.C + off;
+        if (full) {
+            uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+            *(uint2*)cp = o;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < a.N) cp[r] = f2bf(v[r]);
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int A_ITERS = BM / 64, B_ITERS = BN / 64;
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    static_assert((BM / WM) * (BN / WN) == 8, "8 waves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- tile id: XCD-contiguous bands, then grouped (4 row panels x all column panels) order
+    const int tiles_m = (a.M + BM - 1) / BM;
+    const int tiles_n = (a.N + BN - 1) / BN;
+    int t;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, j = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    constexpr int GM = 4;
+    const int group_size = GM * tiles_n;
+    const int group = t / group_size;
+    const int first_m = group * GM;
+    const int gm = min(tiles_m - first_m, GM);
+    const int tm = first_m + (t % group_size) % gm;
+    const int tn = (t % group_size) / gm;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging roles: thread stages 16-byte chunk (lane & 7) of rows (tid >> 3) + 64 * i
+    const int chunk_src = (lane & 7) ^ (lane >> 3);       // source-side XOR swizzle
+    RowSrc rows[A_ITERS];
+    const svr_conv_geom& g = a.conv;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+        int m = m0 + (tid >> 3) + 64 * i;
+        m = min(m, a.M - 1);
+        if constexpr (CONV) {
+            const int xo = m % g.Wo;
+            const int r2 = m / g.Wo;
+            const int yo = r2 % g.Ho;
+            const int to = r2 / g.Ho;
+            rows[i].t = to * g.st - g.pt;
+            rows[i].y = yo * g.sh - g.ph;
+            rows[i].x = xo * g.sw - g.pw;
+            rows[i].base = nullptr;
+        } else {
+            rows[i].base = (const char*)a.A + (int64_t)m * a.lda * 2 + chunk_src * 16;
+            rows[i].t = rows[i].y = rows[i].x = 0;
+        }
+    }
+    const char* wrow[B_ITERS];
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+        const int n = n0 + (tid >> 3) + 64 * i;               // W is padded to a multiple of BN rows
+        wrow[i] = (const char*)a.W + (int64_t)n * a.K * 2 + chunk_src * 16;
+    }
+
+    const int nk = a.K / BK;
+
+    auto stage = [&](int kt, int s) {
+        char* sA = smem + s * STAGE_BYTES;
+        char* sB = sA + BM * BK * 2;
+        const int64_t koff = (int64_t)kt * (BK * 2);
+        if constexpr (CONV) {
+            const int k0 = kt * BK;
+            const int tap = k0 / g.Cin;
+            const int c0 = k0 - tap * g.Cin;
+            const int dx = tap % g.kw;
+            const int r2 = tap / g.kw;
+            const int dy = r2 % g.kh;
+            const int dt = r2 / g.kh;
+#pragma unroll
+            for (int i = 0; i < A_ITERS; ++i) {
+                int ts = rows[i].t + dt;
+                const int ys = rows[i].y + dy, xs = rows[i].x + dx;
+                const char* src;
+                if ((unsigned)ys >= (unsigned)g.H || (unsigned)xs >= (unsigned)g.W) {
+                    src = (const char*)g.zeros;
+                } else {
+                    const char* basep = (const char*)a.A;
+                    if (ts < 0) {
+                        if (g.halo != nullptr) { basep = (const char*)g.halo; ts += g.halo_frames; }
+                        else ts = 0;
+                    }
+                    const int64_t vox = ((int64_t)ts * g.H + ys) * g.W + xs;
+                    src = basep + (vox * g.Cin + c0 + chunk_src * 8) * 2;
+                }
+                glds16(src, sA + (wave * 8 + 64 * i) * 128);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_ITERS; ++i) glds16(rows[i].base + koff, sA + (wave * 8 + 64 * i) * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) glds16(wrow[i] + koff, sB + (wave * 8 + 64 * i) * 128);
+    };
+
+    // ---- compute roles
+    const int wm0 = (wave / WAVES_N) * WM;
+    const int wn0 = (wave % WAVES_N) * WN;
+    const int frow = lane & 15;
+    // byte offset of this lane's 16-byte chunk inside a 128-byte LDS row, per k-step
+    const int koffs0 = ((0 * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
+    const int koffs1 = ((1 * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    __syncthreads();          // drains the LDS-DMA queue (vmcnt(0)) before the barrier
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const char* sA = smem + cur * STAGE_BYTES;
+        const char* sB = sA + BM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ko = ks == 0 ? koffs0 : koffs1;
+            bf16x8 af[FM], bfr[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                bfr[j] = *(const bf16x8*)(sB + (wn0 + 16 * j + frow) * 128 + ko);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                af[i] = *(const bf16x8*)(sA + (wm0 + 16 * i + frow) * 128 + ko);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();      // next tile landed (vmcnt(0)) + everyone done reading `cur`
+    }
+
+    // ---- epilogue.  Lane holds C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) + 0..3].
+    const int ng = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm0 + 16 * i + frow;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn0 + 16 * j + ng;
+            // SWIGLU: 16-column blocks alternate gate | in; even j = gate block, odd j = in block
+            const f32x4 u = acc[i][j | 1];
+            if (m < a.M && n < a.N && !((j & 1) && a.epilogue == SVR_EPI_SWIGLU)) epilogue_store(a, acc[i][j], u, m, n);
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+static int launch(const svr_gemm_args& a, hipStream_t s) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+    auto kern = gemm_kernel<BM, BN, WM, WN, CONV>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
+    *why = nullptr;
+    if (a.M <= 0 || a.N <= 0) return 0;
+    if (a.K <= 0 || (a.K % BK) != 0) { *why = "svr_gemm_bf16: K must be a positive multiple of 64"; return -1; }
+    if (a.conv.enabled) {
+        const svr_conv_geom& g = a.conv;
+        if (g.Cin % BK != 0) { *why = "svr_gemm_bf16(conv): Cin must be a multiple of 64"; return -1; }
+        if (a.K != g.kt * g.kh * g.kw * g.Cin) { *why = "svr_gemm_bf16(conv): K != taps*Cin"; return -1; }
+        if (a.M != g.To * g.Ho * g.Wo) { *why = "svr_gemm_bf16(conv): M != To*Ho*Wo"; return -1; }
+        if (!g.zeros) { *why = "svr_gemm_bf16(conv): zero page missing"; return -1; }
+        if (g.halo && g.halo_frames < g.pt) { *why = "svr_gemm_bf16(conv): halo shorter than causal pad"; return -1; }
+    }
+    if (a.epilogue == SVR_EPI_SWIGLU && (a.N % 32) != 0) { *why = "svr_gemm_bf16: SWIGLU needs N % 32 == 0"; return -1; }
+    if (a.ps.enabled && (a.N != 4 * a.ps.rz * a.ps.C || a.M != a.ps.F * a.ps.H * a.ps.W || (a.ps.C % 4) != 0)) {
+        *why = "svr_gemm_bf16: bad pixel-shuffle geometry"; return -1;
+    }
+    const bool wide = (a.N % 256) == 0;     // otherwise W is padded to a multiple of 128 rows
+    if (a.conv.enabled) {
+        return wide ? launch<256, 256, 128, 64, true>(a, s) : launch<256, 128, 64, 64, true>(a, s);
+    }
+    return wide ? launch<256, 256, 128, 64, false>(a, s) : launch<256, 128, 64, 64, false>(a, s);
+}
+
+}  // namespace svr

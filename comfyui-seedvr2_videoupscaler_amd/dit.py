@@ -1,0 +1,273 @@
+"""NaDiT (SeedVR2-3B family) forward pass on MI355X: host orchestration of the HIP kernels.
+
+Mirrors ``NaDiT.forward(vid, txt, vid_shape, txt_shape, timestep) -> NaDiTOutput(vid_sample)``
+(reference: src/models/dit_3b/nadit.py:190-248) for a batch of one clip, which is how the
+runner calls it (src/core/infer.py:361-367 with a single-element list, generation_phases.py:718-735).
+
+Design (MI355X-first, not a module-by-module translation):
+  * one activation matrix ``hid`` [N + Lt, d]: video tokens first, the Lt text tokens behind them, so
+    the 22 shared-weight blocks run ONE GEMM over both streams (the 10 MM blocks run two);
+  * no window-ordered copies: q/k-norm + RoPE run in place on the token-ordered QKV buffer with a
+    per-token window-local position table, the attention kernel gathers rows through an index vector
+    and scatters its output back, text outputs land in a scratch tail and are mean-pooled;
+  * AdaLN modulation is per channel at batch 1 -> all (scale, shift, gate) vectors of all layers are
+    built once per step (svr_ada_combine) and consumed as fused prologue/epilogue operands:
+    RMSNorm+modulate in one pass, gate*x+residual inside the proj_out / mlp-out GEMM epilogues,
+    SiLU(gate)*in inside the MLP-in GEMM epilogue (weights interleaved at load);
+  * the reference's ``vid_out_ada`` cache-key collision (it modulates with the *attn* slot of the
+    timestep embedding) is reproduced deliberately.
+"""
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import windows
+from .config import DiTConfig
+from .ops import EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU
+from .packing import pack_matrix, pack_swiglu, pack_vec
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class NaDiTOutput:
+    vid_sample: torch.Tensor
+
+
+@dataclass
+class _Lin:
+    w: torch.Tensor
+    b: Optional[torch.Tensor]
+    n: int
+    k: int
+
+
+def timestep_sinusoid(t: float, dim: int = 256) -> torch.Tensor:
+    """diffusers.get_timestep_embedding(flip_sin_to_cos=False, downscale_freq_shift=0), fp32
+    (embedding.py:50-55).  Host constant: the one-step sampler always asks for t = T = 1000."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    ang = torch.tensor([float(t)], dtype=torch.float32)[:, None] * freqs[None, :]
+    return torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1)
+
+
+class NaDiTEngine:
+    def __init__(self, cfg: DiTConfig, state_dict: Dict[str, torch.Tensor], ops):
+        self.cfg, self.ops = cfg, ops
+        dev = ops.device
+        self.device = dev
+        d, inner = cfg.vid_dim, cfg.heads * cfg.head_dim
+        if cfg.head_dim != 128:
+            raise ValueError("the window-attention kernel is built for head_dim 128")
+        sd = state_dict
+
+        def lin(name, bias=True):
+            w = sd[name + ".weight"]
+            return _Lin(pack_matrix(w, dev), pack_vec(sd[name + ".bias"], dev) if bias else None,
+                        w.shape[0], (w.shape[1] + 63) // 64 * 64)
+
+        self.vid_in = lin("vid_in.proj")
+        self.txt_in = lin("txt_in")
+        self.emb_in = [lin("emb_in.proj_in"), lin("emb_in.proj_hid"), lin("emb_in.proj_out")]
+        self.vid_out = lin("vid_out.proj")
+        self.out_norm_w = pack_vec(sd["vid_out_norm.weight"], dev)
+        self.kpad_in = self.vid_in.k
+
+        # ---- per-block weights
+        self.blocks = []
+        ada_rows, ada_slots = [], []
+
+        def add_ada(key, slot):
+            ada_rows.append(sd[key].to(BF16))
+            ada_slots.append(slot)
+            return len(ada_rows) - 1
+
+        for i in range(cfg.num_layers):
+            shared = i >= cfg.mm_layers
+            p = f"blocks.{i}."
+            blk = {"shared": shared}
+            for stream, b in (("vid", "all" if shared else "vid"), ("txt", "all" if shared else "txt")):
+                if shared and stream == "txt":
+                    blk["txt"] = blk["vid"]
+                    continue
+                s = {}
+                s["qkv"] = lin(p + f"attn.proj_qkv.{b}", bias=False)
+                s["out"] = lin(p + f"attn.proj_out.{b}")
+                s["wq"] = pack_vec(sd[p + f"attn.norm_q.{b}.weight"], dev)
+                s["wk"] = pack_vec(sd[p + f"attn.norm_k.{b}.weight"], dev)
+                wg, wi = sd[p + f"mlp.{b}.proj_in_gate.weight"], sd[p + f"mlp.{b}.proj_in.weight"]
+                s["mlp_in"] = _Lin(pack_swiglu(wg, wi, dev), None, 2 * wg.shape[0], wg.shape[1])
+                s["mlp_out"] = lin(p + f"mlp.{b}.proj_out", bias=False)
+                # AdaSingle parameters; slot = l*3 + g with l in (attn, mlp), g in (shift, scale, gate)
+                s["ada"] = {}
+                for l, lname in enumerate(("attn", "mlp")):
+                    for gi, gname in enumerate(("shift", "scale", "gate")):
+                        s["ada"][(lname, gname)] = add_ada(p + f"ada.{b}.{lname}_{gname}", l * 3 + gi)
+                blk[stream] = s
+            blk["freqs"] = sd[p + "attn.rope.rope.freqs"].float().cpu()
+            self.blocks.append(blk)
+        # output modulation reuses the attn slot (l = 0) of the embedding: shift g=0, scale g=1
+        self.ada_out_shift = add_ada("vid_out_ada.out_shift", 0)
+        self.ada_out_scale = add_ada("vid_out_ada.out_scale", 1)
+        self.ada_params = torch.stack(ada_rows).to(dev).contiguous()
+        self.ada_slots = torch.tensor(ada_slots, dtype=torch.int32, device=dev)
+        self._plan_cache = {}
+        self._rope_cache = {}
+
+    # ------------------------------------------------------------------ host-side index plans
+    def _plan(self, size, method, Lt):
+        key = (size, method, Lt)
+        if key in self._plan_cache:
+            return self._plan_cache[key]
+        plan = windows.plan_windows(size, tuple(self.cfg.window), method)
+        N = size[0] * size[1] * size[2]
+        n_win = plan.n_win
+        lens = np.diff(plan.cu)
+        total = N + n_win * Lt
+        seq_rows = np.empty(total, dtype=np.int32)
+        out_rows = np.empty(total, dtype=np.int32)
+        cu = np.zeros(n_win + 1, dtype=np.int32)
+        txt_src = N + np.arange(Lt, dtype=np.int32)
+        o = 0
+        for w in range(n_win):
+            rows = plan.tok[plan.cu[w]:plan.cu[w + 1]]
+            seq_rows[o:o + lens[w]] = rows
+            out_rows[o:o + lens[w]] = rows
+            o += lens[w]
+            seq_rows[o:o + Lt] = txt_src                       # every window sees the same text rows
+            out_rows[o:o + Lt] = N + Lt + w * Lt + np.arange(Lt)   # per-window text outputs -> scratch tail
+            o += Lt
+            cu[w + 1] = o
+        dev = self.device
+        res = dict(n_win=n_win, max_len=int(lens.max()) + Lt,
+                   seq_rows=torch.from_numpy(seq_rows).to(dev), out_rows=torch.from_numpy(out_rows).to(dev),
+                   cu=torch.from_numpy(cu).to(dev), pos=torch.from_numpy(plan.pos.copy()).to(dev))
+        self._plan_cache[key] = res
+        return res
+
+    def _rope_tables(self, freqs: torch.Tensor, n_pos: int):
+        key = (tuple(freqs.tolist()), n_pos)
+        if key not in self._rope_cache:
+            ang = torch.arange(n_pos, dtype=torch.float32)[:, None] * freqs[None, :]   # fp32, as the reference
+            self._rope_cache[key] = (ang.cos().to(self.device).contiguous(), ang.sin().to(self.device).contiguous())
+        return self._rope_cache[key]
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, vid: torch.Tensor, txt: torch.Tensor, timestep: float = 1000.0,
+                x_t: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """vid [T, H, W, 33] bf16 (x_t || condition), txt [Lt, txt_in_dim] bf16.
+        Returns the model prediction [T, H, W, 16]; with ``x_t`` given returns the one-step Euler
+        endpoint x_t - pred instead (fused into the un-patchify kernel)."""
+        cfg, ops = self.cfg, self.ops
+        d, heads, hd = cfg.vid_dim, cfg.heads, cfg.head_dim
+        inner = heads * hd
+        T, H, W, Cin = vid.shape
+        assert Cin == cfg.vid_in_channels and H % 2 == 0 and W % 2 == 0
+        t, h, w = T, H // 2, W // 2
+        N, Lt = t * h * w, txt.shape[0]
+        R = N + Lt
+        eps = cfg.norm_eps
+
+        hid = ops.empty(R, d)
+        a0 = ops.empty(N, self.kpad_in)
+        ops.patchify(vid.contiguous(), a0)
+        ops.gemm(a0, self.vid_in.w, hid[:N], N=d, K=self.kpad_in, bias=self.vid_in.b)
+        del a0
+        ops.gemm(txt.contiguous(), self.txt_in.w, hid[N:], N=d, K=self.txt_in.k, bias=self.txt_in.b)
+
+        # ---- timestep embedding -> all AdaLN vectors of the step
+        e = timestep_sinusoid(timestep).to(device=self.device, dtype=ops.act_dtype)
+        e1, e2 = ops.empty(1, d), ops.empty(1, d)
+        emb = ops.empty(1, cfg.emb_dim)
+        ops.gemm(e, self.emb_in[0].w, e1, N=d, K=256, bias=self.emb_in[0].b, epilogue=EPI_BIAS_SILU)
+        ops.gemm(e1, self.emb_in[1].w, e2, N=d, K=d, bias=self.emb_in[1].b, epilogue=EPI_BIAS_SILU)
+        ops.gemm(e2, self.emb_in[2].w, emb, N=cfg.emb_dim, K=d, bias=self.emb_in[2].b)
+        mod = ops.empty(self.ada_params.shape[0], d, dtype=torch.float32)
+        ops.ada_combine(emb.reshape(-1), self.ada_params, self.ada_slots, mod)
+
+        xn = ops.empty(R, d)
+        qkv = ops.empty(R, 3 * inner)
+        h1 = ops.empty(R, cfg.mlp_hidden)
+        jt = torch.arange(Lt, dtype=torch.int16)
+        pos_t = torch.stack([jt, jt, jt], dim=-1).contiguous().to(self.device)
+        scale = 1.0 / math.sqrt(hd)
+
+        for li, blk in enumerate(self.blocks):
+            last = li == cfg.num_layers - 1
+            shared = blk["shared"]
+            sv, st = blk["vid"], blk["txt"]
+            plan = self._plan((t, h, w), cfg.window_method(li), Lt)
+            n_win = plan["n_win"]
+            cos_t, sin_t = self._rope_tables(blk["freqs"], max(Lt + t, h, w) + 16)
+
+            # ---- attention branch
+            ops.rmsnorm_mod(hid[:N], xn[:N], eps, scale=mod[sv["ada"][("attn", "scale")]],
+                            shift=mod[sv["ada"][("attn", "shift")]])
+            if last:      # MMModule(ada, vid_only=True): the text stream is normalised but not modulated
+                ops.rmsnorm_mod(hid[N:], xn[N:], eps)
+            else:
+                ops.rmsnorm_mod(hid[N:], xn[N:], eps, scale=mod[st["ada"][("attn", "scale")]],
+                                shift=mod[st["ada"][("attn", "shift")]])
+            if shared:
+                ops.gemm(xn, sv["qkv"].w, qkv, N=3 * inner, K=d)
+            else:
+                ops.gemm(xn[:N], sv["qkv"].w, qkv[:N], N=3 * inner, K=d)
+                ops.gemm(xn[N:], st["qkv"].w, qkv[N:], N=3 * inner, K=d)
+            ops.qknorm_rope(qkv[:N], heads, plan["pos"], Lt, cos_t, sin_t, sv["wq"], sv["wk"], eps)
+            ops.qknorm_rope(qkv[N:], heads, pos_t, 0, cos_t, sin_t, st["wq"], st["wk"], eps)
+            att = ops.empty(R + n_win * Lt, inner)
+            ops.attn_varlen(qkv, att, plan["seq_rows"], plan["out_rows"], plan["cu"], plan["max_len"], heads, hd, scale)
+            ops.rows_mean(att[R:], att[N:R], n_win, Lt)
+            g_v = mod[sv["ada"][("attn", "gate")]]
+            if shared and not last:
+                ops.gemm(att[:R], sv["out"].w, hid, N=d, K=inner, bias=sv["out"].b, epilogue=EPI_RESID_GATE,
+                         gate=g_v, resid=hid)
+            else:
+                ops.gemm(att[:N], sv["out"].w, hid[:N], N=d, K=inner, bias=sv["out"].b, epilogue=EPI_RESID_GATE,
+                         gate=g_v, resid=hid[:N])
+                if not last:   # the text stream is dead after the last block's attention
+                    ops.gemm(att[N:R], st["out"].w, hid[N:], N=d, K=inner, bias=st["out"].b,
+                             epilogue=EPI_RESID_GATE, gate=mod[st["ada"][("attn", "gate")]], resid=hid[N:])
+            del att
+
+            # ---- MLP branch (SwiGLU); vid-only in the last block
+            hm = cfg.mlp_hidden
+            ops.rmsnorm_mod(hid[:N], xn[:N], eps, scale=mod[sv["ada"][("mlp", "scale")]],
+                            shift=mod[sv["ada"][("mlp", "shift")]])
+            if not last:
+                ops.rmsnorm_mod(hid[N:], xn[N:], eps, scale=mod[st["ada"][("mlp", "scale")]],
+                                shift=mod[st["ada"][("mlp", "shift")]])
+            gm_v = mod[sv["ada"][("mlp", "gate")]]
+            if shared and not last:
+                ops.gemm(xn, sv["mlp_in"].w, h1, N=2 * hm, K=d, epilogue=EPI_SWIGLU)
+                ops.gemm(h1, sv["mlp_out"].w, hid, N=d, K=hm, epilogue=EPI_RESID_GATE, gate=gm_v, resid=hid)
+            else:
+                ops.gemm(xn[:N], sv["mlp_in"].w, h1[:N], N=2 * hm, K=d, epilogue=EPI_SWIGLU)
+                ops.gemm(h1[:N], sv["mlp_out"].w, hid[:N], N=d, K=hm, epilogue=EPI_RESID_GATE, gate=gm_v,
+                         resid=hid[:N])
+                if not last:
+                    ops.gemm(xn[N:], st["mlp_in"].w, h1[N:], N=2 * hm, K=d, epilogue=EPI_SWIGLU)
+                    ops.gemm(h1[N:], st["mlp_out"].w, hid[N:], N=d, K=hm, epilogue=EPI_RESID_GATE,
+                             gate=mod[st["ada"][("mlp", "gate")]], resid=hid[N:])
+
+        # ---- output head
+        ops.rmsnorm_mod(hid[:N], xn[:N], eps, w=self.out_norm_w, scale=mod[self.ada_out_scale],
+                        shift=mod[self.ada_out_shift])
+        pred = ops.empty(N, cfg.patch_out_dim)
+        ops.gemm(xn[:N], self.vid_out.w, pred, N=cfg.patch_out_dim, K=d, bias=self.vid_out.b)
+        out = ops.empty(T, H, W, cfg.vid_out_channels)
+        ops.unpatchify_euler(pred, None if x_t is None else x_t.contiguous(), out)
+        return out
+
+    # reference-shaped call: NaDiT.forward(vid (L,33), txt (l,5120), vid_shape (1,3), txt_shape, timestep)
+    def __call__(self, vid, txt, vid_shape, txt_shape=None, timestep=1000.0):
+        if vid_shape.shape[0] != 1:
+            raise NotImplementedError("one clip per call (the pipeline calls the DiT with a single-element batch)")
+        T, H, W = (int(v) for v in vid_shape[0].tolist())
+        ts = float(timestep.reshape(-1)[0]) if torch.is_tensor(timestep) else float(timestep)
+        out = self.forward(vid.reshape(T, H, W, -1).to(self.ops.act_dtype), txt.to(self.ops.act_dtype), ts)
+        return NaDiTOutput(vid_sample=out.reshape(T * H * W, -1))

@@ -1,0 +1,133 @@
+"""ctypes binding of libseedvr2_hip.so (the C ABI declared in include/seedvr2_hip.h).
+
+The library is the product: if it is missing or fails to load, every op raises -- there is no
+CPU / eager-PyTorch fallback on purpose (a silent fallback would void every parity claim).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libseedvr2_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "seedvr2_hip.h")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+               "-mllvm", "-pragma-unroll-threshold=1000000"]
+
+EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU = 0, 1, 2, 3
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("enabled", C.c_int32),
+                ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+                ("To", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("kt", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("st", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
+                ("pt", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32),
+                ("halo_frames", C.c_int32),
+                ("halo", C.c_void_p), ("zeros", C.c_void_p)]
+
+
+class PixelShuffle(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("F", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("rz", C.c_int32), ("C", C.c_int32), ("drop_first", C.c_int32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64),
+                ("W", C.c_void_p),
+                ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("bias", C.c_void_p), ("gate", C.c_void_p),
+                ("resid", C.c_void_p), ("ldr", C.c_int64),
+                ("epilogue", C.c_int32), ("out_f32", C.c_int32),
+                ("conv", ConvGeom), ("ps", PixelShuffle)]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/seedvr2_hip.h
+_vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SYMBOLS = {
+    "svr_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "svr_rmsnorm_mod": (C.c_int, [_vp, _vp, _i64, _i32, _f, _vp, _vp, _vp, _vp]),
+    "svr_ada_combine": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "svr_qknorm_rope": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _f, _vp]),
+    "svr_attn_varlen": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f, _vp]),
+    "svr_rows_mean": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "svr_patchify": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "svr_unpatchify_euler": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "svr_groupnorm_stats": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "svr_groupnorm_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _i32, _vp]),
+    "svr_im2col_causal": (C.c_int, [_vp, _vp, C.POINTER(ConvGeom), _i32, _vp]),
+    "svr_blend_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "svr_blend_finalize": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _f, _vp]),
+    "svr_affine_slice": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _f, _f, _vp]),
+    "svr_last_error": (C.c_char_p, []),
+    "svr_abi_version": (C.c_int, []),
+    "svr_device_info": (C.c_int, [C.c_char_p, _i32]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] + [INCLUDE]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    mt = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > mt for s in sources())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source into libseedvr2_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "svr_api.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise HipLibraryError("hipcc failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises HipLibraryError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: the SeedVR2 HIP kernels are not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no CPU fallback.")
+    try:
+        handle = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name} (stale build?)") from e
+        fn.restype, fn.argtypes = res, args
+    if handle.svr_abi_version() != 1:
+        raise HipLibraryError("libseedvr2_hip.so ABI version mismatch; rebuild")
+    _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().svr_last_error()
+        raise HipLibraryError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,247 @@
+"""Torch-tensor front end of the C ABI: validates layouts, passes raw device pointers and the current
+HIP stream.  PyTorch is used for device memory and streams only; all arithmetic happens in
+libseedvr2_hip.so.  Every method raises if the library is missing or a tensor is not on the GPU.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import hip_lib
+from .hip_lib import EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU  # noqa: F401 (re-export)
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class Conv3dGeom:
+    """Causal conv geometry over an NDHWC input (see svr_conv_geom in include/seedvr2_hip.h)."""
+    T: int
+    H: int
+    W: int
+    Cin: int
+    To: int
+    Ho: int
+    Wo: int
+    k: tuple          # (kt, kh, kw)
+    stride: tuple     # (st, sh, sw)
+    pad: tuple        # (pt, ph, pw) front pads
+    halo: Optional[torch.Tensor] = None   # [halo_frames, H, W, Cin] bf16
+
+
+@dataclass
+class PixelShuffleGeom:
+    F: int
+    H: int
+    W: int
+    rz: int
+    C: int
+    drop_first: bool
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipOps:
+    """The product backend.  One instance per device."""
+
+    name = "hip"
+    act_dtype = BF16          # storage dtype of activations
+
+    def __init__(self, device="cuda:0"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise hip_lib.HipLibraryError("HipOps needs a ROCm GPU device (cuda:N); there is no CPU fallback")
+        self.lib = hip_lib.lib()          # raises loudly if the .so is not built
+        with torch.cuda.device(self.device):
+            buf = C.create_string_buffer(256)
+            rc = self.lib.svr_device_info(buf, 256)
+            self.device_info = buf.value.decode()
+            if rc != 0:
+                raise hip_lib.HipLibraryError(f"unsupported device: {self.device_info}")
+        self.zeros = torch.zeros(64, dtype=torch.uint8, device=self.device)
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, t, dtype=None, name="tensor"):
+        if t.device != self.device and not (t.device.type == "cuda" and t.device.index == (self.device.index or 0)):
+            raise ValueError(f"{name} must live on {self.device}, got {t.device}")
+        if dtype is not None and t.dtype != dtype:
+            raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+        return t
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or BF16, device=self.device)
+
+    # ------------------------------------------------------------------ GEMM / conv
+    def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
+             out_f32=False, conv: Optional[Conv3dGeom] = None, ps: Optional[PixelShuffleGeom] = None,
+             lda=None, ldc=None, ldr=None):
+        """out[M, N] = A[M, K] @ W[:N, :K]^T with fused epilogue.  W is [Npad, K] bf16 (Npad % 128 == 0)."""
+        self._chk(A, BF16, "A"); self._chk(W, BF16, "W")
+        self._chk(out, torch.float32 if out_f32 else BF16, "out")
+        if W.shape[1] != K or W.shape[0] < N or W.shape[0] % 128:
+            raise ValueError(f"packed weight shape {tuple(W.shape)} incompatible with N={N}, K={K}")
+        a = hip_lib.GemmArgs()
+        if conv is not None:
+            M = conv.To * conv.Ho * conv.Wo
+            g = a.conv
+            g.enabled = 1
+            g.T, g.H, g.W, g.Cin = conv.T, conv.H, conv.W, conv.Cin
+            g.To, g.Ho, g.Wo = conv.To, conv.Ho, conv.Wo
+            g.kt, g.kh, g.kw = conv.k
+            g.st, g.sh, g.sw = conv.stride
+            g.pt, g.ph, g.pw = conv.pad
+            if conv.halo is not None:
+                self._chk(conv.halo, BF16, "halo")
+                g.halo_frames = conv.halo.shape[0]
+                g.halo = conv.halo.data_ptr()
+            g.zeros = self.zeros.data_ptr()
+            if A.numel() != conv.T * conv.H * conv.W * conv.Cin:
+                raise ValueError("conv input size mismatch")
+            lda = 0
+        else:
+            if M is None:
+                M = A.shape[0]
+            if lda is None:
+                lda = A.stride(0) if A.dim() == 2 else K
+        if ps is not None:
+            a.ps.enabled = 1
+            a.ps.F, a.ps.H, a.ps.W, a.ps.rz, a.ps.C = ps.F, ps.H, ps.W, ps.rz, ps.C
+            a.ps.drop_first = int(ps.drop_first)
+            ldc = 0
+        elif ldc is None:
+            ldc = out.stride(0) if out.dim() == 2 else (N // 2 if epilogue == EPI_SWIGLU else N)
+        a.A, a.lda, a.W, a.C, a.ldc = A.data_ptr(), lda, W.data_ptr(), out.data_ptr(), ldc
+        a.M, a.N, a.K = M, N, K
+        if bias is not None:
+            a.bias = self._chk(bias, torch.float32, "bias").data_ptr()
+        if gate is not None:
+            a.gate = self._chk(gate, torch.float32, "gate").data_ptr()
+        if resid is not None:
+            self._chk(resid, BF16, "resid")
+            a.resid = resid.data_ptr()
+            a.ldr = ldr if ldr is not None else (resid.stride(0) if resid.dim() == 2 else N)
+        a.epilogue, a.out_f32 = epilogue, int(out_f32)
+        hip_lib.check(self.lib.svr_gemm_bf16(C.byref(a), self._stream()), "svr_gemm_bf16")
+        return out
+
+    # ------------------------------------------------------------------ DiT side kernels
+    def rmsnorm_mod(self, x, out, eps, w=None, scale=None, shift=None):
+        self._chk(x, BF16, "x"); self._chk(out, BF16, "out")
+        rows, dim = x.shape
+        hip_lib.check(self.lib.svr_rmsnorm_mod(_ptr(x), _ptr(out), rows, dim, eps, _ptr(w), _ptr(scale), _ptr(shift),
+                                               self._stream()), "svr_rmsnorm_mod")
+        return out
+
+    def ada_combine(self, emb, params, slots, out):
+        self._chk(emb, BF16, "emb"); self._chk(params, BF16, "params")
+        self._chk(slots, torch.int32, "slots"); self._chk(out, torch.float32, "out")
+        n_vec, dim = params.shape
+        hip_lib.check(self.lib.svr_ada_combine(_ptr(emb), _ptr(params), _ptr(slots), _ptr(out), n_vec, dim,
+                                               self._stream()), "svr_ada_combine")
+        return out
+
+    def qknorm_rope(self, qkv, heads, pos, t_offset, cos_tab, sin_tab, wq, wk, eps):
+        self._chk(qkv, BF16, "qkv"); self._chk(pos, torch.int16, "pos")
+        self._chk(cos_tab, torch.float32, "cos_tab"); self._chk(sin_tab, torch.float32, "sin_tab")
+        rows = qkv.shape[0]
+        if qkv.shape[1] != 3 * heads * 128 or pos.shape != (rows, 3):
+            raise ValueError("qknorm_rope: bad shapes")
+        n_pos, n_freq = cos_tab.shape
+        hip_lib.check(self.lib.svr_qknorm_rope(_ptr(qkv), rows, heads, _ptr(pos), t_offset, _ptr(cos_tab),
+                                               _ptr(sin_tab), n_pos, n_freq, _ptr(wq), _ptr(wk), eps,
+                                               self._stream()), "svr_qknorm_rope")
+        return qkv
+
+    def attn_varlen(self, qkv, out, seq_rows, out_rows, cu, max_len, heads, head_dim, scale):
+        self._chk(qkv, BF16, "qkv"); self._chk(out, BF16, "out")
+        for t, n in ((seq_rows, "seq_rows"), (out_rows, "out_rows"), (cu, "cu")):
+            self._chk(t, torch.int32, n)
+        hip_lib.check(self.lib.svr_attn_varlen(_ptr(qkv), qkv.stride(0), _ptr(out), out.stride(0), _ptr(seq_rows),
+                                               _ptr(out_rows), _ptr(cu), cu.numel() - 1, max_len, heads, head_dim,
+                                               scale, self._stream()), "svr_attn_varlen")
+        return out
+
+    def rows_mean(self, src, dst, n_groups, rows_per_group):
+        self._chk(src, BF16, "src"); self._chk(dst, BF16, "dst")
+        hip_lib.check(self.lib.svr_rows_mean(_ptr(src), _ptr(dst), n_groups, rows_per_group, src.shape[-1],
+                                             self._stream()), "svr_rows_mean")
+        return dst
+
+    def patchify(self, vid, out):
+        self._chk(vid, BF16, "vid"); self._chk(out, BF16, "out")
+        T, H, W, Cc = vid.shape
+        hip_lib.check(self.lib.svr_patchify(_ptr(vid), _ptr(out), T, H, W, Cc, out.shape[1], self._stream()),
+                      "svr_patchify")
+        return out
+
+    def unpatchify_euler(self, pred, x_t, out):
+        self._chk(pred, BF16, "pred"); self._chk(out, BF16, "out")
+        T, H, W, Cc = out.shape
+        if x_t is not None:
+            self._chk(x_t, BF16, "x_t")
+        hip_lib.check(self.lib.svr_unpatchify_euler(_ptr(pred), pred.stride(0), _ptr(x_t), _ptr(out), T, H, W, Cc,
+                                                    self._stream()), "svr_unpatchify_euler")
+        return out
+
+    # ------------------------------------------------------------------ VAE side kernels
+    def groupnorm_stats(self, x, stats, groups):
+        self._chk(x, BF16, "x"); self._chk(stats, torch.float64, "stats")
+        T, H, W, Cc = x.shape
+        stats.zero_()
+        hip_lib.check(self.lib.svr_groupnorm_stats(_ptr(x), _ptr(stats), T, H * W, Cc, groups, self._stream()),
+                      "svr_groupnorm_stats")
+        return stats
+
+    def groupnorm_apply(self, x, out, stats, gamma, beta, groups, eps, silu):
+        self._chk(x, BF16, "x"); self._chk(out, BF16, "out")
+        T, H, W, Cc = x.shape
+        hip_lib.check(self.lib.svr_groupnorm_apply(_ptr(x), _ptr(out), _ptr(stats), _ptr(gamma), _ptr(beta), T, H * W,
+                                                   Cc, groups, eps, int(silu), self._stream()), "svr_groupnorm_apply")
+        return out
+
+    def im2col_causal(self, x, out, conv: Conv3dGeom):
+        self._chk(x, BF16, "x"); self._chk(out, BF16, "out")
+        g = hip_lib.ConvGeom()
+        g.enabled = 1
+        g.T, g.H, g.W, g.Cin = conv.T, conv.H, conv.W, conv.Cin
+        g.To, g.Ho, g.Wo = conv.To, conv.Ho, conv.Wo
+        g.kt, g.kh, g.kw = conv.k
+        g.st, g.sh, g.sw = conv.stride
+        g.pt, g.ph, g.pw = conv.pad
+        if conv.halo is not None:
+            g.halo_frames = conv.halo.shape[0]
+            g.halo = self._chk(conv.halo, BF16, "halo").data_ptr()
+        g.zeros = self.zeros.data_ptr()
+        hip_lib.check(self.lib.svr_im2col_causal(_ptr(x), _ptr(out), C.byref(g), out.shape[1], self._stream()),
+                      "svr_im2col_causal")
+        return out
+
+    def blend_accumulate(self, tile, acc, cnt, wy, wx, y0, x0):
+        self._chk(tile, BF16, "tile"); self._chk(acc, torch.float32, "acc"); self._chk(cnt, torch.float32, "cnt")
+        T, h, w, Cc = tile.shape
+        _, H, W, _ = acc.shape
+        hip_lib.check(self.lib.svr_blend_accumulate(_ptr(tile), _ptr(acc), _ptr(cnt), _ptr(wy), _ptr(wx), T, h, w, Cc,
+                                                    H, W, y0, x0, self._stream()), "svr_blend_accumulate")
+
+    def blend_finalize(self, acc, cnt, out, scale=1.0, shift=0.0):
+        self._chk(acc, torch.float32, "acc"); self._chk(out, BF16, "out")
+        T, H, W, Cc = acc.shape
+        hip_lib.check(self.lib.svr_blend_finalize(_ptr(acc), _ptr(cnt), _ptr(out), T, H * W, Cc, out.shape[-1], scale,
+                                                  shift, self._stream()), "svr_blend_finalize")
+        return out
+
+    def affine_slice(self, inp, out, scale=1.0, shift=0.0):
+        self._chk(inp, BF16, "inp"); self._chk(out, BF16, "out")
+        c_in, c_out = inp.shape[-1], out.shape[-1]
+        rows = inp.numel() // c_in
+        hip_lib.check(self.lib.svr_affine_slice(_ptr(inp), _ptr(out), rows, c_in, c_out, scale, shift, self._stream()),
+                      "svr_affine_slice")
+        return out

@@ -1,0 +1,403 @@
+"""Causal-Conv3d video VAE (SeedVR2 "video_vae_v3", s8 / t4 / c16) on MI355X: host orchestration.
+
+Mirrors ``VideoAutoencoderKLWrapper.encode / .decode(x, tiled, tile_size, tile_overlap)``
+(reference: src/models/video_vae_v3/modules/attn_video_vae.py:1680-1699) and the runner-level
+latent scaling of ``VideoDiffusionInfer.vae_encode / vae_decode`` (src/core/infer.py:117-278).
+
+Design (MI355X-first):
+  * activations are NDHWC bf16 ([T, H, W, C]); every convolution is one implicit-GEMM launch that
+    gathers its taps straight from the input tensor -- no im2col, no padded copies, no NCDHW;
+  * the causal temporal head is an index clamp (first slice) or a 1-2 frame halo tensor carried per
+    layer between temporal slices (the reference's per-conv ``memory``, causal_inflation_lib.py:260-278);
+    slices are sized from an activation-byte budget instead of the reference's fixed 4 frames (the
+    result is independent of the slice size), so a 1024-px tile runs as ONE slice;
+  * GroupNorm statistics are per frame (causal_norm_wrapper), fp64-reduced; apply+SiLU is one pass;
+  * residual adds, biases and the 3D pixel-shuffle of Upsample3D are GEMM epilogues;
+  * spatial tiling reproduces tiled_encode / tiled_decode tile for tile (per-tile GroupNorm and
+    attention change results, so this is semantics, not an optimisation); blending accumulates fp32.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .config import VAEConfig
+from .ops import EPI_BIAS, EPI_RESID_GATE, Conv3dGeom, PixelShuffleGeom
+from .packing import pack_conv3d, pack_matrix, pack_vec
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class _Conv:
+    name: str
+    w: torch.Tensor
+    b: torch.Tensor
+    cin: int            # channels the kernel sees (after padding thin inputs)
+    cout: int
+    k: Tuple[int, int, int]
+    stride: Tuple[int, int, int] = (1, 1, 1)
+    pad_lo: int = 1     # spatial zero pad, low side
+    pad_hi: int = 1     # spatial zero pad, high side
+    thin: bool = False  # Cin < 64: im2col + plain GEMM
+
+
+@dataclass
+class _Norm:
+    gamma: torch.Tensor
+    beta: torch.Tensor
+
+
+@dataclass
+class _Resnet:
+    norm1: _Norm
+    conv1: _Conv
+    norm2: _Norm
+    conv2: _Conv
+    shortcut: Optional[_Conv]
+
+
+@dataclass
+class _Attn:
+    norm: _Norm
+    qkv_w: torch.Tensor
+    qkv_b: torch.Tensor
+    out_w: torch.Tensor
+    out_b: torch.Tensor
+    dim: int
+
+
+@dataclass
+class _Up:
+    upscale_w: torch.Tensor
+    upscale_b: torch.Tensor
+    conv: _Conv
+    temporal: bool
+    C: int
+
+
+def _tile_ranges(total: int, tile: int, overlap: int) -> List[Tuple[int, int]]:
+    """Tile starts of tiled_encode / tiled_decode (attn_video_vae.py:1363-1372): stride = tile - overlap,
+    tiles that lie entirely inside the previous tile's overlap are skipped."""
+    stride = max(1, tile - overlap)
+    out = []
+    for s in range(0, total, stride):
+        e = min(s + tile, total)
+        if s > 0 and (e - s) <= overlap:
+            continue
+        out.append((s, e))
+    return out
+
+
+def _edge_weights(length: int, ov: int, fade_lo: bool, fade_hi: bool, ramp: Optional[torch.Tensor]) -> torch.Tensor:
+    w = torch.ones(length, dtype=torch.float32)
+    ov = max(0, min(ov, length - 1))
+    if ov > 0:
+        if fade_lo:
+            w[:ov] = ramp[:ov]
+        if fade_hi:
+            w[-ov:] = 1 - ramp[:ov]
+    return w
+
+
+def _cos_ramp(n: int) -> Optional[torch.Tensor]:
+    if n <= 0:
+        return None
+    return 0.5 - 0.5 * torch.cos(torch.linspace(0, 1, steps=n, dtype=torch.float32) * math.pi)
+
+
+class VideoVAEEngine:
+    def __init__(self, cfg: VAEConfig, state_dict: Dict[str, torch.Tensor], ops,
+                 act_budget_bytes: int = 12 << 30):
+        self.cfg, self.ops = cfg, ops
+        self.device = ops.device
+        self.act_budget_bytes = act_budget_bytes
+        sd, dev = state_dict, ops.device
+        ch = cfg.block_out_channels
+        n = len(ch)
+
+        def conv(name, stride=(1, 1, 1), pad=(1, 1), cin_pad=None):
+            w = sd[name + ".weight"]
+            co, ci, kt, kh, kw = w.shape
+            thin = ci < 64
+            if thin:
+                cin_pad = cin_pad or (ci + 3) // 4 * 4
+            return _Conv(name, pack_conv3d(w, dev, cin_pad), pack_vec(sd[name + ".bias"], dev),
+                         cin_pad or ci, co, (kt, kh, kw), stride, pad[0] if kh > 1 else 0, pad[1] if kh > 1 else 0, thin)
+
+        def norm(name):
+            return _Norm(pack_vec(sd[name + ".weight"], dev), pack_vec(sd[name + ".bias"], dev))
+
+        def resnet(name):
+            sc = conv(name + ".conv_shortcut", pad=(0, 0)) if (name + ".conv_shortcut.weight") in sd else None
+            return _Resnet(norm(name + ".norm1"), conv(name + ".conv1"), norm(name + ".norm2"),
+                           conv(name + ".conv2"), sc)
+
+        def attn(name):
+            c = sd[name + ".to_q.weight"].shape[0]
+            wqkv = torch.cat([sd[name + f".{k}.weight"] for k in ("to_q", "to_k", "to_v")], dim=0)
+            bqkv = torch.cat([sd[name + f".{k}.bias"] for k in ("to_q", "to_k", "to_v")], dim=0)
+            return _Attn(norm(name + ".group_norm"), pack_matrix(wqkv, dev), pack_vec(bqkv, dev),
+                         pack_matrix(sd[name + ".to_out.0.weight"], dev), pack_vec(sd[name + ".to_out.0.bias"], dev), c)
+
+        def mid(name):
+            return (resnet(name + ".resnets.0"), attn(name + ".attentions.0"), resnet(name + ".resnets.1"))
+
+        # ---- encoder (Encoder3D, attn_video_vae.py:671-856)
+        self.enc_conv_in = conv("encoder.conv_in", cin_pad=4)
+        self.enc_down = []
+        for i in range(n):
+            res = [resnet(f"encoder.down_blocks.{i}.resnets.{j}") for j in range(cfg.layers_per_block)]
+            down = None
+            if i != n - 1:
+                temporal = i >= n - cfg.temporal_scale_num - 1
+                down = conv(f"encoder.down_blocks.{i}.downsamplers.0.conv",
+                            stride=(2 if temporal else 1, 2, 2), pad=(0, 1))   # F.pad(0,1,0,1) then pad-0 conv
+            self.enc_down.append((res, down))
+        self.enc_mid = mid("encoder.mid_block")
+        self.enc_norm_out = norm("encoder.conv_norm_out")
+        self.enc_conv_out = conv("encoder.conv_out")
+        # ---- decoder (Decoder3D, attn_video_vae.py:859-1035)
+        self.dec_conv_in = conv("decoder.conv_in")
+        self.dec_mid = mid("decoder.mid_block")
+        self.dec_up = []
+        for i in range(n):
+            res = [resnet(f"decoder.up_blocks.{i}.resnets.{j}") for j in range(cfg.layers_per_block + 1)]
+            up = None
+            if i != n - 1:
+                u = f"decoder.up_blocks.{i}.upsamplers.0"
+                w = sd[u + ".upscale_conv.weight"]
+                up = _Up(pack_matrix(w.reshape(w.shape[0], w.shape[1]), dev), pack_vec(sd[u + ".upscale_conv.bias"], dev),
+                         conv(u + ".conv"), i < cfg.temporal_scale_num, w.shape[1])
+            self.dec_up.append((res, up))
+        self.dec_norm_out = norm("decoder.conv_norm_out")
+        self.dec_conv_out = conv("decoder.conv_out")
+        self._iota = {}
+
+    # ------------------------------------------------------------------ layer primitives
+    def _conv(self, cw: _Conv, x: torch.Tensor, st: dict, first: bool, resid: Optional[torch.Tensor] = None):
+        ops = self.ops
+        T, H, W, Cin = x.shape
+        assert Cin == cw.cin, (cw.name, Cin, cw.cin)
+        kt, kh, kw = cw.k
+        sT, sH, sW = cw.stride
+        carry = kt - sT                                     # frames handed to the next temporal slice
+        halo = None if first else st.get(cw.name)
+        pt = (kt - 1) if first else (halo.shape[0] if halo is not None else 0)
+        if not first and carry > 0 and halo is None:
+            raise RuntimeError(f"{cw.name}: missing temporal halo for a non-initial slice")
+        assert (T + pt - kt) % sT == 0, (cw.name, T, pt)
+        To = (T + pt - kt) // sT + 1
+        Ho = (H + cw.pad_lo + cw.pad_hi - kh) // sH + 1
+        Wo = (W + cw.pad_lo + cw.pad_hi - kw) // sW + 1
+        geom = Conv3dGeom(T, H, W, Cin, To, Ho, Wo, cw.k, cw.stride, (pt, cw.pad_lo, cw.pad_lo), halo)
+        out = ops.empty(To, Ho, Wo, cw.cout)
+        K = cw.w.shape[1]
+        epi = EPI_RESID_GATE if resid is not None else EPI_BIAS
+        if cw.thin:
+            cols = ops.empty(To * Ho * Wo, K)
+            ops.im2col_causal(x, cols, geom)
+            ops.gemm(cols, cw.w, out, N=cw.cout, K=K, M=To * Ho * Wo, bias=cw.b, epilogue=epi, resid=resid,
+                     lda=K, ldc=cw.cout, ldr=cw.cout)
+        else:
+            ops.gemm(x, cw.w, out, N=cw.cout, K=K, bias=cw.b, epilogue=epi, resid=resid, conv=geom,
+                     ldc=cw.cout, ldr=cw.cout)
+        if carry > 0:                                       # per-conv memory for the next slice
+            if T >= carry:
+                st[cw.name] = x[T - carry:].clone()
+            else:
+                prev = halo if halo is not None else x[:1].expand(pt, H, W, Cin)
+                st[cw.name] = torch.cat([prev, x], dim=0)[-carry:].contiguous()
+        return out
+
+    def _gn(self, nm: _Norm, x: torch.Tensor, silu: bool):
+        ops, cfg = self.ops, self.cfg
+        stats = ops.empty(x.shape[0], cfg.norm_num_groups, 2, dtype=torch.float64)
+        ops.groupnorm_stats(x, stats, cfg.norm_num_groups)
+        out = ops.empty(*x.shape)
+        ops.groupnorm_apply(x, out, stats, nm.gamma, nm.beta, cfg.norm_num_groups, cfg.norm_eps, silu)
+        return out
+
+    def _resnet(self, rb: _Resnet, x, st, first):
+        h = self._gn(rb.norm1, x, True)
+        h = self._conv(rb.conv1, h, st, first)
+        h = self._gn(rb.norm2, h, True)
+        sc = self._conv(rb.shortcut, x, st, first) if rb.shortcut is not None else x
+        return self._conv(rb.conv2, h, st, first, resid=sc)
+
+    def _attention(self, ab: _Attn, x):
+        ops = self.ops
+        T, H, W, Cc = x.shape
+        n = H * W
+        y = self._gn(ab.norm, x, False)
+        qkv = ops.empty(T * n, 3 * Cc)
+        ops.gemm(y.reshape(T * n, Cc), ab.qkv_w, qkv, N=3 * Cc, K=Cc, bias=ab.qkv_b)
+        key = (T, n)
+        if key not in self._iota:
+            self._iota[key] = (torch.arange(T * n, dtype=torch.int32, device=self.device),
+                               (torch.arange(T + 1, dtype=torch.int32, device=self.device) * n).contiguous())
+        rows, cu = self._iota[key]
+        att = ops.empty(T * n, Cc)
+        ops.attn_varlen(qkv, att, rows, rows, cu, n, 1, Cc, 1.0 / math.sqrt(Cc))
+        out = ops.empty(T, H, W, Cc)
+        ops.gemm(att, ab.out_w, out, N=Cc, K=Cc, M=T * n, bias=ab.out_b, epilogue=EPI_RESID_GATE,
+                 resid=x, ldc=Cc, ldr=Cc)
+        return out
+
+    def _mid(self, m, x, st, first):
+        x = self._resnet(m[0], x, st, first)
+        x = self._attention(m[1], x)
+        return self._resnet(m[2], x, st, first)
+
+    def _upsample(self, up: _Up, x, st, first):
+        ops = self.ops
+        T, H, W, Cc = x.shape
+        rz = 2 if up.temporal else 1
+        drop = up.temporal and first                       # remove_head on the first slice only
+        To = T * rz - (1 if drop else 0)
+        y = ops.empty(To, 2 * H, 2 * W, Cc)
+        ops.gemm(x.reshape(T * H * W, Cc), up.upscale_w, y, N=4 * rz * Cc, K=Cc, M=T * H * W, bias=up.upscale_b,
+                 ps=PixelShuffleGeom(T, H, W, rz, Cc, drop))
+        return self._conv(up.conv, y, st, first)
+
+    # ------------------------------------------------------------------ one temporal slice through a network
+    def _encoder_slice(self, x, st, first):
+        h = self._conv(self.enc_conv_in, x, st, first)
+        for res, down in self.enc_down:
+            for rb in res:
+                h = self._resnet(rb, h, st, first)
+            if down is not None:
+                h = self._conv(down, h, st, first)
+        h = self._mid(self.enc_mid, h, st, first)
+        h = self._gn(self.enc_norm_out, h, True)
+        return self._conv(self.enc_conv_out, h, st, first)
+
+    def _decoder_slice(self, z, st, first):
+        h = self._conv(self.dec_conv_in, z, st, first)
+        h = self._mid(self.dec_mid, h, st, first)
+        for res, up in self.dec_up:
+            for rb in res:
+                h = self._resnet(rb, h, st, first)
+            if up is not None:
+                h = self._upsample(up, h, st, first)
+        h = self._gn(self.dec_norm_out, h, True)
+        return self._conv(self.dec_conv_out, h, st, first)
+
+    # ------------------------------------------------------------------ temporal slicing (slicing_encode / _decode)
+    def _slices(self, T: int, unit: int, frames_per_slice: int) -> List[Tuple[int, int]]:
+        """first slice = 1 + k*unit frames, then k*unit frames each (attn_video_vae.py:1254-1300 with k=1)."""
+        if T <= 1 + frames_per_slice:
+            return [(0, T)]
+        k = max(unit, frames_per_slice // unit * unit)
+        out = [(0, 1 + k)]
+        s = 1 + k
+        while s < T:
+            out.append((s, min(s + k, T)))
+            s += k
+        return out
+
+    def encode_clip(self, x_thwc: torch.Tensor, frames_per_slice: Optional[int] = None) -> torch.Tensor:
+        """[T, H, W, 4] (RGB + zero pad) -> encoder output h [T', H/8, W/8, 2*latent] (mean || logvar)."""
+        T, H, W, _ = x_thwc.shape
+        assert T == 1 or T % 4 == 1, "clip length must be 4n+1 (VideoAutoencoderKLWrapper.preprocess)"
+        if frames_per_slice is None:
+            per_frame = H * W * self.cfg.block_out_channels[0] * 2
+            frames_per_slice = max(4, int(self.act_budget_bytes // per_frame) // 4 * 4)
+        st, outs = {}, []
+        for i, (a, b) in enumerate(self._slices(T, 4, frames_per_slice)):
+            outs.append(self._encoder_slice(x_thwc[a:b], st, i == 0))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    def decode_clip(self, z_thwc: torch.Tensor, latents_per_slice: Optional[int] = None) -> torch.Tensor:
+        """[T', h, w, 16] -> [T, 8h, 8w, 3]."""
+        Tl, h, w, _ = z_thwc.shape
+        if latents_per_slice is None:
+            s = self.cfg.spatial_downsample_factor
+            per_latent = (h * s) * (w * s) * 2 * self.cfg.block_out_channels[0] * 2 * self.cfg.temporal_downsample_factor
+            latents_per_slice = max(1, int(self.act_budget_bytes // per_latent))
+        st, outs = {}, []
+        for i, (a, b) in enumerate(self._slices(Tl, 1, latents_per_slice)):
+            outs.append(self._decoder_slice(z_thwc[a:b], st, i == 0))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    # ------------------------------------------------------------------ public API (runner level)
+    def _to_thwc4(self, x_cthw: torch.Tensor) -> torch.Tensor:
+        Cc, T, H, W = x_cthw.shape
+        x = torch.zeros(T, H, W, 4, dtype=self.ops.act_dtype, device=self.device)
+        x[..., :Cc] = x_cthw.to(device=self.device, dtype=self.ops.act_dtype).permute(1, 2, 3, 0)   # layout only
+        return x
+
+    @torch.no_grad()
+    def encode(self, x_cthw: torch.Tensor, tiled: bool = False, tile_size=(512, 512), tile_overlap=(64, 64),
+               frames_per_slice: Optional[int] = None) -> torch.Tensor:
+        """[3, T, H, W] in [-1, 1] -> scaled latent [T', H/8, W/8, 16] = (mean - shift) * scale."""
+        cfg, ops = self.cfg, self.ops
+        if x_cthw.dim() == 3:
+            x_cthw = x_cthw.unsqueeze(1)
+        x = self._to_thwc4(x_cthw)
+        T, H, W, _ = x.shape
+        s, lc = cfg.spatial_downsample_factor, cfg.latent_channels
+        if not tiled or (H <= tile_size[0] and W <= tile_size[1]):
+            hfull = self.encode_clip(x, frames_per_slice)
+            out = ops.empty(hfull.shape[0], hfull.shape[1], hfull.shape[2], lc)
+            return ops.affine_slice(hfull, out, cfg.scaling_factor, cfg.shifting_factor)
+        lth, ltw = max(1, tile_size[0] // s), max(1, tile_size[1] // s)
+        loh = max(0, min(tile_overlap[0] // s, lth - 1))
+        low = max(0, min(tile_overlap[1] // s, ltw - 1))
+        Hl, Wl = (H + s - 1) // s, (W + s - 1) // s
+        rh, rw = _cos_ramp(loh), _cos_ramp(low)
+        acc = cnt = None
+        for (y0, y1) in _tile_ranges(Hl, lth, loh):
+            for (x0, x1) in _tile_ranges(Wl, ltw, low):
+                tile = x[:, y0 * s:min(y1 * s, H), x0 * s:min(x1 * s, W)].contiguous()
+                enc = self.encode_clip(tile, frames_per_slice)
+                if acc is None:
+                    acc = torch.zeros(enc.shape[0], Hl, Wl, enc.shape[3], dtype=torch.float32, device=self.device)
+                    cnt = torch.zeros(Hl, Wl, dtype=torch.float32, device=self.device)
+                eh = min(y1 - y0, enc.shape[1], Hl - y0)
+                ew = min(x1 - x0, enc.shape[2], Wl - x0)
+                if (eh, ew) != (enc.shape[1], enc.shape[2]):
+                    enc = enc[:, :eh, :ew].contiguous()
+                wy = _edge_weights(eh, loh, y0 > 0, y1 < Hl, rh).to(self.device)
+                wx = _edge_weights(ew, low, x0 > 0, x1 < Wl, rw).to(self.device)
+                ops.blend_accumulate(enc, acc, cnt, wy, wx, y0, x0)
+        out = ops.empty(acc.shape[0], Hl, Wl, lc)
+        return ops.blend_finalize(acc, cnt, out, cfg.scaling_factor, cfg.shifting_factor)
+
+    @torch.no_grad()
+    def decode(self, latent_thwc: torch.Tensor, tiled: bool = False, tile_size=(512, 512), tile_overlap=(64, 64),
+               latents_per_slice: Optional[int] = None) -> torch.Tensor:
+        """scaled latent [T', h, w, 16] -> sample [3, T, 8h, 8w] (or [3, 8h, 8w] for a single frame)."""
+        cfg, ops = self.cfg, self.ops
+        lat = latent_thwc.to(device=self.device, dtype=self.ops.act_dtype).contiguous()
+        if lat.dim() == 3:
+            lat = lat.unsqueeze(0)
+        Tl, H, W, lc = lat.shape
+        z = ops.empty(Tl, H, W, lc)
+        # latent / scale + shift  ==  (latent - (-shift*scale)) * (1/scale)
+        ops.affine_slice(lat, z, 1.0 / cfg.scaling_factor, -cfg.shifting_factor * cfg.scaling_factor)
+        s = cfg.spatial_downsample_factor
+        lth, ltw = max(1, tile_size[0] // s), max(1, tile_size[1] // s)
+        if not tiled or (H <= lth and W <= ltw):
+            y = self.decode_clip(z, latents_per_slice)
+        else:
+            oh, ow = tile_overlap
+            loh = max(0, min(oh // s, lth - 1))
+            low = max(0, min(ow // s, ltw - 1))
+            rh, rw = _cos_ramp(oh), _cos_ramp(ow)          # decode ramps live in output pixels
+            acc = cnt = None
+            for (y0, y1) in _tile_ranges(H, lth, loh):
+                for (x0, x1) in _tile_ranges(W, ltw, low):
+                    dec = self.decode_clip(z[:, y0:y1, x0:x1].contiguous(), latents_per_slice)
+                    if acc is None:
+                        acc = torch.zeros(dec.shape[0], H * s, W * s, dec.shape[3], dtype=torch.float32, device=self.device)
+                        cnt = torch.zeros(H * s, W * s, dtype=torch.float32, device=self.device)
+                    ho, wo = (y1 - y0) * s, (x1 - x0) * s
+                    wy = _edge_weights(ho, oh, y0 > 0, y1 < H, rh).to(self.device)
+                    wx = _edge_weights(wo, ow, x0 > 0, x1 < W, rw).to(self.device)
+                    ops.blend_accumulate(dec, acc, cnt, wy, wx, y0 * s, x0 * s)
+            y = ops.empty(*acc.shape)
+            ops.blend_finalize(acc, cnt, y, 1.0, 0.0)
+        y = y.permute(3, 0, 1, 2)                           # layout only: [3, T, H, W]
+        return y[:, 0] if y.shape[1] == 1 else y

@@ -1,0 +1,152 @@
+/*
+ * libseedvr2_hip.so -- C ABI of the MI355X (gfx950) SeedVR2 hot path.
+ *
+ * The reference (numz/ComfyUI-SeedVR2_VideoUpscaler) is pure Python/PyTorch and has no FFI
+ * layer; its hot path runs as torch ops below three call sites of the runner
+ * (src/core/infer.py:164-184 vae.encode, :249-266 vae.decode, :361-367 dit forward).  Each entry
+ * point below replaces the torch op sequence cited next to it.  All pointers are raw DEVICE
+ * pointers (tensor.data_ptr()), all tensors are dense row-major, activations bf16 unless noted,
+ * `stream` is a hipStream_t.  Functions return 0 on success, non-zero on failure
+ * (svr_last_error() gives the message).  The library never allocates caller-visible memory.
+ *
+ * Layouts: DiT activations  [tokens, channels]; VAE activations NDHWC = [T, H, W, C].
+ */
+#ifndef SEEDVR2_HIP_H
+#define SEEDVR2_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVR_ABI_VERSION 1
+
+/* ---- GEMM / implicit-GEMM convolution epilogues ------------------------------------------ */
+#define SVR_EPI_BIAS        0   /* C = acc + bias                                              */
+#define SVR_EPI_BIAS_SILU   1   /* C = silu(acc + bias)                 embedding.py:56-61     */
+#define SVR_EPI_RESID_GATE  2   /* C = resid + gate * (acc + bias)      mmsr_block.py:108-109,
+                                   125-126 (AdaSingle "out" + residual); attn_video_vae.py:360 */
+#define SVR_EPI_SWIGLU      3   /* C[:, h] = silu(acc[:, gate h]) * acc[:, in h]; W rows are
+                                   interleaved in blocks of 16 (gate16 | in16)  mlp.py:60-61   */
+
+typedef struct svr_conv_geom {
+    int32_t enabled;            /* 0: plain GEMM, A is [M, K]                                  */
+    int32_t T, H, W, Cin;       /* input  [T, H, W, Cin]                                       */
+    int32_t To, Ho, Wo;         /* output [To, Ho, Wo, N];  M = To*Ho*Wo                       */
+    int32_t kt, kh, kw;         /* kernel taps; W is [Npad, kt*kh*kw*Cin], tap-major, Cin minor */
+    int32_t st, sh, sw;         /* strides                                                     */
+    int32_t pt, ph, pw;         /* front pads: pt causal head frames, ph/pw zero pad (low side;
+                                   reads past H/W on the high side are zero too)               */
+    int32_t halo_frames;        /* frames in `halo` (previous temporal slice tail), 0 = none   */
+    const void* halo;           /* bf16 [halo_frames, H, W, Cin] or NULL: replicate frame 0
+                                   (causal_inflation_lib.py:422-437 extend_head / :260-278)    */
+    const void* zeros;          /* >= 16 zero bytes on the device (spatial padding source)     */
+} svr_conv_geom;
+
+typedef struct svr_pixel_shuffle {
+    int32_t enabled;            /* scatter-store epilogue of Upsample3D.upscale_conv:
+                                   "b (x y z c) f h w -> b c (f z) (h x) (w y)"
+                                   attn_video_vae.py:137-143, + remove_head :152-153           */
+    int32_t F, H, W;            /* input grid (M = F*H*W)                                      */
+    int32_t rz;                 /* temporal ratio 1 | 2 (spatial ratio is always 2)            */
+    int32_t C;                  /* output channels (N = 4*rz*C)                                */
+    int32_t drop_first;         /* 1: drop the duplicated 2nd output frame (first slice only)  */
+} svr_pixel_shuffle;
+
+typedef struct svr_gemm_args {
+    const void* A;  int64_t lda;        /* bf16 [M, K] (ignored rows/K layout when conv.enabled: A = input tensor) */
+    const void* W;                      /* bf16 [Npad, K] row-major (nn.Linear layout), K % 64 == 0,
+                                           Npad = N rounded up to the tile width (128)                       */
+    void* C;        int64_t ldc;        /* bf16 (or fp32 if out_f32) [M, N(/2 for SWIGLU)]                     */
+    int32_t M, N, K;
+    const float* bias;                  /* fp32 [N] or NULL                                                    */
+    const float* gate;                  /* fp32 [N] or NULL (=1)            SVR_EPI_RESID_GATE                 */
+    const void* resid; int64_t ldr;     /* bf16 [M, N] or NULL (may alias C) SVR_EPI_RESID_GATE                */
+    int32_t epilogue;
+    int32_t out_f32;
+    svr_conv_geom conv;
+    svr_pixel_shuffle ps;
+} svr_gemm_args;
+
+/* nn.Linear / F.conv3d replacement (MFMA bf16, fp32 accumulate).
+ * Replaces: every nn.Linear in src/models/dit_3b (mmattn.py:173,269; mlp.py:60-61; patch_v1.py:96,113;
+ * embedding.py:56-61; nadit.py:211) and InflatedCausalConv3d.forward (causal_inflation_lib.py:213-305). */
+int svr_gemm_bf16(const svr_gemm_args* args, void* stream);
+
+/* ---- DiT elementwise / normalisation ------------------------------------------------------- */
+/* y = rms_norm(x) [* w] * scale + shift, per row.  normalization.py:88-109 + modulation.py:110.
+ * x,y bf16 [rows, dim]; w (affine weight) / scale / shift fp32 [dim] or NULL.                  */
+int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps,
+                    const float* w, const float* scale, const float* shift, void* stream);
+
+/* mod[l][i] = emb[i*stride + off(l)] + param[l][i]: builds the fused AdaSingle vectors
+ * (scaleA+scaleB, shiftA+shiftB, gateA+gateB).  modulation.py:76,88-113.
+ * emb bf16 [dim*6] viewed "(d l g)"; params bf16 [n_vec, dim]; slot[n_vec] = l*3+g; out fp32.    */
+int svr_ada_combine(const void* emb, const void* params, const int32_t* slot, float* out,
+                    int32_t n_vec, int32_t dim, void* stream);
+
+/* In-place q/k RMSNorm(head_dim, affine) + 3-axis interleaved-pair RoPE on a packed qkv buffer.
+ * mmattn.py:207-208 + rope.py:118-126,172-173.  qkv bf16 [rows, 3*heads*128]; pos int16 [rows,3];
+ * cs fp32 [n_pos, 2, 63] = cos|sin(pos * freq) table per axis is folded on the host into one
+ * table indexed by position; wq,wk fp32 [128]; t_offset is added to pos[:,0] (text length).     */
+int svr_qknorm_rope(void* qkv, int64_t rows, int32_t heads, const int16_t* pos, int32_t t_offset,
+                    const float* cos_tab, const float* sin_tab, int32_t n_pos, int32_t n_freq,
+                    const float* wq, const float* wk, float eps, void* stream);
+
+/* Variable-length window attention, softmax(q k^T / sqrt(d)) v per window.  attention.py:27-64,
+ * mmattn.py:245-264 (gather by window, text rows appended to every window, scatter back).
+ * qkv bf16 [*, 3*heads*D] (q|k|v); seq_rows int32 [total] = source row of each window position;
+ * out_rows int32 [total] = destination row in `out` (bf16 [*, heads*D]); cu int32 [n_seq+1].       */
+int svr_attn_varlen(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out,
+                    const int32_t* seq_rows, const int32_t* out_rows, const int32_t* cu,
+                    int32_t n_seq, int32_t max_len, int32_t heads, int32_t head_dim, float scale,
+                    void* stream);
+
+/* dst[j] = mean_w src[w*n_txt + j] (text outputs coalesced over windows, na.py:396-417).          */
+int svr_rows_mean(const void* src, void* dst, int32_t n_groups, int32_t rows_per_group, int32_t dim,
+                  void* stream);
+
+/* patchify "(T t)(H h)(W w) c -> T H W (t h w c)" (t,h,w = 1,2,2), zero-padded to kpad columns.
+ * patch_v1.py:91.  in bf16 [T,H,W,C] -> out bf16 [T*(H/2)*(W/2), kpad]                             */
+int svr_patchify(const void* in, void* out, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kpad,
+                 void* stream);
+
+/* un-patchify + one-step Euler endpoint x0 = x_t - pred  (patch_v1.py:119-123, euler.py:60-63,
+ * schedules/base.py:108-110 with A=0,B=1).  pred bf16 [T*(H/2)*(W/2), ldp] (first 4*C cols),
+ * x_t bf16 [T,H,W,C] -> out bf16 [T,H,W,C]; x_t NULL -> out = pred.                                */
+int svr_unpatchify_euler(const void* pred, int64_t ldp, const void* x_t, void* out,
+                         int32_t T, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* ---- VAE elementwise ------------------------------------------------------------------------- */
+/* Per-frame GroupNorm statistics over NDHWC.  causal_inflation_lib.py:366-408.
+ * x bf16 [T, HW, C]; stats fp64 [T, groups, 2] (sum, sumsq) must be zeroed by the caller.         */
+int svr_groupnorm_stats(const void* x, double* stats, int32_t T, int64_t HW, int32_t C, int32_t groups,
+                        void* stream);
+/* y = [silu](gamma * (x - mean) * rstd + beta).  attn_video_vae.py:316-323,343-350.               */
+int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float* gamma, const float* beta,
+                        int32_t T, int64_t HW, int32_t C, int32_t groups, float eps, int32_t apply_silu,
+                        void* stream);
+/* im2col for thin-input causal convs (Cin = 3 / 16): out bf16 [To*Ho*Wo, kpad].                    */
+int svr_im2col_causal(const void* in, void* out, const svr_conv_geom* g, int32_t kpad, void* stream);
+/* acc[T, y0:y0+h, x0:x0+w, C] += tile * wy[h] * wx[w]  (fp32 accumulator; tiled_encode/decode
+ * blending, attn_video_vae.py:1445-1457, 1606-1619) and cnt[y, x] += wy*wx.                       */
+int svr_blend_accumulate(const void* tile, float* acc, float* cnt, const float* wy, const float* wx,
+                         int32_t T, int32_t h, int32_t w, int32_t C, int32_t H, int32_t W,
+                         int32_t y0, int32_t x0, void* stream);
+/* out[..., :c_take] = (acc / max(cnt, 1e-6) - shift) * scale -> bf16.  attn_video_vae.py:1463 + infer.py:188. */
+int svr_blend_finalize(const float* acc, const float* cnt, void* out, int32_t T, int64_t HW, int32_t C,
+                       int32_t c_take, float scale, float shift, void* stream);
+/* out[r, :c_out] = (in[r, :c_out] - shift) * scale   (latent (de)scaling + mean slice, infer.py:188, 236). */
+int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int32_t c_out,
+                     float scale, float shift, void* stream);
+
+/* ---- misc ------------------------------------------------------------------------------------ */
+const char* svr_last_error(void);
+int svr_abi_version(void);
+/* prints device name / CU count into buf; returns 0 if a gfx950 device is current. */
+int svr_device_info(char* buf, int32_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEEDVR2_HIP_H */
