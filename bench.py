@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the SeedVR2 hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|cfg1]
+
+A "step" is one pass of the hot path over one temporal batch of synthetic input already resident in
+HBM:  VAE encode -> one-step DiT (NaDiT-3B, 32 layers) -> VAE decode, i.e. exactly the three runner
+calls the reference pipeline makes per batch (src/core/infer.py:117,315,203).  Workloads
+(BASELINE.json configs):
+    cfg3  33 frames 2160x3840 (720p->4K clip of 32 frames, 4n+1 padded), VAE tiled 1024/128   [metric config]
+    cfg2   9 frames 2048x2048 (8-frame 512^2->2K clip), VAE untiled
+    cfg1   1 frame  256x256
+N > 1: one process per GPU (torchrun), every rank upscales its own temporal batch (weak scaling, no
+data-path collective) and the upscaled bf16 frames are all-gathered over RCCL/xGMI inside the step.
+Rank 0 prints ONE JSON line.  `value` = frames all ranks produced / max-over-ranks wall time.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "comfyui-seedvr2_videoupscaler_amd"
+
+WORKLOADS = {
+    # name: (frames, H, W, vae_tiled, description)
+    "cfg3": (33, 2160, 3840, True, "SeedVR2-3B 33-frame (32+1 pad) 720p->4K clip, VAE tiled 1024/128"),
+    "cfg2": (9, 2048, 2048, False, "SeedVR2-3B 9-frame (8+1 pad) 512^2->2048^2 clip, VAE untiled"),
+    "cfg1": (1, 256, 256, False, "SeedVR2-3B single 256x256 image"),
+}
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16 peak, MI355X_MICROARCH.md
+
+
+def sub(name):
+    return importlib.import_module(f"{PKG}.{name}")
+
+
+def make_profiled_ops(device):
+    """HipOps whose conv implicit-GEMM launches are bracketed by HIP events recorded on the launch
+    stream (torch's current stream IS the stream the C ABI launches on)."""
+    ops_mod = sub("ops")
+
+    class ProfiledOps(ops_mod.HipOps):
+        def __init__(self, device):
+            super().__init__(device)
+            self.recording = False
+            self.events = []        # (kind, flops, start, end)
+
+        def gemm(self, A, W, out, **kw):
+            if not self.recording:
+                return super().gemm(A, W, out, **kw)
+            conv = kw.get("conv")
+            if conv is not None:
+                M = conv.To * conv.Ho * conv.Wo
+                kind = "conv_bn256" if kw["N"] % 256 == 0 else "conv_bn128"
+                flops = 2.0 * M * kw["N"] * conv.k[0] * conv.k[1] * conv.k[2] * conv.Cin
+            else:
+                M = kw.get("M") or A.shape[0]
+                kind = "gemm_bn256" if kw["N"] % 256 == 0 else "gemm_bn128"
+                flops = 2.0 * M * kw["N"] * kw["K"]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = super().gemm(A, W, out, **kw)
+            e.record()
+            self.events.append((kind, flops, s, e))
+            return r
+
+        def summary(self):
+            agg = {}
+            for kind, flops, s, e in self.events:
+                a = agg.setdefault(kind, [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += flops
+                a[2] += s.elapsed_time(e) * 1e-3
+            return {k: {"launches": v[0], "flops": v[1], "seconds": v[2],
+                        "avg_us": v[2] / v[0] * 1e6, "tflops": v[1] / max(v[2], 1e-12) / 1e12} for k, v in agg.items()}
+
+    return ProfiledOps(device)
+
+
+def cpu_baseline(flops_per_frame: float) -> dict:
+    """The CPU oracle (oracle/, a port of the reference's PyTorch path) timed on this host's cores on a
+    bounded sample of the same pipeline; converted to the metric's unit through the algorithmic FLOP
+    ratio (labelled extrapolation).  Test infrastructure used only as a reported baseline."""
+    from oracle import dit_oracle, vae_oracle
+    config, weights, windows, flops = sub("config"), sub("weights"), sub("windows"), sub("flops")
+    cores = torch.get_num_threads()
+    vcfg = config.VAE_V3
+    vsd = {k: v.float() for k, v in weights.synth_vae_state_dict(vcfg).items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(3, 5, 128, 128, generator=g) * 2 - 1
+    t0 = time.perf_counter()
+    lat = vae_oracle.runner_vae_encode(x, vsd, vcfg)
+    vae_oracle.runner_vae_decode(lat, vsd, vcfg)
+    t_vae = time.perf_counter() - t0
+    f_vae = sum(flops.vae_flops_tiled(vcfg, 5, 128, 128, False).values())
+    # 4-layer slice of the 3B-width DiT on a 3x32x32 latent
+    dcfg = config.DiTConfig(num_layers=4, mm_layers=2)
+    dsd = weights.synth_dit_state_dict(dcfg)
+    vid = torch.randn(3, 32, 32, 33, generator=g)
+    txt = weights.synth_text_embedding().float()
+    t0 = time.perf_counter()
+    dit_oracle.dit_forward(dsd, dcfg, vid, txt, 1000.0, windows_mod=windows)
+    t_dit = time.perf_counter() - t0
+    f_dit = flops.dit_flops(dcfg, (3, 16, 16))["total"]
+    tflops = (f_vae + f_dit) / (t_vae + t_dit) / 1e12
+    return {"value": tflops * 1e12 / flops_per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
+            "cpu_tflops": tflops,
+            "sample": f"oracle fp32: full VAE enc+dec of a 5x128x128 clip ({t_vae:.1f}s) + 4-layer 3B-width DiT on a "
+                      f"3x32x32 latent ({t_dit:.1f}s); extrapolated to the workload by algorithmic FLOPs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print per-phase timings to stderr")
+    args = ap.parse_args()
+
+    dist_mod = sub("dist")
+    rank, world, local = dist_mod.init_from_env()
+    if world != args.gpus:
+        if rank == 0 and world > 1:
+            print(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}", file=sys.stderr)
+        args.gpus = world
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+
+    config, weights, flops = sub("config"), sub("weights"), sub("flops")
+    frames, H, W, tiled, desc = WORKLOADS[args.workload]
+    ops = make_profiled_ops(device)
+    dcfg, vcfg = config.DIT_3B, config.VAE_V3
+    # random-init weights of the exact architecture, generated on the GPU (no checkpoints available offline)
+    dit = sub("dit").NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, device=device), ops)
+    vae = sub("vae").VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, device=device), ops)
+    runner_mod = sub("runner")
+    runner = runner_mod.VideoDiffusionInfer(
+        runner_mod.default_config(), encode_tiled=tiled, encode_tile_size=(1024, 1024), encode_tile_overlap=(128, 128),
+        decode_tiled=tiled, decode_tile_size=(1024, 1024), decode_tile_overlap=(128, 128))
+    runner.dit, runner.vae = dit, vae
+    runner.configure_diffusion(device=device, dtype=torch.bfloat16)
+
+    g = torch.Generator(device=device).manual_seed(42 + rank)
+    x = (torch.rand(3, frames, H, W, generator=g, device=device) * 2 - 1).to(torch.bfloat16)
+    Tl, hl, wl = (frames - 1) // 4 + 1, H // 8, W // 8
+    noise = torch.randn(Tl, hl, wl, 16, generator=g, device=device).to(torch.bfloat16)
+    txt = weights.synth_text_embedding(device=device)
+    phase = {"encode": 0.0, "dit": 0.0, "decode": 0.0, "gather": 0.0}
+
+    def step(timed: bool):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
+        if timed: ev[0].record()
+        lat = runner.vae_encode([x])[0]
+        if timed: ev[1].record()
+        cond = runner.get_condition(noise, latent_blur=lat, task="sr")
+        x0 = runner.inference([noise], [cond], [txt], [txt])[0]
+        if timed: ev[2].record()
+        out = runner.vae_decode([x0])[0]                       # [3, T, H, W] view of THWC
+        if timed: ev[3].record()
+        thwc = out.permute(1, 2, 3, 0) if out.dim() == 4 else out.permute(1, 2, 0)[None]
+        gathered = dist_mod.all_gather_frames(thwc.contiguous())
+        if timed: ev[4].record()
+        return gathered, ev
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    ops.recording = True
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, ev = step(True)
+        evs.append(ev)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    ops.recording = False
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax)
+    for ev in evs:
+        for i, k in enumerate(("encode", "dit", "decode", "gather")):
+            phase[k] += ev[i].elapsed_time(ev[i + 1])
+    phase = {k: v / args.steps for k, v in phase.items()}
+
+    if rank == 0:
+        f_dit = flops.dit_flops(dcfg, (Tl, hl // 2, wl // 2))
+        f_vae = flops.vae_flops_tiled(vcfg, frames, H, W, tiled)
+        f_step = f_dit["total"] + f_vae["encode"] + f_vae["decode"]
+        kern = ops.summary()
+        conv = [kern[k] for k in ("conv_bn128", "conv_bn256") if k in kern]
+        c_flops, c_sec, c_n = sum(k["flops"] for k in conv), sum(k["seconds"] for k in conv), sum(k["launches"] for k in conv)
+        roof = {"bound": "mfma", "kernel": "svr::gemm_kernel<.., CONV=true> (implicit-GEMM causal Conv3d, both tile shapes)",
+                "achieved": c_flops / max(c_sec, 1e-12) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": c_flops / max(c_sec, 1e-12) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+                "launches": c_n, "avg_launch_us": c_sec / max(c_n, 1) * 1e6,
+                "algorithmic_flops_per_launch": c_flops / max(c_n, 1),
+                "per_kernel": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 1)}
+                               for k, v in kern.items()}}
+        res = {
+            "metric": "upscaled frames/sec (720p->4K, SeedVR2-3B)" if args.workload == "cfg3"
+                      else f"upscaled frames/sec ({args.workload}, SeedVR2-3B)",
+            "value": world * frames * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "frames_per_step_per_gpu": frames,
+                       "pixels": [H, W], "latent": [Tl, hl, wl], "vae_tiled": tiled, "parallelism": f"dp{world}",
+                       "weights": "random-init SeedVR2-3B + video_vae_v3 architecture (seeded)"},
+            "dit_ms_per_step": phase["dit"], "vae_encode_ms": phase["encode"], "vae_decode_ms": phase["decode"],
+            "allgather_ms": phase["gather"],
+            "algorithmic_tflop_per_step": f_step / 1e12,
+            "achieved_tflops_per_gpu": f_step * args.steps / dt / 1e12,
+            "dit_tflops": f_dit["total"] / max(phase["dit"], 1e-9) / 1e9,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(f_step / frames)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""Algorithmic FLOP counts of the hot path (multiply-add = 2 FLOP), SURVEY.md section 8(d):
+
+  DiT   = L*N*(2*d*3d + 2*d*d + 3*2*d*h_mlp) + sum_layers sum_windows 4*H*dh*(len_w + Lt)^2
+          + 2*N*132*d + 2*N*d*64                       (text-stream GEMMs / elementwise excluded)
+  Conv  = 2*Cin*Cout*kt*kh*kw * To*Ho*Wo                per conv
+  VAEattn = T*(4*C*n^2 + 8*C^2*n), n = h*w per frame
+
+These are the figures ``roofline.achieved`` is computed from (padding FLOPs are NOT counted).
+"""
+from typing import Tuple
+
+import numpy as np
+
+from . import windows
+from .config import DiTConfig, VAEConfig
+
+
+def dit_flops(cfg: DiTConfig, grid: Tuple[int, int, int], Lt: int = 58) -> dict:
+    t, h, w = grid
+    N = t * h * w
+    d, hm = cfg.vid_dim, cfg.mlp_hidden
+    linear = cfg.num_layers * N * (2 * d * 3 * d + 2 * d * d + 3 * 2 * d * hm)
+    linear += 2 * N * cfg.patch_in_dim * d + 2 * N * d * cfg.patch_out_dim
+    attn = 0
+    for li in range(cfg.num_layers):
+        plan = windows.plan_windows(grid, tuple(cfg.window), cfg.window_method(li))
+        lens = np.diff(plan.cu).astype(np.float64) + Lt
+        attn += float((4 * cfg.heads * cfg.head_dim * lens * lens).sum())
+    return {"linear": float(linear), "attn": attn, "total": float(linear) + attn}
+
+
+def conv_flops(cin, cout, k, out_vox) -> float:
+    return 2.0 * cin * cout * k[0] * k[1] * k[2] * out_vox
+
+
+def _resnet(cin, cout, vox):
+    f = conv_flops(cin, cout, (3, 3, 3), vox) + conv_flops(cout, cout, (3, 3, 3), vox)
+    if cin != cout:
+        f += conv_flops(cin, cout, (1, 1, 1), vox)
+    return f
+
+
+def _mid(c, T, h, w):
+    n = h * w
+    return 2 * _resnet(c, c, T * n), T * (4.0 * c * n * n + 8.0 * c * c * n)
+
+
+def vae_encode_flops(cfg: VAEConfig, T: int, H: int, W: int) -> dict:
+    ch = cfg.block_out_channels
+    n = len(ch)
+    conv = conv_flops(cfg.in_channels, ch[0], (3, 3, 3), T * H * W)
+    t, h, w, c = T, H, W, ch[0]
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            conv += _resnet(c if j == 0 else ch[i], ch[i], t * h * w)
+        c = ch[i]
+        if i != n - 1:
+            temporal = i >= n - cfg.temporal_scale_num - 1
+            h, w = (h + 1 - 3) // 2 + 1, (w + 1 - 3) // 2 + 1
+            if temporal:
+                t = (t + 2 - 3) // 2 + 1
+            conv += conv_flops(c, c, (3 if temporal else 1, 3, 3), t * h * w)
+    m_conv, m_attn = _mid(c, t, h, w)
+    conv += m_conv + conv_flops(c, 2 * cfg.latent_channels, (3, 3, 3), t * h * w)
+    return {"conv": conv, "attn": m_attn, "total": conv + m_attn}
+
+
+def vae_decode_flops(cfg: VAEConfig, Tl: int, h: int, w: int) -> dict:
+    ch = list(reversed(cfg.block_out_channels))
+    n = len(ch)
+    t, c = Tl, ch[0]
+    conv = conv_flops(cfg.latent_channels, c, (3, 3, 3), t * h * w)
+    m_conv, m_attn = _mid(c, t, h, w)
+    conv += m_conv
+    for i in range(n):
+        for j in range(cfg.layers_per_block + 1):
+            conv += _resnet(c if j == 0 else ch[i], ch[i], t * h * w)
+        c = ch[i]
+        if i != n - 1:
+            temporal = i < cfg.temporal_scale_num
+            rz = 2 if temporal else 1
+            conv += conv_flops(c, c * 4 * rz, (1, 1, 1), t * h * w)
+            t, h, w = (t * 2 - 1 if temporal else t), h * 2, w * 2
+            conv += conv_flops(c, c, (3, 3, 3), t * h * w)
+    conv += conv_flops(c, cfg.out_channels, (3, 3, 3), t * h * w)
+    return {"conv": conv, "attn": m_attn, "total": conv + m_attn}
+
+
+def _tiles(total, tile, overlap):
+    stride = max(1, tile - overlap)
+    out = []
+    for s in range(0, total, stride):
+        e = min(s + tile, total)
+        if s > 0 and (e - s) <= overlap:
+            continue
+        out.append((s, e))
+    return out
+
+
+def vae_flops_tiled(cfg: VAEConfig, T: int, H: int, W: int, tiled: bool, tile=(1024, 1024), overlap=(128, 128)) -> dict:
+    """Encode + decode FLOPs of one clip [T, H, W] (pixels), with the reference's tile grid if tiled."""
+    s = cfg.spatial_downsample_factor
+    Tl = (T - 1) // cfg.temporal_downsample_factor + 1
+    Hl, Wl = (H + s - 1) // s, (W + s - 1) // s
+    if not tiled or (H <= tile[0] and W <= tile[1]):
+        return {"encode": vae_encode_flops(cfg, T, H, W)["total"], "decode": vae_decode_flops(cfg, Tl, Hl, Wl)["total"]}
+    lth, ltw = tile[0] // s, tile[1] // s
+    loh, low = min(overlap[0] // s, lth - 1), min(overlap[1] // s, ltw - 1)
+    enc = dec = 0.0
+    for (y0, y1) in _tiles(Hl, lth, loh):
+        for (x0, x1) in _tiles(Wl, ltw, low):
+            enc += vae_encode_flops(cfg, T, min(y1 * s, H) - y0 * s, min(x1 * s, W) - x0 * s)["total"]
+            dec += vae_decode_flops(cfg, Tl, y1 - y0, x1 - x0)["total"]
+    return {"encode": enc, "decode": dec}

@@ -1,0 +1,324 @@
+"""-m gpu: per-kernel numerics of the HIP C ABI against the plain-PyTorch fp32 reference of the same op
+(tests/ops_reference.py), same bf16-rounded inputs.
+
+Tolerances (stated here as the contract):
+  * fp32-store test epilogue (``out_f32``): rel-err <= 1e-3 vs the fp32 reference (north-star bound);
+  * production bf16 store: rel-err <= 2.5e-3 (one bf16 rounding of a perfect result is already 1.7e-3);
+  * integer/index kernels (patchify, im2col): bit exact.
+rel-err = ||a - b||_2 / ||b||_2.
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import sub, rel_err
+from ops_reference import TorchOps, EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+TOL_BF16 = 2.5e-3
+TOL_F32 = 1e-3
+
+
+@pytest.fixture(scope="module")
+def hip():
+    ops = sub("ops")
+    return ops.HipOps("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return TorchOps("cuda:0", act_dtype=torch.float32)
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=BF16):
+    g = torch.Generator(device="cuda").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g, device="cuda") * scale).to(dtype)
+
+
+def packed(n, k, seed=1):
+    packing = sub("packing")
+    w = rnd(n, k, scale=1.0 / math.sqrt(k), seed=seed)
+    return w, packing.pack_matrix(w, "cuda")
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 256), (257, 64, 192), (1, 2560, 256),
+                                   (513, 384, 64), (2048, 1536, 2560)])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_gemm_bias(hip, ref, M, N, K, out_f32):
+    A = rnd(M, K)
+    w, W = packed(N, K)
+    bias = rnd(N, dtype=torch.float32, seed=3)
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32 if out_f32 else BF16)
+    hip.gemm(A, W, out, N=N, K=K, bias=bias, out_f32=out_f32)
+    want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias)
+    assert rel_err(out.float(), want) < (TOL_F32 if out_f32 else TOL_BF16)
+
+
+def test_gemm_transpose_detecting(hip):
+    """A = I against an asymmetric W must return W^T rows exactly (catches swapped C/D layouts)."""
+    K = N = 256
+    A = torch.eye(K, device="cuda", dtype=BF16)
+    w = (torch.arange(N * K, device="cuda").reshape(N, K) % 251).to(BF16)
+    W = sub("packing").pack_matrix(w, "cuda")
+    out = torch.empty(K, N, device="cuda", dtype=BF16)
+    hip.gemm(A, W, out, N=N, K=K)
+    assert torch.equal(out, w.t().contiguous())
+
+
+def test_gemm_epilogues(hip, ref):
+    M, N, K = 777, 512, 320
+    A = rnd(M, K)
+    w, W = packed(N, K)
+    bias = rnd(N, dtype=torch.float32, seed=3)
+    gate = rnd(N, dtype=torch.float32, seed=4)
+    resid = rnd(M, N, seed=5)
+    for epi, kw in ((EPI_BIAS_SILU, {}), (EPI_RESID_GATE, dict(gate=gate, resid=resid)),
+                    (EPI_RESID_GATE, dict(resid=resid)), (EPI_RESID_GATE, dict(gate=gate))):
+        out = torch.empty(M, N, device="cuda", dtype=BF16)
+        hip.gemm(A, W, out, N=N, K=K, bias=bias, epilogue=epi, **kw)
+        want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias, epilogue=epi, **kw)
+        assert rel_err(out.float(), want) < TOL_BF16, epi
+    # in-place residual (C aliases resid), row-sliced views as the DiT uses them
+    buf = rnd(M + 58, N, seed=6)
+    want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE,
+                    gate=gate, resid=buf[:M].clone())
+    tail = buf[M:].clone()
+    hip.gemm(A, W, buf[:M], N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE, gate=gate, resid=buf[:M])
+    assert rel_err(buf[:M].float(), want) < TOL_BF16
+    assert torch.equal(buf[M:], tail)
+
+
+def test_gemm_swiglu(hip, ref):
+    packing = sub("packing")
+    M, K, Hd = 515, 256, 768
+    A = rnd(M, K)
+    wg, wi = rnd(Hd, K, scale=1 / 16, seed=7), rnd(Hd, K, scale=1 / 16, seed=8)
+    W = packing.pack_swiglu(wg, wi, "cuda")
+    out = torch.empty(M, Hd, device="cuda", dtype=BF16)
+    hip.gemm(A, W, out, N=2 * Hd, K=K, epilogue=EPI_SWIGLU)
+    want = torch.nn.functional.silu(A.float() @ wg.float().t()) * (A.float() @ wi.float().t())
+    assert rel_err(out.float(), want) < TOL_BF16
+    # and the reference double agrees with the closed form (keeps the two test backends honest)
+    w2 = ref.gemm(A, W, torch.empty(M, Hd, device="cuda"), N=2 * Hd, K=K, epilogue=EPI_SWIGLU)
+    assert rel_err(w2, want) < 1e-5
+
+
+# ------------------------------------------------------------------ implicit-GEMM causal conv
+CONV_CASES = [
+    # Cin, Cout, k, stride, pad(lo,hi), T, H, W, halo_frames
+    (128, 128, (3, 3, 3), (1, 1, 1), (1, 1), 3, 10, 12, 0),
+    (128, 128, (3, 3, 3), (1, 1, 1), (1, 1), 2, 9, 7, 2),
+    (128, 256, (3, 3, 3), (1, 1, 1), (1, 1), 5, 8, 8, 0),
+    (256, 256, (3, 3, 3), (2, 2, 2), (0, 1), 5, 12, 10, 0),
+    (256, 256, (3, 3, 3), (2, 2, 2), (0, 1), 4, 12, 10, 1),
+    (128, 128, (1, 3, 3), (1, 2, 2), (0, 1), 3, 14, 16, 0),
+    (512, 256, (1, 1, 1), (1, 1, 1), (0, 0), 3, 6, 5, 0),
+    (512, 32, (3, 3, 3), (1, 1, 1), (1, 1), 2, 6, 7, 0),
+    (128, 3, (3, 3, 3), (1, 1, 1), (1, 1), 3, 9, 11, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_implicit_gemm(hip, ref, case):
+    packing, opsmod = sub("packing"), sub("ops")
+    Cin, Cout, k, stride, (plo, phi), T, H, W, hf = case
+    kt, kh, kw = k
+    x = rnd(T, H, W, Cin)
+    halo = rnd(hf, H, W, Cin, seed=9) if hf else None
+    w5 = rnd(Cout, Cin, kt, kh, kw, scale=1.0 / math.sqrt(Cin * kt * kh * kw), seed=2)
+    Wp = packing.pack_conv3d(w5, "cuda")
+    bias = rnd(Cout, dtype=torch.float32, seed=3)
+    pt = hf if hf else kt - 1
+    To = (T + pt - kt) // stride[0] + 1
+    Ho = (H + plo + phi - kh) // stride[1] + 1
+    Wo = (W + plo + phi - kw) // stride[2] + 1
+    geom = opsmod.Conv3dGeom(T, H, W, Cin, To, Ho, Wo, k, stride, (pt, plo, plo), halo)
+    resid = rnd(To, Ho, Wo, Cout, seed=11)
+    out = torch.empty(To, Ho, Wo, Cout, device="cuda", dtype=BF16)
+    hip.gemm(x, Wp, out, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, epilogue=EPI_RESID_GATE, resid=resid,
+             ldc=Cout, ldr=Cout)
+    want = ref.gemm(x, Wp, torch.empty(To, Ho, Wo, Cout, device="cuda"), N=Cout, K=Wp.shape[1], bias=bias,
+                    conv=geom, epilogue=EPI_RESID_GATE, resid=resid)
+    # independent check of the reference double itself against F.conv3d semantics of the causal conv
+    head = halo.float() if hf else x[:1].float().expand(pt, H, W, Cin)
+    xin = torch.cat([head, x.float()], 0).permute(3, 0, 1, 2)[None]
+    xin = torch.nn.functional.pad(xin, (plo, phi, plo, phi))
+    y = torch.nn.functional.conv3d(xin, w5.float(), bias, stride=stride)[0].permute(1, 2, 3, 0) + resid.float()
+    assert rel_err(want, y) < 1e-5
+    assert rel_err(out.float(), want) < TOL_BF16
+
+
+@pytest.mark.parametrize("rz,drop", [(1, False), (2, False), (2, True)])
+def test_upscale_pixel_shuffle_epilogue(hip, ref, rz, drop):
+    packing, opsmod = sub("packing"), sub("ops")
+    F_, H, W, Cc = 3, 5, 6, 256
+    x = rnd(F_ * H * W, Cc)
+    w, Wp = packed(4 * rz * Cc, Cc)
+    bias = rnd(4 * rz * Cc, dtype=torch.float32, seed=3)
+    ps = opsmod.PixelShuffleGeom(F_, H, W, rz, Cc, drop)
+    To = F_ * rz - (1 if drop else 0)
+    out = torch.full((To, 2 * H, 2 * W, Cc), float("nan"), device="cuda", dtype=BF16)
+    hip.gemm(x, Wp, out, N=4 * rz * Cc, K=Cc, M=F_ * H * W, bias=bias, ps=ps)
+    want = ref.gemm(x, Wp, torch.empty(To, 2 * H, 2 * W, Cc, device="cuda"), N=4 * rz * Cc, K=Cc, M=F_ * H * W,
+                    bias=bias, ps=ps)
+    # closed form: "b (x y z c) f h w -> b c (f z) (h x) (w y)"
+    y = (x.float() @ w.float().t() + bias).reshape(F_, H, W, 2, 2, rz, Cc)
+    y = y.permute(0, 5, 1, 3, 2, 4, 6).reshape(F_ * rz, 2 * H, 2 * W, Cc)
+    if drop:
+        y = torch.cat([y[:1], y[2:]], 0)
+    assert rel_err(want, y) < 1e-5
+    assert not torch.isnan(out.float()).any()
+    assert rel_err(out.float(), want) < TOL_BF16
+
+
+# ------------------------------------------------------------------ DiT side kernels
+@pytest.mark.parametrize("rows,dim", [(1000, 2560), (58, 2560), (333, 256), (7, 3072)])
+def test_rmsnorm_mod(hip, ref, rows, dim):
+    x = rnd(rows, dim, scale=2.0)
+    w, sc, sh = (rnd(dim, dtype=torch.float32, seed=s) for s in (1, 2, 3))
+    for kw in (dict(), dict(scale=sc, shift=sh), dict(w=w, scale=sc, shift=sh)):
+        out = torch.empty(rows, dim, device="cuda", dtype=BF16)
+        hip.rmsnorm_mod(x, out, 1e-5, **kw)
+        want = ref.rmsnorm_mod(x, torch.empty(rows, dim, device="cuda"), 1e-5, **kw)
+        assert rel_err(out.float(), want) < TOL_BF16
+
+
+def test_ada_combine(hip, ref):
+    dim, nv = 2560, 13
+    emb, params = rnd(dim * 6), rnd(nv, dim, seed=2)
+    slots = torch.tensor([0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 1], dtype=torch.int32, device="cuda")
+    out = torch.empty(nv, dim, device="cuda", dtype=torch.float32)
+    hip.ada_combine(emb, params, slots, out)
+    want = ref.ada_combine(emb, params, slots, torch.empty(nv, dim, device="cuda"))
+    assert torch.allclose(out, want, atol=1e-6)
+
+
+def _rope_tables(n_pos):
+    freqs = sub("weights").rope_freqs_lang(42)
+    ang = torch.arange(n_pos, dtype=torch.float32)[:, None] * freqs[None, :]
+    return ang.cos().cuda().contiguous(), ang.sin().cuda().contiguous()
+
+
+def test_qknorm_rope(hip, ref):
+    rows, heads = 500, 20
+    qkv = rnd(rows, 3 * heads * 128)
+    g = torch.Generator().manual_seed(0)
+    pos = torch.stack([torch.randint(0, 4, (rows,), generator=g), torch.randint(0, 15, (rows,), generator=g),
+                       torch.randint(0, 27, (rows,), generator=g)], -1).to(torch.int16).cuda()
+    cos, sin = _rope_tables(100)
+    wq, wk = rnd(128, dtype=torch.float32, seed=1) + 1, rnd(128, dtype=torch.float32, seed=2) + 1
+    want = ref.qknorm_rope(qkv.float().clone(), heads, pos, 58, cos, sin, wq, wk, 1e-5)
+    got = qkv.clone()
+    hip.qknorm_rope(got, heads, pos, 58, cos, sin, wq, wk, 1e-5)
+    assert torch.equal(got[:, 2 * heads * 128:], qkv[:, 2 * heads * 128:])          # V untouched
+    assert rel_err(got.float(), want) < TOL_BF16
+
+
+def _attn_case(lens, heads, D, n_rows, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    seq_rows, out_rows, cu = [], [], [0]
+    o = 0
+    for L in lens:
+        seq_rows.append(torch.randint(0, n_rows, (L,), generator=g))
+        out_rows.append(torch.arange(o, o + L))
+        o += L
+        cu.append(o)
+    to = lambda t: torch.cat(t).to(torch.int32).cuda()
+    return to(seq_rows), to(out_rows), torch.tensor(cu, dtype=torch.int32).cuda(), o
+
+
+@pytest.mark.parametrize("lens,heads,D", [([135, 64, 1, 200, 129, 1273], 3, 128), ([314], 20, 128),
+                                          ([100, 33, 257], 1, 512)])
+def test_attn_varlen(hip, ref, lens, heads, D):
+    n_rows = 1500
+    qkv = rnd(n_rows, 3 * heads * D)
+    seq_rows, out_rows, cu, total = _attn_case(lens, heads, D, n_rows)
+    scale = 1.0 / math.sqrt(D)
+    out = torch.zeros(total, heads * D, device="cuda", dtype=BF16)
+    hip.attn_varlen(qkv, out, seq_rows, out_rows, cu, max(lens), heads, D, scale)
+    want = ref.attn_varlen(qkv, torch.zeros(total, heads * D, device="cuda"), seq_rows, out_rows, cu, max(lens),
+                           heads, D, scale)
+    assert rel_err(out.float(), want) < 4e-3       # P is rounded to bf16 before PV (as flash kernels do)
+
+
+def test_attn_varlen_spiky_scores(hip, ref):
+    """Forces the online-softmax rescale: one key dominates late in the sequence."""
+    heads, D, L = 2, 128, 400
+    qkv = rnd(L, 3 * heads * D, scale=0.5)
+    qkv[300, heads * D:2 * heads * D] = qkv[5, :heads * D] * 8          # k[300] aligned with q[5]
+    rows = torch.arange(L, dtype=torch.int32, device="cuda")
+    cu = torch.tensor([0, L], dtype=torch.int32, device="cuda")
+    out = torch.zeros(L, heads * D, device="cuda", dtype=BF16)
+    hip.attn_varlen(qkv, out, rows, rows, cu, L, heads, D, 1.0 / math.sqrt(D))
+    want = ref.attn_varlen(qkv, torch.zeros(L, heads * D, device="cuda"), rows, rows, cu, L, heads, D, 1.0 / math.sqrt(D))
+    assert rel_err(out.float(), want) < 4e-3
+
+
+def test_rows_mean_patchify_unpatchify(hip, ref):
+    src = rnd(7 * 58, 2560)
+    dst = torch.empty(58, 2560, device="cuda", dtype=BF16)
+    hip.rows_mean(src, dst, 7, 58)
+    assert rel_err(dst.float(), ref.rows_mean(src, torch.empty(58, 2560, device="cuda"), 7, 58)) < TOL_BF16
+    vid = rnd(3, 8, 12, 33)
+    out = torch.empty(3 * 4 * 6, 192, device="cuda", dtype=BF16)
+    hip.patchify(vid, out)
+    assert torch.equal(out, ref.patchify(vid, torch.empty(3 * 4 * 6, 192, device="cuda", dtype=BF16)))
+    pred, x_t = rnd(3 * 4 * 6, 64), rnd(3, 8, 12, 16, seed=4)
+    for xt in (x_t, None):
+        o = torch.empty(3, 8, 12, 16, device="cuda", dtype=BF16)
+        hip.unpatchify_euler(pred, xt, o)
+        assert rel_err(o.float(), ref.unpatchify_euler(pred, xt, torch.empty(3, 8, 12, 16, device="cuda"))) < TOL_BF16
+
+
+# ------------------------------------------------------------------ VAE side kernels
+@pytest.mark.parametrize("C", [128, 256, 512])
+def test_groupnorm(hip, ref, C):
+    T, H, W = 3, 37, 41
+    x = rnd(T, H, W, C, scale=1.5) + 0.7
+    gamma, beta = rnd(C, dtype=torch.float32, seed=1) + 1, rnd(C, dtype=torch.float32, seed=2)
+    stats = torch.empty(T, 32, 2, device="cuda", dtype=torch.float64)
+    hip.groupnorm_stats(x, stats, 32)
+    want_stats = ref.groupnorm_stats(x, torch.empty(T, 32, 2, device="cuda", dtype=torch.float64), 32)
+    assert torch.allclose(stats, want_stats, rtol=1e-5)
+    for silu in (True, False):
+        out = torch.empty_like(x)
+        hip.groupnorm_apply(x, out, stats, gamma, beta, 32, 1e-6, silu)
+        want = ref.groupnorm_apply(x, torch.empty(T, H, W, C, device="cuda"), want_stats, gamma, beta, 32, 1e-6, silu)
+        gn = torch.nn.functional.group_norm(x.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-6).permute(0, 2, 3, 1)
+        assert rel_err(want, torch.nn.functional.silu(gn) if silu else gn) < 1e-4
+        assert rel_err(out.float(), want) < TOL_BF16
+
+
+@pytest.mark.parametrize("Cin,kpad,hf", [(4, 128, 0), (4, 128, 2), (16, 448, 0)])
+def test_im2col_causal(hip, ref, Cin, kpad, hf):
+    opsmod = sub("ops")
+    T, H, W = 3, 9, 10
+    x = rnd(T, H, W, Cin)
+    halo = rnd(hf, H, W, Cin, seed=5) if hf else None
+    geom = opsmod.Conv3dGeom(T, H, W, Cin, T, H, W, (3, 3, 3), (1, 1, 1), (2, 1, 1), halo)
+    out = torch.empty(T * H * W, kpad, device="cuda", dtype=BF16)
+    hip.im2col_causal(x, out, geom)
+    assert torch.equal(out, ref.im2col_causal(x, torch.empty(T * H * W, kpad, device="cuda", dtype=BF16), geom))
+
+
+def test_blend_and_affine(hip, ref):
+    T, h, w, C, H, W = 2, 5, 6, 32, 9, 11
+    tile = rnd(T, h, w, C)
+    wy, wx = torch.rand(h, device="cuda"), torch.rand(w, device="cuda")
+    acc, cnt = torch.zeros(T, H, W, C, device="cuda"), torch.zeros(H, W, device="cuda")
+    acc2, cnt2 = acc.clone(), cnt.clone()
+    for (y0, x0) in ((0, 0), (3, 4), (4, 5)):
+        hip.blend_accumulate(tile, acc, cnt, wy, wx, y0, x0)
+        ref.blend_accumulate(tile, acc2, cnt2, wy, wx, y0, x0)
+    assert torch.allclose(acc, acc2, atol=1e-5) and torch.allclose(cnt, cnt2, atol=1e-6)
+    out = torch.empty(T, H, W, 16, device="cuda", dtype=BF16)
+    hip.blend_finalize(acc, cnt, out, 0.9152, 0.1)
+    want = ref.blend_finalize(acc2, cnt2, torch.empty(T, H, W, 16, device="cuda"), 0.9152, 0.1)
+    assert rel_err(out.float(), want) < TOL_BF16
+    inp = rnd(50, 32)
+    o = torch.empty(50, 16, device="cuda", dtype=BF16)
+    hip.affine_slice(inp, o, 1 / 0.9152, -0.05)
+    assert rel_err(o.float(), ref.affine_slice(inp, torch.empty(50, 16, device="cuda"), 1 / 0.9152, -0.05)) < TOL_BF16

