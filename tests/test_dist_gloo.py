@@ -1,0 +1,63 @@
+"""-m "not gpu": the N>1 path (batch sharding + all-gather of frames) with 2 gloo processes on CPU."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import sub, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_batches, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from conftest import sub as _sub
+    d = _sub("dist")
+    r, w, _ = d.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    owned_idx = d.batch_indices(n_batches, r, w)
+    # "upscaled frames" of batch b: a [2, 3, 4, 3] tensor filled with b (bf16 like the product)
+    owned = [torch.full((2, 3, 4, 3), float(b), dtype=torch.bfloat16) for b in owned_idx]
+    full = d.gather_batches(owned, owned_idx, n_batches)
+    ok = all(float(full[b].float().mean()) == float(b) for b in range(n_batches))
+    g = d.all_gather_frames(torch.full((2, 3, 4, 3), float(rank), dtype=torch.bfloat16))
+    ok = ok and g.shape == (2 * world, 3, 4, 3) and float(g[2 * rank].float().mean()) == rank
+    q.put((rank, ok, owned_idx))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_batches", [4, 5])
+def test_two_rank_batch_sharding_and_allgather(n_batches):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_batches, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    owned = sorted(sum((idx for _, _, idx in res), []))
+    assert owned == list(range(n_batches))            # every batch owned exactly once
+
+
+def test_split_frames_and_round_robin():
+    d = sub("dist")
+    assert d.split_frames(128, 17) == [(i * 17, min((i + 1) * 17, 128)) for i in range(8)]
+    assert d.batch_indices(8, 3, 8) == [3] and d.batch_indices(5, 1, 2) == [1, 3]
