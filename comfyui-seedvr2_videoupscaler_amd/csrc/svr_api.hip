@@ -6,6 +6,7 @@
 
 // single translation unit: the kernel sources are included here so one hipcc call builds the library
 #include "svr_gemm.hip"
+#include "svr_gemm_pipe.hip"
 #include "svr_attn.hip"
 #include "svr_elementwise.hip"
 
@@ -28,6 +29,13 @@ extern "C" {
 
 const char* svr_last_error(void) { return g_err; }
 int svr_abi_version(void) { return SVR_ABI_VERSION; }
+
+int svr_set_option(const char* key, int32_t value) {
+    if (!key) return fail("svr_set_option: null key");
+    if (!strcmp(key, "gemm_impl")) { g_gemm_impl = value; return 0; }
+    if (!strcmp(key, "pipe_abl")) { g_pipe_abl = value; return 0; }
+    return fail("svr_set_option: unknown key");
+}
 
 int svr_device_info(char* buf, int32_t buflen) {
     int dev = 0;

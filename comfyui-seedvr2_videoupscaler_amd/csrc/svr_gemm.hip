@@ -19,6 +19,8 @@
 // groups of 4 row-panels x all column panels.
 #include "svr_common.h"
 #include "../../include/seedvr2_hip.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace svr {
 
@@ -279,6 +281,21 @@ static int launch(const svr_gemm_args& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// pipelined 256x256x64 kernel (svr_gemm_pipe.hip)
+template <bool CONV> static int launch_pipe(const svr_gemm_args& a, hipStream_t s);
+static bool pipe_eligible(const svr_gemm_args& a);
+
+// Kernel selection (svr_set_option("gemm_impl", v); env SVR_GEMM_IMPL seeds it): 0 = auto (the
+// measured-best kernel per problem class), 1 = one-barrier-per-K-tile kernel everywhere,
+// 2 = pipelined kernel wherever it is eligible.  Used by A/B measurements and the kernel tests.
+int g_gemm_impl = [] { const char* e = getenv("SVR_GEMM_IMPL"); return e ? atoi(e) : 0; }();
+int g_pipe_abl = [] { const char* e = getenv("SVR_PIPE_ABL"); return e ? atoi(e) : 0; }();
+static bool use_pipe_kernel(const svr_gemm_args& a) {
+    if (g_gemm_impl == 1) return false;
+    if (g_gemm_impl == 2) return true;
+    return false;      // auto: the pipelined kernel does not beat the simple one yet (profiles/kbench_r1_ab.txt)
+}
+
 int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     *why = nullptr;
     if (a.M <= 0 || a.N <= 0) return 0;
@@ -295,6 +312,8 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     if (a.ps.enabled && (a.N != 4 * a.ps.rz * a.ps.C || a.M != a.ps.F * a.ps.H * a.ps.W || (a.ps.C % 4) != 0)) {
         *why = "svr_gemm_bf16: bad pixel-shuffle geometry"; return -1;
     }
+    if (pipe_eligible(a) && use_pipe_kernel(a))
+        return a.conv.enabled ? launch_pipe<true>(a, s) : launch_pipe<false>(a, s);
     const bool wide = (a.N % 256) == 0;     // otherwise W is padded to a multiple of 128 rows
     if (a.conv.enabled) {
         return wide ? launch<256, 256, 128, 64, true>(a, s) : launch<256, 128, 64, 64, true>(a, s);

@@ -63,6 +63,7 @@ SYMBOLS = {
     "svr_blend_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "svr_blend_finalize": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _f, _vp]),
     "svr_affine_slice": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _f, _f, _vp]),
+    "svr_set_option": (C.c_int, [C.c_char_p, _i32]),
     "svr_last_error": (C.c_char_p, []),
     "svr_abi_version": (C.c_int, []),
     "svr_device_info": (C.c_int, [C.c_char_p, _i32]),

@@ -76,6 +76,10 @@ class HipOps:
             raise ValueError(f"{name} must be contiguous")
         return t
 
+    def set_option(self, key: str, value: int):
+        """Tuning / measurement knob of the library (see svr_set_option in include/seedvr2_hip.h)."""
+        hip_lib.check(self.lib.svr_set_option(key.encode(), int(value)), "svr_set_option")
+
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or BF16, device=self.device)
 

@@ -141,6 +141,9 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
                      float scale, float shift, void* stream);
 
 /* ---- misc ------------------------------------------------------------------------------------ */
+/* Tuning / measurement knobs (no effect on results): "gemm_impl" 0 auto | 1 simple | 2 pipelined,
+ * "pipe_abl" measurement-only ablations of the pipelined kernel (non-zero values give garbage). */
+int svr_set_option(const char* key, int32_t value);
 const char* svr_last_error(void);
 int svr_abi_version(void);
 /* prints device name / CU count into buf; returns 0 if a gfx950 device is current. */

@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmark at the hot path's real shapes (cfg3): one line per kernel with HIP-event
+timings and algorithmic TFLOP/s or GB/s.  Also the target of the rocprofv3 --pmc passes
+(tools/gpu_pmc.sh), so kernel names / launch counts here are what profiles/ refers to.
+
+    python tools/kbench.py [--reps 5] [--only conv,gemm,attn,side]
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "comfyui-seedvr2_videoupscaler_amd"
+sub = lambda n: importlib.import_module(f"{PKG}.{n}")
+BF16 = torch.bfloat16
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="conv,gemm,attn,side")
+    args = ap.parse_args()
+    only = set(args.only.split(","))
+    ops_mod, packing = sub("ops"), sub("packing")
+    ops = ops_mod.HipOps("cuda:0")
+    dev = ops.device
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: (torch.rand(*s, generator=g, device=dev) * 2 - 1).to(BF16)
+    out = []
+
+    def report(name, sec, flops=None, bytes_=None):
+        r = {"kernel": name, "us": round(sec * 1e6, 1)}
+        if flops:
+            r["tflops"] = round(flops / sec / 1e12, 1)
+        if bytes_:
+            r["gbps"] = round(bytes_ / sec / 1e9, 1)
+        out.append(r)
+        print(json.dumps(r), flush=True)
+
+    if "conv" in only:
+        # (name, T, H, W, Cin, Cout): the shapes that carry the VAE FLOPs at cfg3 (1024-px tiles)
+        for name, T, H, W, Ci, Co in (("conv3x3x3 128->128 @1024^2", 5, 1024, 1024, 128, 128),
+                                      ("conv3x3x3 256->128 @1024^2", 5, 1024, 1024, 256, 128),
+                                      ("conv3x3x3 256->256 @512^2", 9, 512, 512, 256, 256),
+                                      ("conv3x3x3 512->256 @512^2", 9, 512, 512, 512, 256),
+                                      ("conv3x3x3 512->512 @256^2", 9, 256, 256, 512, 512)):
+            x = rnd(T, H, W, Ci)
+            w = packing.pack_conv3d(torch.randn(Co, Ci, 3, 3, 3, generator=g, device=dev) / math.sqrt(27 * Ci), dev)
+            b = torch.zeros(Co, dtype=torch.float32, device=dev)
+            y = ops.empty(T, H, W, Co)
+            geom = ops_mod.Conv3dGeom(T, H, W, Ci, T, H, W, (3, 3, 3), (1, 1, 1), (2, 1, 1), None)
+            sec = timeit(lambda: ops.gemm(x, w, y, N=Co, K=27 * Ci, bias=b, conv=geom, ldc=Co), args.reps)
+            report(name, sec, flops=2.0 * T * H * W * Co * 27 * Ci)
+            del x, w, y
+    if "gemm" in only:
+        M = 291600
+        for name, N, K, epi in (("gemm qkv 2560->7680", 7680, 2560, ops_mod.EPI_BIAS),
+                                ("gemm attn-out 2560->2560 (+gate,resid)", 2560, 2560, ops_mod.EPI_RESID_GATE),
+                                ("gemm mlp-in swiglu 2560->2x6912", 13824, 2560, ops_mod.EPI_SWIGLU),
+                                ("gemm mlp-out 6912->2560 (+gate,resid)", 2560, 6912, ops_mod.EPI_RESID_GATE)):
+            a = rnd(M, K)
+            w = packing.pack_matrix(torch.randn(N, K, generator=g, device=dev) / math.sqrt(K), dev)
+            nout = N // 2 if epi == ops_mod.EPI_SWIGLU else N
+            c = ops.empty(M, nout)
+            kw = {}
+            if epi == ops_mod.EPI_RESID_GATE:
+                kw = dict(gate=torch.ones(N, dtype=torch.float32, device=dev), resid=rnd(M, N))
+            sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, epilogue=epi, **kw), args.reps)
+            report(name, sec, flops=2.0 * M * N * K)
+            del a, w, c, kw
+    if "attn" in only:
+        windows, config = sub("windows"), sub("config")
+        for method in ("720pwin_by_size_bysize", "720pswin_by_size_bysize"):
+            size, Lt, heads = (9, 135, 240), 58, 20
+            plan = windows.plan_windows(size, (4, 3, 3), method)
+            N = size[0] * size[1] * size[2]
+            import numpy as np
+            lens = np.diff(plan.cu)
+            seq = np.concatenate([np.concatenate([plan.tok[plan.cu[i]:plan.cu[i + 1]], N + np.arange(Lt)])
+                                  for i in range(plan.n_win)]).astype(np.int32)
+            outr = np.concatenate([np.concatenate([plan.tok[plan.cu[i]:plan.cu[i + 1]], N + Lt + i * Lt + np.arange(Lt)])
+                                   for i in range(plan.n_win)]).astype(np.int32)
+            cu = np.concatenate([[0], np.cumsum(lens + Lt)]).astype(np.int32)
+            qkv = rnd(N + Lt, 3 * heads * 128)
+            att = ops.empty(N + Lt + plan.n_win * Lt, heads * 128)
+            t_seq, t_out, t_cu = (torch.from_numpy(v).to(dev) for v in (seq, outr, cu))
+            sec = timeit(lambda: ops.attn_varlen(qkv, att, t_seq, t_out, t_cu, int(lens.max()) + Lt, heads, 128,
+                                                 1 / math.sqrt(128)), args.reps)
+            fl = sum(4.0 * heads * 128 * float(l + Lt) ** 2 for l in lens)
+            report(f"attn window {method} ({plan.n_win} windows)", sec, flops=fl)
+            del qkv, att
+        # VAE mid-block attention on one 1024-px tile: 9 frames x (128*128) tokens, 1 head of 512
+        T, n, Cc = 9, 128 * 128, 512
+        qkv = rnd(T * n, 3 * Cc)
+        att = ops.empty(T * n, Cc)
+        rows = torch.arange(T * n, dtype=torch.int32, device=dev)
+        cu = (torch.arange(T + 1, dtype=torch.int32, device=dev) * n).contiguous()
+        sec = timeit(lambda: ops.attn_varlen(qkv, att, rows, rows, cu, n, 1, Cc, 1 / math.sqrt(Cc)), max(1, args.reps // 2))
+        report("attn VAE mid (9 x 16384 tokens, d=512)", sec, flops=4.0 * Cc * n * n * T)
+        del qkv, att
+    if "side" in only:
+        T, H, W, Cc = 5, 1024, 1024, 128
+        x = rnd(T, H, W, Cc)
+        y = ops.empty(T, H, W, Cc)
+        stats = ops.empty(T, 32, 2, dtype=torch.float64)
+        gam = torch.ones(Cc, dtype=torch.float32, device=dev)
+        sec = timeit(lambda: ops.groupnorm_stats(x, stats, 32), args.reps)
+        report("groupnorm_stats 5x1024^2x128", sec, bytes_=x.numel() * 2)
+        sec = timeit(lambda: ops.groupnorm_apply(x, y, stats, gam, gam, 32, 1e-6, True), args.reps)
+        report("groupnorm_apply+silu 5x1024^2x128", sec, bytes_=x.numel() * 4)
+        del x, y
+        M, d = 291600, 2560
+        x = rnd(M, d)
+        y = ops.empty(M, d)
+        sc = torch.ones(d, dtype=torch.float32, device=dev)
+        sec = timeit(lambda: ops.rmsnorm_mod(x, y, 1e-5, scale=sc, shift=sc), args.reps)
+        report("rmsnorm_mod 291600x2560", sec, bytes_=x.numel() * 4)
+    return out
+
+
+if __name__ == "__main__":
+    main()
