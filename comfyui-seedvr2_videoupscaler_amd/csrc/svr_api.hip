@@ -7,6 +7,7 @@
 // single translation unit: the kernel sources are included here so one hipcc call builds the library
 #include "svr_gemm.hip"
 #include "svr_gemm_pipe.hip"
+#include "svr_conv_halo.hip"
 #include "svr_attn.hip"
 #include "svr_elementwise.hip"
 
@@ -34,6 +35,7 @@ int svr_set_option(const char* key, int32_t value) {
     if (!key) return fail("svr_set_option: null key");
     if (!strcmp(key, "gemm_impl")) { g_gemm_impl = value; return 0; }
     if (!strcmp(key, "pipe_abl")) { g_pipe_abl = value; return 0; }
+    if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
     return fail("svr_set_option: unknown key");
 }
 

@@ -285,6 +285,11 @@ static int launch(const svr_gemm_args& a, hipStream_t s) {
 template <bool CONV> static int launch_pipe(const svr_gemm_args& a, hipStream_t s);
 static bool pipe_eligible(const svr_gemm_args& a);
 
+// LDS-halo conv kernel (svr_conv_halo.hip)
+template <int BN> static int launch_conv_halo(const svr_gemm_args& a, hipStream_t s);
+static bool conv_halo_eligible(const svr_gemm_args& a);
+int g_conv_impl = [] { const char* e = getenv("SVR_CONV_IMPL"); return e ? atoi(e) : 0; }();   // 0 auto, 1 generic
+
 // Kernel selection (svr_set_option("gemm_impl", v); env SVR_GEMM_IMPL seeds it): 0 = auto (the
 // measured-best kernel per problem class), 1 = one-barrier-per-K-tile kernel everywhere,
 // 2 = pipelined kernel wherever it is eligible.  Used by A/B measurements and the kernel tests.
@@ -312,6 +317,8 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     if (a.ps.enabled && (a.N != 4 * a.ps.rz * a.ps.C || a.M != a.ps.F * a.ps.H * a.ps.W || (a.ps.C % 4) != 0)) {
         *why = "svr_gemm_bf16: bad pixel-shuffle geometry"; return -1;
     }
+    if (g_conv_impl != 1 && conv_halo_eligible(a))
+        return launch_conv_halo<128>(a, s);   // (the 256-wide variant needs > 256 VGPRs; 128-wide tiles cost 13 % more staging)
     if (pipe_eligible(a) && use_pipe_kernel(a))
         return a.conv.enabled ? launch_pipe<true>(a, s) : launch_pipe<false>(a, s);
     const bool wide = (a.N % 256) == 0;     // otherwise W is padded to a multiple of 128 rows

@@ -142,6 +142,7 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
 
 /* ---- misc ------------------------------------------------------------------------------------ */
 /* Tuning / measurement knobs (no effect on results): "gemm_impl" 0 auto | 1 simple | 2 pipelined,
+ * "conv_impl" 0 auto (LDS-halo kernel for stride-1 3x3 convs) | 1 generic implicit GEMM everywhere,
  * "pipe_abl" measurement-only ablations of the pipelined kernel (non-zero values give garbage). */
 int svr_set_option(const char* key, int32_t value);
 const char* svr_last_error(void);

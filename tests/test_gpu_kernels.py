@@ -143,6 +143,11 @@ CONV_CASES = [
     (512, 256, (1, 1, 1), (1, 1, 1), (0, 0), 3, 6, 5, 0),
     (512, 32, (3, 3, 3), (1, 1, 1), (1, 1), 2, 6, 7, 0),
     (128, 3, (3, 3, 3), (1, 1, 1), (1, 1), 3, 9, 11, 2),
+    # LDS-halo kernel: several 8x32 patches with ragged edges, 2 and 4 channel slices, 1x3x3, N tiles
+    (128, 128, (3, 3, 3), (1, 1, 1), (1, 1), 3, 21, 70, 0),
+    (256, 128, (3, 3, 3), (1, 1, 1), (1, 1), 2, 17, 33, 2),
+    (128, 384, (3, 3, 3), (1, 1, 1), (1, 1), 2, 8, 64, 0),
+    (192, 128, (1, 3, 3), (1, 1, 1), (1, 1), 2, 9, 31, 0),
 ]
 
 
@@ -174,6 +179,33 @@ def test_conv3d_implicit_gemm(hip, ref, case):
     y = torch.nn.functional.conv3d(xin, w5.float(), bias, stride=stride)[0].permute(1, 2, 3, 0) + resid.float()
     assert rel_err(want, y) < 1e-5
     assert rel_err(out.float(), want) < TOL_BF16
+
+
+def test_conv3d_halo_kernel_race_screen_and_generic_agreement(hip):
+    """The LDS-halo conv keeps loads in flight across barriers: repeated launches must be bit-identical,
+    and it must agree with the generic implicit-GEMM kernel (same K order => same fp32 sums up to
+    MFMA-shape-dependent rounding)."""
+    packing, opsmod = sub("packing"), sub("ops")
+    T, H, W, Cin, Cout = 4, 96, 160, 256, 256
+    x = rnd(T, H, W, Cin)
+    w5 = rnd(Cout, Cin, 3, 3, 3, scale=1.0 / math.sqrt(Cin * 27), seed=2)
+    Wp = packing.pack_conv3d(w5, "cuda")
+    bias = rnd(Cout, dtype=torch.float32, seed=3)
+    geom = opsmod.Conv3dGeom(T, H, W, Cin, T, H, W, (3, 3, 3), (1, 1, 1), (2, 1, 1), None)
+    outs = []
+    for _ in range(3):
+        out = torch.empty(T, H, W, Cout, device="cuda", dtype=torch.float32)
+        hip.gemm(x, Wp, out, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, out_f32=True)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    hip.set_option("conv_impl", 1)
+    try:
+        gen = torch.empty(T, H, W, Cout, device="cuda", dtype=torch.float32)
+        hip.gemm(x, Wp, gen, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, out_f32=True)
+    finally:
+        hip.set_option("conv_impl", 0)
+    assert rel_err(outs[0], gen) < 1e-5
 
 
 @pytest.mark.parametrize("rz,drop", [(1, False), (2, False), (2, True)])
