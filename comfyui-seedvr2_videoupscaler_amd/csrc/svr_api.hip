@@ -122,12 +122,21 @@ int svr_unpatchify_euler(const void* pred, int64_t ldp, const void* x_t, void* o
     return check(hipGetLastError(), "svr_unpatchify_euler");
 }
 
-int svr_groupnorm_stats(const void* x, double* stats, int32_t T, int64_t HW, int32_t C, int32_t groups, void* stream) {
+int64_t svr_groupnorm_workspace_bytes(int32_t T, int64_t HW, int32_t groups) {
+    return (int64_t)T * blocks_for(HW, GN_ROWS_PER_BLOCK) * groups * 16;
+}
+
+int svr_groupnorm_stats(const void* x, double* stats, void* workspace, int32_t T, int64_t HW, int32_t C, int32_t groups,
+                        void* stream) {
     if (T <= 0 || HW <= 0) return 0;
-    if (C % 8 || C > 512 || (C / groups) % 4 || (256 % (C / 8)))
-        return fail("svr_groupnorm_stats: need C in {128,256,512}-like (C%8==0, C<=512, (C/groups)%4==0)");
-    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(blocks_for(HW, 2048), T), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, stats, HW, C, groups);
+    if (C % 8 || C > 512 || groups > 32 || (C / groups) % 4 || (256 % (C / 8)))
+        return fail("svr_groupnorm_stats: need C in {128,256,512}-like (C%8==0, C<=512, groups<=32, (C/groups)%4==0)");
+    if (!workspace) return fail("svr_groupnorm_stats: workspace missing (svr_groupnorm_workspace_bytes)");
+    const unsigned nblk = blocks_for(HW, GN_ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (double2*)workspace, HW, C, groups);
+    hipLaunchKernelGGL(groupnorm_reduce_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream,
+                       (const double2*)workspace, stats, (int)nblk, groups);
     return check(hipGetLastError(), "svr_groupnorm_stats");
 }
 

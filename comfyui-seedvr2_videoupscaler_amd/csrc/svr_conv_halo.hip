@@ -44,7 +44,9 @@ constexpr int CH_D = 3;                                   // weight prefetch dis
 
 template <int N> SVR_DEVICE void ch_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BN>
+// ABL: measurement-only ablations (svr_set_option("pipe_abl")): 1 = no staging inside the K loop,
+// 2 = no MFMA, 3 = MFMA only (no staging, fragment reads or barriers in the loop).  Garbage results.
+template <int BN, int ABL>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
     constexpr int HBN = BN / 128;                         // weight units per tap
     constexpr int PPS = 9 * HBN;                          // intervals per A step
@@ -186,8 +188,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-                    acc[HB][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][ks], af[mt][ks], acc[HB][mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NTW; ++nt) {
+                    if constexpr (ABL != 2)
+                        acc[HB][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][ks], af[mt][ks], acc[HB][mt][nt], 0, 0, 0);
+                    else { asm volatile("" ::"v"(wf[nt][ks])); asm volatile("" ::"v"(af[mt][ks])); }
+                }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
         ch_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
     }
-    if (grp == 0) {                                       // group 0 reads one interval ahead
+    if (grp == 0 || ABL == 3) {                           // group 0 reads one interval ahead
         reads(std::integral_constant<int, 0>{}, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -218,17 +223,19 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
         const int k = s * PPS + J;
         if (grp == 0) {
             mfmas(jc);
-            if constexpr (J + 1 < PPS) reads(std::integral_constant<int, J + 1>{}, s, k + 1);
-            else if (s + 1 < nA) reads(std::integral_constant<int, 0>{}, s + 1, k + 1);
+            if constexpr (ABL != 3) {
+                if constexpr (J + 1 < PPS) reads(std::integral_constant<int, J + 1>{}, s, k + 1);
+                else if (s + 1 < nA) reads(std::integral_constant<int, 0>{}, s + 1, k + 1);
+            }
         } else {
-            reads(jc, s, k);
+            if constexpr (ABL != 3) reads(jc, s, k);
         }
         // loads of this interval: halo piece J of step s+1, weight unit k + CH_D
         bool a_issued = false;
-        if constexpr (J < CH_PIECES) {
+        if constexpr (J < CH_PIECES && ABL != 1 && ABL != 3) {
             if (s + 1 < nA) a_issued = stage_a_piece(std::integral_constant<int, (J < CH_PIECES ? J : 0)>{}, fnext, (s + 1) & 1);
         }
-        const bool b_issued = k + CH_D < P;
+        const bool b_issued = k + CH_D < P && ABL != 1 && ABL != 3;
         if (b_issued) {
             constexpr int JU = (J + CH_D) % PPS;
             stage_b(s + (J + CH_D) / PPS, JU / HBN, JU % HBN, (k + CH_D) & (CH_NB - 1));
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
         __builtin_amdgcn_sched_barrier(0);
         if (grp == 1) mfmas(jc);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (ABL != 3) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -267,33 +274,79 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
         }
     }
 
-    // ---- epilogue.  32x32 tile: lane holds C[voxel = lane & 31][cout = 8 q + 4 (lane >> 5) + 0..3]
+    // ---- epilogue through LDS (BN == 128): the MFMA layout gives each lane 4 couts of 32 different
+    // voxels (8-byte stores scattered over 32 cache lines, and the same for the residual loads), so the
+    // fp32 tile (+ bias) is parked in LDS [256 voxels][132 floats] and written back row-contiguous:
+    // 16 lanes cover one voxel's 128 couts, every global access is a full 16-byte lane / 256-byte row.
+    static_assert(BN == 128, "LDS epilogue is written for the 128-cout tile");
+    constexpr int EP_PITCH = 528;                         // 128 floats + 16 B pad: conflict-free b128 writes
     const int hi4 = hi * 4;
+    {
+        f32x4 bv[NTW][4];
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) {
-        const int y = y0 + wm * MTW + mt, x = x0 + l31;
-        const bool ok = y < g.H && x < g.W;
-        const int m = (to * g.H + y) * g.W + x;
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-        for (int hb = 0; hb < HBN; ++hb)
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + wn * 64 + nt * 32 + 8 * gq + hi4;
+                bv[nt][gq] = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            char* row = smem + ((wm * MTW + mt) * 32 + l31) * EP_PITCH;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                const f32x16_t v = acc[hb][mt][nt];
+                const f32x16_t v = acc[0][mt][nt];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    const int n = n0 + hb * 128 + (BN == 256 ? wn * 32 : wn * 64 + nt * 32) + 8 * gq + hi4;
-                    const f32x4 accv = {v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
-                    if (ok && n < a.N) epilogue_store(a, accv, accv, m, n);
+                    f32x4 o = {v[4 * gq] + bv[nt][gq][0], v[4 * gq + 1] + bv[nt][gq][1],
+                               v[4 * gq + 2] + bv[nt][gq][2], v[4 * gq + 3] + bv[nt][gq][3]};
+                    if (a.epilogue == SVR_EPI_BIAS_SILU) { o[0] = silu(o[0]); o[1] = silu(o[1]); o[2] = silu(o[2]); o[3] = silu(o[3]); }
+                    *(f32x4*)(row + (wn * 64 + nt * 32 + 8 * gq + hi4) * 4) = o;
                 }
             }
+        }
+    }
+    __syncthreads();
+    const bool resid_gate = a.epilogue == SVR_EPI_RESID_GATE;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int id = it * 512 + tid;
+        const int vox = id >> 4, ch = id & 15;            // voxel of the patch, 8-cout chunk
+        const int y = y0 + (vox >> 5), x = x0 + (vox & 31);
+        if (y >= g.H || x >= g.W) continue;
+        const int64_t m = ((int64_t)to * g.H + y) * g.W + x;
+        const int n = n0 + ch * 8;
+        const f32x4 lo = *(const f32x4*)(smem + vox * EP_PITCH + ch * 32);
+        const f32x4 hi_ = *(const f32x4*)(smem + vox * EP_PITCH + ch * 32 + 16);
+        float f[8] = {lo[0], lo[1], lo[2], lo[3], hi_[0], hi_[1], hi_[2], hi_[3]};
+        if (resid_gate) {
+            if (a.gate) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] *= a.gate[n + e];
+            }
+            if (a.resid) {
+                const uint4 rr = *(const uint4*)((const bf16_t*)a.resid + m * a.ldr + n);
+                float r8[8];
+                unpack8(rr, r8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += r8[e];
+            }
+        }
+        if (a.out_f32) {
+            float* cp = (float*)a.C + m * a.ldc + n;
+            *(float4*)cp = make_float4(f[0], f[1], f[2], f[3]);
+            *(float4*)(cp + 4) = make_float4(f[4], f[5], f[6], f[7]);
+        } else {
+            *(uint4*)((bf16_t*)a.C + m * a.ldc + n) = pack8(f);
+        }
     }
 }
 
-template <int BN>
-static int launch_conv_halo(const svr_gemm_args& a, hipStream_t s) {
+template <int BN, int ABL>
+static int launch_conv_halo_abl(const svr_gemm_args& a, hipStream_t s) {
     const svr_conv_geom& g = a.conv;
     const int tiles = g.To * ((g.H + CH_TY - 1) / CH_TY) * ((g.W + CH_TX - 1) / CH_TX) * (a.N / BN);
-    auto kern = conv_halo_kernel<BN>;
+    auto kern = conv_halo_kernel<BN, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
@@ -304,6 +357,19 @@ static int launch_conv_halo(const svr_gemm_args& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+template <int BN>
+static int launch_conv_halo(const svr_gemm_args& a, hipStream_t s) {
+#ifdef SVR_ABLATIONS
+    switch (g_pipe_abl) {
+        case 1: return launch_conv_halo_abl<BN, 1>(a, s);
+        case 2: return launch_conv_halo_abl<BN, 2>(a, s);
+        case 3: return launch_conv_halo_abl<BN, 3>(a, s);
+        default: break;
+    }
+#endif
+    return launch_conv_halo_abl<BN, 0>(a, s);
+}
+
 // stride-1 "same" 3x3 spatial kernel (1 or 3 temporal taps), channels in 64-slices, N in 128-tiles,
 // plain bias / residual epilogue, bf16 or fp32 store
 static bool conv_halo_eligible(const svr_gemm_args& a) {
@@ -311,6 +377,7 @@ static bool conv_halo_eligible(const svr_gemm_args& a) {
     return g.enabled && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.st == 1 && g.ph == 1 && g.pw == 1 &&
            g.Ho == g.H && g.Wo == g.W && g.Cin % 64 == 0 && (a.N % 128) == 0 && g.kt >= 1 && g.kt <= 3 &&
            g.To == g.T + g.pt - g.kt + 1 && !a.ps.enabled && a.epilogue != SVR_EPI_SWIGLU &&
+           (a.ldc % 8) == 0 && (!a.resid || (a.ldr % 8) == 0) &&
            (int64_t)g.H * g.W * g.Cin * 2 < (int64_t)1 << 32;
 }
 

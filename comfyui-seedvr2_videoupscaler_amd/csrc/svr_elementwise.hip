@@ -170,13 +170,17 @@ __global__ void unpatchify_euler_kernel(const bf16_t* __restrict__ pred, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-frame GroupNorm over NDHWC.  Statistics in fp32 per thread, fp64 across threads/blocks.
+// Per-frame GroupNorm over NDHWC.  Statistics: fp32 per thread over a fixed row set, then fixed-order
+// fp64 reductions (inside the block through LDS, across blocks by a second kernel) -- no atomics, so
+// the result is bit-reproducible and independent of how the clip is cut into temporal slices.
 // ------------------------------------------------------------------------------------------------
 constexpr int GN_ROWS_PER_BLOCK = 2048;
 
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x, double* __restrict__ stats,
+// partial[(t * nblk + blockIdx.x) * groups + g] = {sum, sum of squares} of this block's rows
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x, double2* __restrict__ partial,
                                                               int64_t HW, int C, int groups) {
-    __shared__ float lsum[256], lsq[256];           // indexed by 4-channel quad (C/4 <= 256)
+    __shared__ float red[256][4];
+    __shared__ double qsum[128][2];                 // per 4-channel quad (C/4 <= 128)
     const int t = blockIdx.y;
     const int cchunks = C >> 3;                     // 16-byte chunks per row
     const int tid = threadIdx.x;
@@ -184,8 +188,6 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
     const int rstep = 256 / cchunks;
     const int64_t r0 = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK;
     const int64_t r1 = min(r0 + GN_ROWS_PER_BLOCK, HW);
-    if (tid < 256) { lsum[tid] = 0.f; lsq[tid] = 0.f; }
-    __syncthreads();
     float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
     const bf16_t* base = x + ((int64_t)t * HW) * C + cc * 8;
     for (int64_t r = r0 + tid / cchunks; r < r1; r += rstep) {
@@ -197,18 +199,49 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
         s1 += f[4] + f[5] + f[6] + f[7];
         q1 += f[4] * f[4] + f[5] * f[5] + f[6] * f[6] + f[7] * f[7];
     }
-    atomicAdd(&lsum[cc * 2], s0); atomicAdd(&lsq[cc * 2], q0);
-    atomicAdd(&lsum[cc * 2 + 1], s1); atomicAdd(&lsq[cc * 2 + 1], q1);
+    red[tid][0] = s0; red[tid][1] = q0; red[tid][2] = s1; red[tid][3] = q1;
+    __syncthreads();
+    if (tid < cchunks * 2) {                        // quad = chunk * 2 + half: fixed-order sum over the row lanes
+        const int c = tid >> 1, h = tid & 1;
+        double s = 0.0, q = 0.0;
+        for (int j = 0; j < rstep; ++j) {
+            s += (double)red[j * cchunks + c][2 * h];
+            q += (double)red[j * cchunks + c][2 * h + 1];
+        }
+        qsum[tid][0] = s; qsum[tid][1] = q;
+    }
     __syncthreads();
     const int quads_per_group = (C / groups) >> 2;  // channels per group / 4 (>= 1)
     if (tid < groups) {
         double s = 0.0, q = 0.0;
         for (int i = 0; i < quads_per_group; ++i) {
-            s += (double)lsum[tid * quads_per_group + i];
-            q += (double)lsq[tid * quads_per_group + i];
+            s += qsum[tid * quads_per_group + i][0];
+            q += qsum[tid * quads_per_group + i][1];
         }
-        atomicAdd(&stats[((int64_t)t * groups + tid) * 2], s);
-        atomicAdd(&stats[((int64_t)t * groups + tid) * 2 + 1], q);
+        partial[((int64_t)t * gridDim.x + blockIdx.x) * groups + tid] = make_double2(s, q);
+    }
+}
+
+// stats[t][g] = fixed-order sum of the nblk block partials.  One block per frame, 8 lanes per group.
+__global__ __launch_bounds__(256) void groupnorm_reduce_kernel(const double2* __restrict__ partial, double* __restrict__ stats,
+                                                               int nblk, int groups) {
+    const int t = blockIdx.x;
+    const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
+    double s = 0.0, q = 0.0;
+    if (g < groups) {
+        for (int b = l; b < nblk; b += 8) {
+            const double2 v = partial[((int64_t)t * nblk + b) * groups + g];
+            s += v.x; q += v.y;
+        }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {               // fixed tree over the 8 lanes of a group
+        s += __shfl_down(s, o, 8);
+        q += __shfl_down(q, o, 8);
+    }
+    if (g < groups && l == 0) {
+        stats[((int64_t)t * groups + g) * 2] = s;
+        stats[((int64_t)t * groups + g) * 2 + 1] = q;
     }
 }
 

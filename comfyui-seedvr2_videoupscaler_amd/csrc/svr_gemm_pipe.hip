@@ -310,17 +310,7 @@ static int launch_pipe_abl(const svr_gemm_args& a, hipStream_t s) {
 template <bool CONV>
 static int launch_pipe(const svr_gemm_args& a, hipStream_t s) {
     const int abl = g_pipe_abl;
-    if constexpr (!CONV) {                // ablation builds exist for the plain GEMM only
-        switch (abl) {
-            case 1: return launch_pipe_abl<false, 1>(a, s);
-            case 2: return launch_pipe_abl<false, 2>(a, s);
-            case 3: return launch_pipe_abl<false, 3>(a, s);
-            case 4: return launch_pipe_abl<false, 4>(a, s);
-            case 5: return launch_pipe_abl<false, 5>(a, s);
-            case 6: return launch_pipe_abl<false, 6>(a, s);
-            default: break;
-        }
-    }
+    (void)abl;   // the ablation variants (ABL 1..6) are not instantiated in product builds
     return launch_pipe_abl<CONV, 0>(a, s);
 }
 

@@ -57,7 +57,8 @@ SYMBOLS = {
     "svr_rows_mean": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "svr_patchify": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "svr_unpatchify_euler": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "svr_groupnorm_stats": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "svr_groupnorm_workspace_bytes": (C.c_int64, [_i32, _i64, _i32]),
+    "svr_groupnorm_stats": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "svr_groupnorm_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _i32, _vp]),
     "svr_im2col_causal": (C.c_int, [_vp, _vp, C.POINTER(ConvGeom), _i32, _vp]),
     "svr_blend_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -94,7 +95,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, "svr_api.hip"), "-o", LIB_PATH]
+    extra = ["-DSVR_ABLATIONS"] if os.environ.get("SVR_BUILD_ABLATIONS") else []   # measurement-only kernel variants
+    cmd = [hipcc] + HIPCC_FLAGS + extra + [os.path.join(CSRC, "svr_api.hip"), "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)

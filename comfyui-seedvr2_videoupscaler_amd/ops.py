@@ -199,9 +199,10 @@ class HipOps:
     def groupnorm_stats(self, x, stats, groups):
         self._chk(x, BF16, "x"); self._chk(stats, torch.float64, "stats")
         T, H, W, Cc = x.shape
-        stats.zero_()
-        hip_lib.check(self.lib.svr_groupnorm_stats(_ptr(x), _ptr(stats), T, H * W, Cc, groups, self._stream()),
-                      "svr_groupnorm_stats")
+        ws = torch.empty(int(self.lib.svr_groupnorm_workspace_bytes(T, H * W, groups)), dtype=torch.uint8,
+                         device=self.device)
+        hip_lib.check(self.lib.svr_groupnorm_stats(_ptr(x), _ptr(stats), _ptr(ws), T, H * W, Cc, groups,
+                                                   self._stream()), "svr_groupnorm_stats")
         return stats
 
     def groupnorm_apply(self, x, out, stats, gamma, beta, groups, eps, silu):

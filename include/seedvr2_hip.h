@@ -119,9 +119,12 @@ int svr_unpatchify_euler(const void* pred, int64_t ldp, const void* x_t, void* o
 
 /* ---- VAE elementwise ------------------------------------------------------------------------- */
 /* Per-frame GroupNorm statistics over NDHWC.  causal_inflation_lib.py:366-408.
- * x bf16 [T, HW, C]; stats fp64 [T, groups, 2] (sum, sumsq) must be zeroed by the caller.         */
-int svr_groupnorm_stats(const void* x, double* stats, int32_t T, int64_t HW, int32_t C, int32_t groups,
-                        void* stream);
+ * x bf16 [T, HW, C]; stats fp64 [T, groups, 2] (sum, sumsq), fully overwritten.  Reductions run in a
+ * fixed order (no atomics): bit-reproducible, independent of temporal slicing.  `workspace` is a
+ * caller-provided scratch of svr_groupnorm_workspace_bytes(T, HW, groups) bytes.                    */
+int64_t svr_groupnorm_workspace_bytes(int32_t T, int64_t HW, int32_t groups);
+int svr_groupnorm_stats(const void* x, double* stats, void* workspace, int32_t T, int64_t HW, int32_t C,
+                        int32_t groups, void* stream);
 /* y = [silu](gamma * (x - mean) * rstd + beta).  attn_video_vae.py:316-323,343-350.               */
 int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float* gamma, const float* beta,
                         int32_t T, int64_t HW, int32_t C, int32_t groups, float eps, int32_t apply_silu,

@@ -15,7 +15,7 @@ HAVE_HIPCC = shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/
 
 def _declared():
     src = open(os.path.join(ROOT, "include", "seedvr2_hip.h")).read()
-    return sorted(set(re.findall(r"^\s*(?:int|const char\*)\s+(svr_\w+)\s*\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(svr_\w+)\s*\(", src, flags=re.M)))
 
 
 @pytest.mark.skipif(not HAVE_HIPCC, reason="hipcc not available")

@@ -340,6 +340,12 @@ def test_groupnorm(hip, ref, C):
     hip.groupnorm_stats(x, stats, 32)
     want_stats = ref.groupnorm_stats(x, torch.empty(T, 32, 2, device="cuda", dtype=torch.float64), 32)
     assert torch.allclose(stats, want_stats, rtol=1e-5)
+    again = torch.empty_like(stats)
+    hip.groupnorm_stats(x, again, 32)
+    assert torch.equal(stats, again)                       # fixed-order reduction: bit-reproducible
+    one = torch.empty(1, 32, 2, device="cuda", dtype=torch.float64)
+    hip.groupnorm_stats(x[1:2].contiguous(), one, 32)
+    assert torch.equal(one[0], stats[1])                   # and independent of the frame's position in the slice
     for silu in (True, False):
         out = torch.empty_like(x)
         hip.groupnorm_apply(x, out, stats, gamma, beta, 32, 1e-6, silu)

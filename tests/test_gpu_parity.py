@@ -92,17 +92,21 @@ def test_vae_vs_reference_golden(hip, tiled):
 
 
 def test_vae_temporal_slicing_invariance(hip):
-    """Size-independent property: slice size must not change the result (causal halos carry state)."""
+    """Size-independent property: slice size must not change the result (causal halos carry state).
+    Every kernel on the path reduces in a fixed order (no atomics), so the property is checked BIT-EXACT:
+    a random-weight VAE amplifies any perturbation to the bf16 noise floor (1e-2) within ~20 layers, so a
+    tolerance could not tell a halo bug from rounding noise, equality can."""
     config, weights, vae = sub("config"), sub("weights"), sub("vae")
     cfg = config.VAE_V3
     eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg), hip)
     g = torch.Generator().manual_seed(3)
     x = (torch.rand(3, 13, 64, 64, generator=g) * 2 - 1).to(BF16).cuda()
-    a, b = eng.encode(x).float(), eng.encode(x, frames_per_slice=4).float()
-    assert rel_err(b, a) < 5e-3
+    a, b = eng.encode(x), eng.encode(x, frames_per_slice=4)
+    assert torch.equal(a, b), rel_err(b.float(), a.float())
+    assert torch.equal(a, eng.encode(x, frames_per_slice=8))
     z = torch.randn(4, 8, 8, 16, generator=g).to(BF16).cuda()
-    a, b = eng.decode(z).float(), eng.decode(z, latents_per_slice=1).float()
-    assert a.shape == (3, 13, 64, 64) and rel_err(b, a) < 5e-3
+    a, b = eng.decode(z), eng.decode(z, latents_per_slice=1)
+    assert a.shape == (3, 13, 64, 64) and torch.equal(a, b), rel_err(b.float(), a.float())
 
 
 def test_vae_oracle_live_ragged(hip):

@@ -6,5 +6,5 @@ export TMPDIR=/tmp
 ONLY=${1:-gemm}; shift
 for v in "$@"; do
   echo "== SVR_PIPE_ABL=$v"
-  SVR_GEMM_IMPL=2 SVR_PIPE_ABL=$v timeout 600 python tools/kbench.py --reps 5 --only $ONLY 2>/dev/null | tee gpurun_out/kbench_abl$v.jsonl
+  SVR_PIPE_ABL=$v timeout 600 python tools/kbench.py --reps 5 --only $ONLY 2>/dev/null | tee gpurun_out/kbench_abl$v.jsonl
 done
