@@ -57,11 +57,15 @@ def make_profiled_ops(device):
             conv = kw.get("conv")
             if conv is not None:
                 M = conv.To * conv.Ho * conv.Wo
-                kind = "conv_bn256" if kw["N"] % 256 == 0 else "conv_bn128"
+                # mirrors conv_halo_eligible() in csrc/svr_conv_halo.hip: stride-1 "same" 3x3 spatial kernels
+                halo = (conv.k[1] == 3 and conv.k[2] == 3 and tuple(conv.stride) == (1, 1, 1) and conv.pad[1] == 1
+                        and conv.pad[2] == 1 and conv.Ho == conv.H and conv.Wo == conv.W and conv.Cin % 64 == 0
+                        and kw["N"] % 128 == 0)
+                kind = "conv_halo" if halo else "conv_generic"
                 flops = 2.0 * M * kw["N"] * conv.k[0] * conv.k[1] * conv.k[2] * conv.Cin
             else:
                 M = kw.get("M") or A.shape[0]
-                kind = "gemm_bn256" if kw["N"] % 256 == 0 else "gemm_bn128"
+                kind = "gemm"
                 flops = 2.0 * M * kw["N"] * kw["K"]
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -200,13 +204,24 @@ def main():
         f_vae = flops.vae_flops_tiled(vcfg, frames, H, W, tiled)
         f_step = f_dit["total"] + f_vae["encode"] + f_vae["decode"]
         kern = ops.summary()
-        conv = [kern[k] for k in ("conv_bn128", "conv_bn256") if k in kern]
-        c_flops, c_sec, c_n = sum(k["flops"] for k in conv), sum(k["seconds"] for k in conv), sum(k["launches"] for k in conv)
-        roof = {"bound": "mfma", "kernel": "svr::gemm_kernel<.., CONV=true> (implicit-GEMM causal Conv3d, both tile shapes)",
+        # dominant kernel: the LDS-halo implicit-GEMM conv (67 % of the step, profiles/r1_cfg3_kernel_stats.csv)
+        dom = kern.get("conv_halo") or kern.get("conv_generic") or kern["gemm"]
+        c_flops, c_sec, c_n = dom["flops"], dom["seconds"], dom["launches"]
+        traffic, traffic_note = None, None
+        try:     # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload (never measured live)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_cfg3_pmc_traffic.json")))
+            if pmc.get("workload") == args.workload and "conv_halo" in kern:
+                traffic = pmc["kernels"]["svr::conv_halo_kernel<128, 0>"]["hbm_bytes_per_launch"]
+                traffic_note = "bytes/launch, FETCH_SIZE*2 + WRITE_SIZE from profiles/r1_cfg3_pmc_traffic.json"
+        except (OSError, KeyError, ValueError):
+            pass
+        roof = {"bound": "mfma", "kernel": "svr::conv_halo_kernel<128> (LDS-halo implicit-GEMM causal Conv3d, 3x3 spatial taps)",
                 "achieved": c_flops / max(c_sec, 1e-12) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": c_flops / max(c_sec, 1e-12) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+                "frac": c_flops / max(c_sec, 1e-12) / 1e12 / PEAK_BF16_TFLOPS, "traffic": traffic,
+                "traffic_note": traffic_note,
                 "launches": c_n, "avg_launch_us": c_sec / max(c_n, 1) * 1e6,
                 "algorithmic_flops_per_launch": c_flops / max(c_n, 1),
+                "share_of_step_time": c_sec / max(dt, 1e-12),
                 "per_kernel": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 1)}
                                for k, v in kern.items()}}
         res = {
