@@ -62,8 +62,16 @@ int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps
                     const float* shift, void* stream) {
     if (rows <= 0) return 0;
     if (dim % 8 || dim > 64 * 8 * 8) return fail("svr_rmsnorm_mod: dim must be a multiple of 8 and <= 4096");
-    hipLaunchKernelGGL(rmsnorm_mod_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (bf16_t*)y, rows, dim, eps, w, scale, shift);
+    const unsigned grid = (unsigned)(rows < 4 * 2048 ? blocks_for(rows, 4) : 2048);      // 8 blocks per CU, rows strided
+    const int nc = (dim + 511) / 512;
+#define SVR_RMS_LAUNCH(NC) hipLaunchKernelGGL(rmsnorm_mod_kernel<NC>, dim3(grid), dim3(256), 0, (hipStream_t)stream, \
+                                              (const bf16_t*)x, (bf16_t*)y, rows, dim, eps, w, scale, shift)
+    switch (nc) {
+        case 1: SVR_RMS_LAUNCH(1); break; case 2: SVR_RMS_LAUNCH(2); break; case 3: SVR_RMS_LAUNCH(3); break;
+        case 4: SVR_RMS_LAUNCH(4); break; case 5: SVR_RMS_LAUNCH(5); break; case 6: SVR_RMS_LAUNCH(6); break;
+        case 7: SVR_RMS_LAUNCH(7); break; default: SVR_RMS_LAUNCH(8); break;
+    }
+#undef SVR_RMS_LAUNCH
     return check(hipGetLastError(), "svr_rmsnorm_mod");
 }
 

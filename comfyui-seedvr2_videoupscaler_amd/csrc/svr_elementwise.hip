@@ -12,48 +12,77 @@ namespace svr {
 // ------------------------------------------------------------------------------------------------
 constexpr int RMS_MAXC = 8;   // 16-byte chunks per lane -> dim <= 4096
 
+// One wave per row, rows strided over the grid so that the per-channel affine (w * scale, shift) is loaded
+// ONCE per wave into registers and reused for all its rows (a per-element reload made the first version
+// load-issue bound at 1.1 TB/s); the next row's chunks are fetched while the current one is reduced.
+template <int NC>             // chunks per lane actually used: ceil(dim / 512)
 __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                           int64_t rows, int dim, float eps,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int nchunk = dim >> 3;
-    const uint4* xp = (const uint4*)(x + row * dim);
-    uint4 v[RMS_MAXC];
-    float ss = 0.f;
+    float mul[NC][8], add[NC][8];
+    const bool affine = w || scale || shift;
+    if (affine) {
 #pragma unroll
-    for (int i = 0; i < RMS_MAXC; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nchunk) {
-            v[i] = xp[c];
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = c * 8 + e;
+                float m = 1.f, a = 0.f;
+                if (c < nchunk) {
+                    if (w) m *= w[ch];
+                    if (scale) m *= scale[ch];
+                    if (shift) a = shift[ch];
+                }
+                mul[i][e] = m; add[i][e] = a;
+            }
+        }
+    }
+    uint4 v[NC], nx[NC];
+    auto fetch = [&](int64_t row, uint4 (&dst)[NC]) {
+        const uint4* xp = (const uint4*)(x + row * dim);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            dst[i] = c < nchunk ? xp[c] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    if (wave0 < rows) fetch(wave0, nx);
+    for (int64_t row = wave0; row < rows; row += nwaves) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) v[i] = nx[i];
+        if (row + nwaves < rows) fetch(row + nwaves, nx);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
             float f[8];
             unpack8(v[i], f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
         }
-    }
-    ss = wave_sum(ss);
-    const float inv = rsqrtf(ss / (float)dim + eps);
-    uint4* yp = (uint4*)(y + row * dim);
+        ss = wave_sum(ss);
+        const float inv = rsqrtf(ss / (float)dim + eps);
+        uint4* yp = (uint4*)(y + row * dim);
 #pragma unroll
-    for (int i = 0; i < RMS_MAXC; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nchunk) {
-            float f[8];
-            unpack8(v[i], f);
+        for (int i = 0; i < NC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunk) {
+                float f[8];
+                unpack8(v[i], f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = f[e] * inv;
-                const int ch = c * 8 + e;
-                if (w) t *= w[ch];
-                if (scale) t *= scale[ch];
-                if (shift) t += shift[ch];
-                f[e] = t;
+                for (int e = 0; e < 8; ++e) {
+                    // same operation order as the reference: ((x * inv) * w * scale) + shift  (modulation.py:110)
+                    float t = f[e] * inv;
+                    f[e] = affine ? t * mul[i][e] + add[i][e] : t;
+                }
+                yp[c] = pack8(f);
             }
-            yp[c] = pack8(f);
         }
     }
 }

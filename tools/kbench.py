@@ -61,7 +61,11 @@ def main():
                                       ("conv3x3x3 256->128 @1024^2", 5, 1024, 1024, 256, 128),
                                       ("conv3x3x3 256->256 @512^2", 9, 512, 512, 256, 256),
                                       ("conv3x3x3 512->256 @512^2", 9, 512, 512, 512, 256),
-                                      ("conv3x3x3 512->512 @256^2", 9, 256, 256, 512, 512)):
+                                      ("conv3x3x3 512->512 @256^2", 9, 256, 256, 512, 512),
+                                      # non power-of-two row pitch (HBM channel / TLB aliasing probe)
+                                      ("conv3x3x3 128->128 @1024x1056", 5, 1024, 1056, 128, 128),
+                                      ("conv3x3x3 128->128 @1024x992", 5, 1024, 992, 128, 128),
+                                      ("conv3x3x3 256->256 @512x544", 9, 512, 544, 256, 256)):
             x = rnd(T, H, W, Ci)
             w = packing.pack_conv3d(torch.randn(Co, Ci, 3, 3, 3, generator=g, device=dev) / math.sqrt(27 * Ci), dev)
             b = torch.zeros(Co, dtype=torch.float32, device=dev)
