@@ -60,7 +60,7 @@ def make_profiled_ops(device):
                 # mirrors conv_halo_eligible() in csrc/svr_conv_halo.hip: stride-1 "same" 3x3 spatial kernels
                 halo = (conv.k[1] == 3 and conv.k[2] == 3 and tuple(conv.stride) == (1, 1, 1) and conv.pad[1] == 1
                         and conv.pad[2] == 1 and conv.Ho == conv.H and conv.Wo == conv.W and conv.Cin % 64 == 0
-                        and kw["N"] % 128 == 0)
+                        and (kw["N"] % 128 == 0 or kw["N"] <= 32))
                 kind = "conv_halo" if halo else "conv_generic"
                 flops = 2.0 * M * kw["N"] * conv.k[0] * conv.k[1] * conv.k[2] * conv.Cin
             else:

@@ -48,10 +48,13 @@ template <int N> SVR_DEVICE void ch_wait_vmcnt() { asm volatile("s_waitcnt vmcnt
 // 2 = no MFMA, 3 = MFMA only (no staging, fragment reads or barriers in the loop).  Garbage results.
 template <int BN, int ABL>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
-    constexpr int HBN = BN / 128;                         // weight units per tap
+    // BN = 128: 8 waves = 4 (row pairs) x 2 (64 couts);  BN = 32 (thin outputs: conv_out 128->3, 512->32):
+    // 8 waves = 8 rows x 32 couts, the weight unit is 32 rows (4 KiB) staged by waves 0-3 only.
+    static_assert(BN == 128 || BN == 32, "N tile");
+    constexpr int HBN = 1;                                // weight units per tap
     constexpr int PPS = 9 * HBN;                          // intervals per A step
-    constexpr int MTW = (BN == 256) ? 4 : 2;              // 32-voxel rows per wave
-    constexpr int NTW = (BN == 256) ? 1 : 2;              // 32-cout blocks per wave and unit
+    constexpr int MTW = (BN == 128) ? 2 : 1;              // 32-voxel rows per wave
+    constexpr int NTW = (BN == 128) ? 2 : 1;              // 32-cout blocks per wave and unit
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
@@ -60,13 +63,13 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;                            // the two waves of a SIMD are in different groups
-    const int wm = (BN == 256) ? (wave >> 2) : (wave >> 1);
-    const int wn = (BN == 256) ? (wave & 3) : (wave & 1);
+    const int wm = (BN == 128) ? (wave >> 1) : wave;
+    const int wn = (BN == 128) ? (wave & 1) : 0;
 
     // ---- tile id -> (frame, patch row, patch column, cout tile); XCD-contiguous bands
     const int tiles_x = (g.W + CH_TX - 1) / CH_TX;
     const int tiles_y = (g.H + CH_TY - 1) / CH_TY;
-    const int tiles_n = a.N / BN;
+    const int tiles_n = (a.N + BN - 1) / BN;
     int tl;
     {
         const int nwg = gridDim.x, bid = blockIdx.x;
@@ -134,8 +137,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
         const int c0 = (s - dt * cpk) * 64;
         const int64_t koff = ((int64_t)(dt * 9 + tap) * g.Cin + c0) * 2 + hb * wunit;
         char* dst = wave_dst + CH_BOFF + slot * CH_BUNIT;
-        glds16(wbase[0] + koff, dst);
-        glds16(wbase[1] + koff, dst + 64 * 128);
+        if constexpr (BN == 128) {
+            glds16(wbase[0] + koff, dst);
+            glds16(wbase[1] + koff, dst + 64 * 128);
+        } else {
+            if (wave < 4) glds16(wbase[0] + koff, dst);   // 32 weight rows = the first 256 threads
+        }
     };
 
     // ---- fragment addressing
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
             rd_a[dx][ks] = (wm * MTW * CH_HX + l31) * 128 + (((2 * ks + hi) ^ (((dx + l31) >> 1) & 7)) << 4);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)                        // weight rows of a wave start at multiples of 32
-        rd_b[ks] = CH_BOFF + ((BN == 256 ? wn * 32 : wn * 64) + l31) * 128 + (((2 * ks + hi) ^ ((lane >> 1) & 7)) << 4);
+        rd_b[ks] = CH_BOFF + (wn * 64 + l31) * 128 + (((2 * ks + hi) ^ ((lane >> 1) & 7)) << 4);
 
     f32x16_t acc[HBN][MTW][NTW];
 #pragma unroll
@@ -240,8 +247,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
             constexpr int JU = (J + CH_D) % PPS;
             stage_b(s + (J + CH_D) / PPS, JU / HBN, JU % HBN, (k + CH_D) & (CH_NB - 1));
         }
-        if (b_issued) { if (a_issued) ch_wait_vmcnt<3>(); else ch_wait_vmcnt<2>(); }
-        else          { if (a_issued) ch_wait_vmcnt<1>(); else ch_wait_vmcnt<0>(); }
+        // loads this wave may leave in flight: what it issued in this interval (weight unit k+2 is older)
+        const int nb = !b_issued ? 0 : (BN == 128 ? 2 : (wave < 4 ? 1 : 0));
+        if (nb == 2)      { if (a_issued) ch_wait_vmcnt<3>(); else ch_wait_vmcnt<2>(); }
+        else if (nb == 1) { if (a_issued) ch_wait_vmcnt<2>(); else ch_wait_vmcnt<1>(); }
+        else              { if (a_issued) ch_wait_vmcnt<1>(); else ch_wait_vmcnt<0>(); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if (grp == 1) mfmas(jc);
@@ -274,11 +284,25 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
         }
     }
 
+    if constexpr (BN != 128) {
+        // thin outputs (N <= 32, e.g. 3 RGB channels with ldc = 3): per-lane epilogue, the byte volume is tiny.
+        // 32x32 tile: lane holds C[voxel = lane & 31][cout = 8 q + 4 (lane >> 5) + 0..3]
+        const int y = y0 + wm, x = x0 + l31;
+        const bool ok = y < g.H && x < g.W;
+        const int m = (to * g.H + y) * g.W + x;
+        const f32x16_t v = acc[0][0][0];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int n = n0 + 8 * gq + hi * 4;
+            const f32x4 accv = {v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
+            if (ok && n < a.N) epilogue_store(a, accv, accv, m, n);
+        }
+        return;
+    } else {
     // ---- epilogue through LDS (BN == 128): the MFMA layout gives each lane 4 couts of 32 different
     // voxels (8-byte stores scattered over 32 cache lines, and the same for the residual loads), so the
     // fp32 tile (+ bias) is parked in LDS [256 voxels][132 floats] and written back row-contiguous:
     // 16 lanes cover one voxel's 128 couts, every global access is a full 16-byte lane / 256-byte row.
-    static_assert(BN == 128, "LDS epilogue is written for the 128-cout tile");
     constexpr int EP_PITCH = 528;                         // 128 floats + 16 B pad: conflict-free b128 writes
     const int hi4 = hi * 4;
     {
@@ -340,12 +364,13 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const svr_gemm_args a) {
             *(uint4*)((bf16_t*)a.C + m * a.ldc + n) = pack8(f);
         }
     }
+    }   // BN == 128
 }
 
 template <int BN, int ABL>
 static int launch_conv_halo_abl(const svr_gemm_args& a, hipStream_t s) {
     const svr_conv_geom& g = a.conv;
-    const int tiles = g.To * ((g.H + CH_TY - 1) / CH_TY) * ((g.W + CH_TX - 1) / CH_TX) * (a.N / BN);
+    const int tiles = g.To * ((g.H + CH_TY - 1) / CH_TY) * ((g.W + CH_TX - 1) / CH_TX) * ((a.N + BN - 1) / BN);
     auto kern = conv_halo_kernel<BN, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -375,9 +400,9 @@ static int launch_conv_halo(const svr_gemm_args& a, hipStream_t s) {
 static bool conv_halo_eligible(const svr_gemm_args& a) {
     const svr_conv_geom& g = a.conv;
     return g.enabled && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.st == 1 && g.ph == 1 && g.pw == 1 &&
-           g.Ho == g.H && g.Wo == g.W && g.Cin % 64 == 0 && (a.N % 128) == 0 && g.kt >= 1 && g.kt <= 3 &&
+           g.Ho == g.H && g.Wo == g.W && g.Cin % 64 == 0 && g.kt >= 1 && g.kt <= 3 &&
            g.To == g.T + g.pt - g.kt + 1 && !a.ps.enabled && a.epilogue != SVR_EPI_SWIGLU &&
-           (a.ldc % 8) == 0 && (!a.resid || (a.ldr % 8) == 0) &&
+           (a.N <= 32 || ((a.N % 128) == 0 && (a.ldc % 8) == 0 && (!a.resid || (a.ldr % 8) == 0))) &&
            (int64_t)g.H * g.W * g.Cin * 2 < (int64_t)1 << 32;
 }
 

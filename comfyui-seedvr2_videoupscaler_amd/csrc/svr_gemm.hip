@@ -318,7 +318,7 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
         *why = "svr_gemm_bf16: bad pixel-shuffle geometry"; return -1;
     }
     if (g_conv_impl != 1 && conv_halo_eligible(a))
-        return launch_conv_halo<128>(a, s);   // (the 256-wide variant needs > 256 VGPRs; 128-wide tiles cost 13 % more staging)
+        return a.N <= 32 ? launch_conv_halo<32>(a, s) : launch_conv_halo<128>(a, s);
     if (pipe_eligible(a) && use_pipe_kernel(a))
         return a.conv.enabled ? launch_pipe<true>(a, s) : launch_pipe<false>(a, s);
     const bool wide = (a.N % 256) == 0;     // otherwise W is padded to a multiple of 128 rows

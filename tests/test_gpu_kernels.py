@@ -148,6 +148,9 @@ CONV_CASES = [
     (256, 128, (3, 3, 3), (1, 1, 1), (1, 1), 2, 17, 33, 2),
     (128, 384, (3, 3, 3), (1, 1, 1), (1, 1), 2, 8, 64, 0),
     (192, 128, (1, 3, 3), (1, 1, 1), (1, 1), 2, 9, 31, 0),
+    # thin outputs on the LDS-halo kernel's 32-cout variant (decoder conv_out 128->3, encoder conv_out 512->32)
+    (128, 3, (3, 3, 3), (1, 1, 1), (1, 1), 3, 40, 70, 0),
+    (512, 32, (3, 3, 3), (1, 1, 1), (1, 1), 2, 19, 45, 2),
 ]
 
 

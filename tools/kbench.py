@@ -65,7 +65,8 @@ def main():
                                       # non power-of-two row pitch (HBM channel / TLB aliasing probe)
                                       ("conv3x3x3 128->128 @1024x1056", 5, 1024, 1056, 128, 128),
                                       ("conv3x3x3 128->128 @1024x992", 5, 1024, 992, 128, 128),
-                                      ("conv3x3x3 256->256 @512x544", 9, 512, 544, 256, 256)):
+                                      ("conv3x3x3 256->256 @512x544", 9, 512, 544, 256, 256),
+                                      ("conv3x3x3 128->3 @1024^2 (decoder conv_out)", 5, 1024, 1024, 128, 3)):
             x = rnd(T, H, W, Ci)
             w = packing.pack_conv3d(torch.randn(Co, Ci, 3, 3, 3, generator=g, device=dev) / math.sqrt(27 * Ci), dev)
             b = torch.zeros(Co, dtype=torch.float32, device=dev)
