@@ -97,26 +97,26 @@ def cpu_baseline(flops_per_frame: float) -> dict:
     vcfg = config.VAE_V3
     vsd = {k: v.float() for k, v in weights.synth_vae_state_dict(vcfg).items()}
     g = torch.Generator().manual_seed(0)
-    x = torch.rand(3, 5, 128, 128, generator=g) * 2 - 1
+    x = torch.rand(3, 9, 160, 160, generator=g) * 2 - 1
     t0 = time.perf_counter()
     lat = vae_oracle.runner_vae_encode(x, vsd, vcfg)
     vae_oracle.runner_vae_decode(lat, vsd, vcfg)
     t_vae = time.perf_counter() - t0
-    f_vae = sum(flops.vae_flops_tiled(vcfg, 5, 128, 128, False).values())
-    # 4-layer slice of the 3B-width DiT on a 3x32x32 latent
-    dcfg = config.DiTConfig(num_layers=4, mm_layers=2)
+    f_vae = sum(flops.vae_flops_tiled(vcfg, 9, 160, 160, False).values())
+    # 6-layer slice of the 3B-width DiT on a 3x48x48 latent
+    dcfg = config.DiTConfig(num_layers=6, mm_layers=3)
     dsd = weights.synth_dit_state_dict(dcfg)
-    vid = torch.randn(3, 32, 32, 33, generator=g)
+    vid = torch.randn(3, 48, 48, 33, generator=g)
     txt = weights.synth_text_embedding().float()
     t0 = time.perf_counter()
     dit_oracle.dit_forward(dsd, dcfg, vid, txt, 1000.0, windows_mod=windows)
     t_dit = time.perf_counter() - t0
-    f_dit = flops.dit_flops(dcfg, (3, 16, 16))["total"]
+    f_dit = flops.dit_flops(dcfg, (3, 24, 24))["total"]
     tflops = (f_vae + f_dit) / (t_vae + t_dit) / 1e12
     return {"value": tflops * 1e12 / flops_per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
             "cpu_tflops": tflops,
-            "sample": f"oracle fp32: full VAE enc+dec of a 5x128x128 clip ({t_vae:.1f}s) + 4-layer 3B-width DiT on a "
-                      f"3x32x32 latent ({t_dit:.1f}s); extrapolated to the workload by algorithmic FLOPs"}
+            "sample": f"oracle fp32: full VAE enc+dec of a 9x160x160 clip ({t_vae:.1f}s) + 6-layer 3B-width DiT on a "
+                      f"3x48x48 latent ({t_dit:.1f}s); extrapolated to the workload by algorithmic FLOPs"}
 
 
 def main():
