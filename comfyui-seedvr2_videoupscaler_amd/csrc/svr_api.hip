@@ -8,6 +8,7 @@
 #include "svr_gemm.hip"
 #include "svr_gemm_pipe.hip"
 #include "svr_conv_halo.hip"
+#include "svr_conv_halo2.hip"
 #include "svr_attn.hip"
 #include "svr_elementwise.hip"
 

@@ -154,8 +154,19 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("conv_impl", [0, 2], ids=["halo16x32", "halo8x32"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv3d_implicit_gemm(hip, ref, case):
+def test_conv3d_implicit_gemm(hip, ref, case, conv_impl):
+    """conv_impl 0: the library's choice (16x32-voxel LDS-halo kernel where eligible), 2: the first (8x32) halo
+    kernel; geometries neither accepts run on the generic implicit-GEMM kernel in both."""
+    hip.set_option("conv_impl", conv_impl)
+    try:
+        _conv_case(hip, ref, case)
+    finally:
+        hip.set_option("conv_impl", 0)
+
+
+def _conv_case(hip, ref, case):
     packing, opsmod = sub("packing"), sub("ops")
     Cin, Cout, k, stride, (plo, phi), T, H, W, hf = case
     kt, kh, kw = k
