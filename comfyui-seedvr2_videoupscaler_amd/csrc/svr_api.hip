@@ -59,6 +59,19 @@ int svr_gemm_bf16(const svr_gemm_args* args, void* stream) {
     return check(rc, "svr_gemm_bf16");
 }
 
+int32_t svr_gemm_gn_blocks(const svr_gemm_args* args) {
+    if (!args || !args->conv.enabled || args->gn_groups <= 0) return 0;
+    return conv_gn_blocks(*args);
+}
+
+int svr_groupnorm_reduce(const void* partial, double* stats, int32_t T, int32_t nblk, int32_t groups, void* stream) {
+    if (T <= 0 || nblk <= 0) return 0;
+    if (groups <= 0 || groups > 32) return fail("svr_groupnorm_reduce: 1..32 groups");
+    hipLaunchKernelGGL(groupnorm_reduce_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream,
+                       (const double2*)partial, stats, (int)nblk, groups);
+    return check(hipGetLastError(), "svr_groupnorm_reduce");
+}
+
 int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps, const float* w, const float* scale,
                     const float* shift, void* stream) {
     if (rows <= 0) return 0;

@@ -270,6 +270,9 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) 
             bv[nt][gq] = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     const bool resid_gate = a.epilogue == SVR_EPI_RESID_GATE;
+    // fused GroupNorm statistics of the stored (bf16-rounded) output: this thread always stores the same
+    // 8-cout chunk (tid & 15), so it keeps two quad sums over its 16 voxels
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         if ((wm >> 1) == pass) {
@@ -319,10 +322,44 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) 
                 *(float4*)cp = make_float4(f[0], f[1], f[2], f[3]);
                 *(float4*)(cp + 4) = make_float4(f[4], f[5], f[6], f[7]);
             } else {
-                *(uint4*)((bf16_t*)a.C + m * a.ldc + n) = pack8(f);
+                const uint4 pk = pack8(f);
+                *(uint4*)((bf16_t*)a.C + m * a.ldc + n) = pk;
+                if (a.gn_partial) {
+                    float r[8];
+                    unpack8(pk, r);
+                    gs0 += r[0] + r[1] + r[2] + r[3];
+                    gq0 += r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+                    gs1 += r[4] + r[5] + r[6] + r[7];
+                    gq1 += r[4] * r[4] + r[5] * r[5] + r[6] * r[6] + r[7] * r[7];
+                }
             }
         }
         if (pass == 0) __syncthreads();
+    }
+    if (a.gn_partial) {                                   // fixed-order reduction: thread -> quad -> group
+        __syncthreads();
+        float4* red = (float4*)smem;                      // [512]
+        double2* qsum = (double2*)(smem + 8192);          // [32 quads]
+        red[tid] = make_float4(gs0, gq0, gs1, gq1);
+        __syncthreads();
+        if (tid < 32) {                                   // quad = 2 * chunk + half; rows tid' with tid' & 15 == chunk
+            const int c = tid >> 1, h = tid & 1;
+            double s = 0.0, q = 0.0;
+            for (int j = 0; j < 32; ++j) {
+                const float4 v = red[(j << 4) | c];
+                s += (double)(h ? v.z : v.x);
+                q += (double)(h ? v.w : v.y);
+            }
+            qsum[tid] = make_double2(s, q);
+        }
+        __syncthreads();
+        const int qpg = (a.N / a.gn_groups) >> 2;         // quads per group (channels per group / 4)
+        if (tid < 32 / qpg) {
+            double s = 0.0, q = 0.0;
+            for (int i = 0; i < qpg; ++i) { s += qsum[tid * qpg + i].x; q += qsum[tid * qpg + i].y; }
+            const int blk = ty * tiles_x + tx, nblk = tiles_y * tiles_x;
+            ((double2*)a.gn_partial)[((int64_t)to * nblk + blk) * a.gn_groups + (n0 >> 2) / qpg + tid] = make_double2(s, q);
+        }
     }
 }
 
@@ -337,6 +374,13 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
     }
     hipLaunchKernelGGL(conv_halo2_kernel, dim3(tiles), dim3(512), CG_LDS, s, a);
     return (int)hipGetLastError();
+}
+
+static int conv_gn_blocks(const svr_gemm_args& a) {
+    if (g_conv_impl != 0 || !conv_halo_eligible(a) || (a.N % 128) != 0 || a.conv.Cin % 32 != 0 || a.out_f32) return 0;
+    const int cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 0;          // channels per group: 4, 8 or 16
+    if (cpg < 4 || (cpg & 3) || a.N % a.gn_groups || 128 % cpg) return 0;
+    return ((a.conv.H + CG_TY - 1) / CG_TY) * ((a.conv.W + CG_TX - 1) / CG_TX);
 }
 
 // what conv_halo_eligible() accepts with 128-cout tiles and channels in 32-slices

@@ -303,6 +303,9 @@ static bool use_pipe_kernel(const svr_gemm_args& a) {
     return false;      // auto: the pipelined kernel does not beat the simple one yet (profiles/kbench_r1_ab.txt)
 }
 
+// per-frame partial blocks of fused GroupNorm statistics for this problem (0: not produced)
+static int conv_gn_blocks(const svr_gemm_args& a);
+
 int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     *why = nullptr;
     if (a.M <= 0 || a.N <= 0) return 0;
@@ -319,6 +322,7 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     if (a.ps.enabled && (a.N != 4 * a.ps.rz * a.ps.C || a.M != a.ps.F * a.ps.H * a.ps.W || (a.ps.C % 4) != 0)) {
         *why = "svr_gemm_bf16: bad pixel-shuffle geometry"; return -1;
     }
+    if (a.gn_partial && conv_gn_blocks(a) == 0) { *why = "svr_gemm_bf16: gn_partial set but this launch cannot produce fused GroupNorm statistics"; return -1; }
     if (g_conv_impl == 0 && conv_halo2_eligible(a)) return launch_conv_halo2(a, s);
     if (g_conv_impl != 1 && conv_halo_eligible(a))
         return a.N <= 32 ? launch_conv_halo<32>(a, s) : launch_conv_halo<128>(a, s);

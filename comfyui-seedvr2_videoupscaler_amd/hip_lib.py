@@ -43,13 +43,16 @@ class GemmArgs(C.Structure):
                 ("bias", C.c_void_p), ("gate", C.c_void_p),
                 ("resid", C.c_void_p), ("ldr", C.c_int64),
                 ("epilogue", C.c_int32), ("out_f32", C.c_int32),
-                ("conv", ConvGeom), ("ps", PixelShuffle)]
+                ("conv", ConvGeom), ("ps", PixelShuffle),
+                ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/seedvr2_hip.h
 _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
     "svr_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "svr_gemm_gn_blocks": (C.c_int32, [C.POINTER(GemmArgs)]),
+    "svr_groupnorm_reduce": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "svr_rmsnorm_mod": (C.c_int, [_vp, _vp, _i64, _i32, _f, _vp, _vp, _vp, _vp]),
     "svr_ada_combine": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "svr_qknorm_rope": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _f, _vp]),
@@ -124,7 +127,7 @@ def lib():
         except AttributeError as e:
             raise HipLibraryError(f"{LIB_PATH} does not export {name} (stale build?)") from e
         fn.restype, fn.argtypes = res, args
-    if handle.svr_abi_version() != 1:
+    if handle.svr_abi_version() != 2:
         raise HipLibraryError("libseedvr2_hip.so ABI version mismatch; rebuild")
     _lib = handle
     return _lib

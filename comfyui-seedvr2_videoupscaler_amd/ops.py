@@ -86,8 +86,11 @@ class HipOps:
     # ------------------------------------------------------------------ GEMM / conv
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
              out_f32=False, conv: Optional[Conv3dGeom] = None, ps: Optional[PixelShuffleGeom] = None,
-             lda=None, ldc=None, ldr=None):
-        """out[M, N] = A[M, K] @ W[:N, :K]^T with fused epilogue.  W is [Npad, K] bf16 (Npad % 128 == 0)."""
+             lda=None, ldc=None, ldr=None, gn_groups: int = 0):
+        """out[M, N] = A[M, K] @ W[:N, :K]^T with fused epilogue.  W is [Npad, K] bf16 (Npad % 128 == 0).
+        With ``gn_groups`` > 0 (conv mode) returns ``(out, stats)``: per-frame GroupNorm (sum, sumsq) of the stored
+        output [To, groups, 2] fp64 fused into the conv epilogue, or ``None`` when the kernel serving this
+        geometry does not produce them (the caller then runs groupnorm_stats)."""
         self._chk(A, BF16, "A"); self._chk(W, BF16, "W")
         self._chk(out, torch.float32 if out_f32 else BF16, "out")
         if W.shape[1] != K or W.shape[0] < N or W.shape[0] % 128:
@@ -133,7 +136,22 @@ class HipOps:
             a.resid = resid.data_ptr()
             a.ldr = ldr if ldr is not None else (resid.stride(0) if resid.dim() == 2 else N)
         a.epilogue, a.out_f32 = epilogue, int(out_f32)
+        stats = None
+        if gn_groups > 0 and conv is not None:
+            a.gn_groups = gn_groups
+            nblk = int(self.lib.svr_gemm_gn_blocks(C.byref(a)))
+            if nblk > 0:
+                partial = torch.empty(conv.To * nblk * gn_groups * 2, dtype=torch.float64, device=self.device)
+                a.gn_partial = partial.data_ptr()
+                stats = torch.empty(conv.To, gn_groups, 2, dtype=torch.float64, device=self.device)
+            else:
+                a.gn_groups = 0
         hip_lib.check(self.lib.svr_gemm_bf16(C.byref(a), self._stream()), "svr_gemm_bf16")
+        if gn_groups > 0:
+            if stats is not None:
+                hip_lib.check(self.lib.svr_groupnorm_reduce(_ptr(partial), _ptr(stats), conv.To, nblk, gn_groups,
+                                                            self._stream()), "svr_groupnorm_reduce")
+            return out, stats
         return out
 
     # ------------------------------------------------------------------ DiT side kernels

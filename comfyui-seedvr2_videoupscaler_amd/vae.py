@@ -176,7 +176,10 @@ class VideoVAEEngine:
         self._iota = {}
 
     # ------------------------------------------------------------------ layer primitives
-    def _conv(self, cw: _Conv, x: torch.Tensor, st: dict, first: bool, resid: Optional[torch.Tensor] = None):
+    def _conv(self, cw: _Conv, x: torch.Tensor, st: dict, first: bool, resid: Optional[torch.Tensor] = None,
+              gn: bool = False):
+        """Causal conv of one temporal slice.  ``gn=True``: also return the per-frame GroupNorm statistics of the
+        output when the conv kernel can fuse them into its epilogue (else None) -> ``(out, stats)``."""
         ops = self.ops
         T, H, W, Cin = x.shape
         assert Cin == cw.cin, (cw.name, Cin, cw.cin)
@@ -195,11 +198,15 @@ class VideoVAEEngine:
         out = ops.empty(To, Ho, Wo, cw.cout)
         K = cw.w.shape[1]
         epi = EPI_RESID_GATE if resid is not None else EPI_BIAS
+        stats = None
         if cw.thin:
             cols = ops.empty(To * Ho * Wo, K)
             ops.im2col_causal(x, cols, geom)
             ops.gemm(cols, cw.w, out, N=cw.cout, K=K, M=To * Ho * Wo, bias=cw.b, epilogue=epi, resid=resid,
                      lda=K, ldc=cw.cout, ldr=cw.cout)
+        elif gn:
+            _, stats = ops.gemm(x, cw.w, out, N=cw.cout, K=K, bias=cw.b, epilogue=epi, resid=resid, conv=geom,
+                                ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups)
         else:
             ops.gemm(x, cw.w, out, N=cw.cout, K=K, bias=cw.b, epilogue=epi, resid=resid, conv=geom,
                      ldc=cw.cout, ldr=cw.cout)
@@ -209,22 +216,25 @@ class VideoVAEEngine:
             else:
                 prev = halo if halo is not None else x[:1].expand(pt, H, W, Cin)
                 st[cw.name] = torch.cat([prev, x], dim=0)[-carry:].contiguous()
-        return out
+        return (out, stats) if gn else out
 
-    def _gn(self, nm: _Norm, x: torch.Tensor, silu: bool):
+    def _gn(self, nm: _Norm, x: torch.Tensor, silu: bool, stats: Optional[torch.Tensor] = None):
+        """GroupNorm (+SiLU); ``stats`` = statistics of ``x`` already produced by the conv that wrote it."""
         ops, cfg = self.ops, self.cfg
-        stats = ops.empty(x.shape[0], cfg.norm_num_groups, 2, dtype=torch.float64)
-        ops.groupnorm_stats(x, stats, cfg.norm_num_groups)
+        if stats is None:
+            stats = ops.empty(x.shape[0], cfg.norm_num_groups, 2, dtype=torch.float64)
+            ops.groupnorm_stats(x, stats, cfg.norm_num_groups)
         out = ops.empty(*x.shape)
         ops.groupnorm_apply(x, out, stats, nm.gamma, nm.beta, cfg.norm_num_groups, cfg.norm_eps, silu)
         return out
 
-    def _resnet(self, rb: _Resnet, x, st, first):
-        h = self._gn(rb.norm1, x, True)
-        h = self._conv(rb.conv1, h, st, first)
-        h = self._gn(rb.norm2, h, True)
+    def _resnet(self, rb: _Resnet, x, st, first, x_stats=None):
+        """-> (out, GroupNorm statistics of out or None).  ``x_stats``: statistics of ``x`` if its producer fused them."""
+        h = self._gn(rb.norm1, x, True, x_stats)
+        h, hs = self._conv(rb.conv1, h, st, first, gn=True)
+        h = self._gn(rb.norm2, h, True, hs)
         sc = self._conv(rb.shortcut, x, st, first) if rb.shortcut is not None else x
-        return self._conv(rb.conv2, h, st, first, resid=sc)
+        return self._conv(rb.conv2, h, st, first, resid=sc, gn=True)
 
     def _attention(self, ab: _Attn, x):
         ops = self.ops
@@ -245,8 +255,8 @@ class VideoVAEEngine:
                  resid=x, ldc=Cc, ldr=Cc)
         return out
 
-    def _mid(self, m, x, st, first):
-        x = self._resnet(m[0], x, st, first)
+    def _mid(self, m, x, st, first, x_stats=None):
+        x, _ = self._resnet(m[0], x, st, first, x_stats)
         x = self._attention(m[1], x)
         return self._resnet(m[2], x, st, first)
 
@@ -259,29 +269,30 @@ class VideoVAEEngine:
         y = ops.empty(To, 2 * H, 2 * W, Cc)
         ops.gemm(x.reshape(T * H * W, Cc), up.upscale_w, y, N=4 * rz * Cc, K=Cc, M=T * H * W, bias=up.upscale_b,
                  ps=PixelShuffleGeom(T, H, W, rz, Cc, drop))
-        return self._conv(up.conv, y, st, first)
+        return self._conv(up.conv, y, st, first, gn=True)
 
     # ------------------------------------------------------------------ one temporal slice through a network
+    # (hs = GroupNorm statistics of h when the conv that produced h fused them into its epilogue, else None)
     def _encoder_slice(self, x, st, first):
-        h = self._conv(self.enc_conv_in, x, st, first)
+        h, hs = self._conv(self.enc_conv_in, x, st, first, gn=True)
         for res, down in self.enc_down:
             for rb in res:
-                h = self._resnet(rb, h, st, first)
+                h, hs = self._resnet(rb, h, st, first, hs)
             if down is not None:
-                h = self._conv(down, h, st, first)
-        h = self._mid(self.enc_mid, h, st, first)
-        h = self._gn(self.enc_norm_out, h, True)
+                h, hs = self._conv(down, h, st, first, gn=True)
+        h, hs = self._mid(self.enc_mid, h, st, first, hs)
+        h = self._gn(self.enc_norm_out, h, True, hs)
         return self._conv(self.enc_conv_out, h, st, first)
 
     def _decoder_slice(self, z, st, first):
-        h = self._conv(self.dec_conv_in, z, st, first)
-        h = self._mid(self.dec_mid, h, st, first)
+        h, hs = self._conv(self.dec_conv_in, z, st, first, gn=True)
+        h, hs = self._mid(self.dec_mid, h, st, first, hs)
         for res, up in self.dec_up:
             for rb in res:
-                h = self._resnet(rb, h, st, first)
+                h, hs = self._resnet(rb, h, st, first, hs)
             if up is not None:
-                h = self._upsample(up, h, st, first)
-        h = self._gn(self.dec_norm_out, h, True)
+                h, hs = self._upsample(up, h, st, first)
+        h = self._gn(self.dec_norm_out, h, True, hs)
         return self._conv(self.dec_conv_out, h, st, first)
 
     # ------------------------------------------------------------------ temporal slicing (slicing_encode / _decode)

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SVR_ABI_VERSION 1
+#define SVR_ABI_VERSION 2
 
 /* ---- GEMM / implicit-GEMM convolution epilogues ------------------------------------------ */
 #define SVR_EPI_BIAS        0   /* C = acc + bias                                              */
@@ -66,7 +66,18 @@ typedef struct svr_gemm_args {
     int32_t out_f32;
     svr_conv_geom conv;
     svr_pixel_shuffle ps;
+    /* Optional fused GroupNorm statistics of the STORED output (conv mode, N = channel count): when the
+     * launch is served by the LDS-halo conv kernel (svr_gemm_gn_blocks(args) > 0) every workgroup writes
+     * the (sum, sum of squares) of its patch per group to gn_partial[frame][block][group] (fp64 pairs,
+     * svr_gemm_gn_blocks() blocks per frame); svr_groupnorm_reduce() turns them into `stats`.  Fixed
+     * reduction order, like svr_groupnorm_stats.  NULL / 0: off.                                          */
+    void* gn_partial;
+    int32_t gn_groups;
 } svr_gemm_args;
+
+/* Number of per-frame partial blocks the launch described by `args` will write to args->gn_partial
+ * (0: the kernel that serves this problem does not produce fused statistics -- use svr_groupnorm_stats). */
+int32_t svr_gemm_gn_blocks(const svr_gemm_args* args);
 
 /* nn.Linear / F.conv3d replacement (MFMA bf16, fp32 accumulate).
  * Replaces: every nn.Linear in src/models/dit_3b (mmattn.py:173,269; mlp.py:60-61; patch_v1.py:96,113;
@@ -125,6 +136,9 @@ int svr_unpatchify_euler(const void* pred, int64_t ldp, const void* x_t, void* o
 int64_t svr_groupnorm_workspace_bytes(int32_t T, int64_t HW, int32_t groups);
 int svr_groupnorm_stats(const void* x, double* stats, void* workspace, int32_t T, int64_t HW, int32_t C,
                         int32_t groups, void* stream);
+/* stats[t][g] = fixed-order sum over the `nblk` block partials [T][nblk][groups] (fp64 pairs) written by
+ * svr_groupnorm_stats' first stage or by a conv launch with gn_partial set.                           */
+int svr_groupnorm_reduce(const void* partial, double* stats, int32_t T, int32_t nblk, int32_t groups, void* stream);
 /* y = [silu](gamma * (x - mean) * rstd + beta).  attn_video_vae.py:316-323,343-350.               */
 int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float* gamma, const float* beta,
                         int32_t T, int64_t HW, int32_t C, int32_t groups, float eps, int32_t apply_silu,

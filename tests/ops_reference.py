@@ -29,7 +29,11 @@ class TorchOps:
 
     # ------------------------------------------------------------------ GEMM / conv
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
-             out_f32=False, conv=None, ps=None, lda=None, ldc=None, ldr=None):
+             out_f32=False, conv=None, ps=None, lda=None, ldc=None, ldr=None, gn_groups=0):
+        """``gn_groups`` > 0: return ``(out, None)`` like a HIP launch whose kernel cannot fuse the statistics."""
+        if gn_groups > 0:
+            return self.gemm(A, W, out, N=N, K=K, M=M, bias=bias, epilogue=epilogue, gate=gate, resid=resid,
+                             out_f32=out_f32, conv=conv, ps=ps, lda=lda, ldc=ldc, ldr=ldr), None
         Wf = W[:N, :K].float()
         if conv is not None:
             g = conv

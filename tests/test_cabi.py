@@ -15,7 +15,7 @@ HAVE_HIPCC = shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/
 
 def _declared():
     src = open(os.path.join(ROOT, "include", "seedvr2_hip.h")).read()
-    return sorted(set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(svr_\w+)\s*\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|int32_t|int64_t|const char\*)\s+(svr_\w+)\s*\(", src, flags=re.M)))
 
 
 @pytest.mark.skipif(not HAVE_HIPCC, reason="hipcc not available")
@@ -30,8 +30,8 @@ def test_library_builds_loads_and_exports_header_symbols():
         assert hasattr(lib, name), f"{name} declared in seedvr2_hip.h but not exported"
     assert sorted(hip_lib.SYMBOLS) == declared, "ctypes table and header disagree"
     lib.svr_abi_version.restype = ctypes.c_int
-    assert lib.svr_abi_version() == 1
-    assert hip_lib.lib().svr_abi_version() == 1
+    assert lib.svr_abi_version() == 2
+    assert hip_lib.lib().svr_abi_version() == 2
 
 
 def test_struct_layout_matches_header():

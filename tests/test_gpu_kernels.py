@@ -245,6 +245,38 @@ def test_upscale_pixel_shuffle_epilogue(hip, ref, rz, drop):
     assert rel_err(out.float(), want) < TOL_BF16
 
 
+@pytest.mark.parametrize("Cin,Cout,resid", [(128, 128, True), (256, 128, False), (128, 256, True), (128, 512, False)])
+def test_conv_fused_groupnorm_stats(hip, ref, Cin, Cout, resid):
+    """GroupNorm (sum, sumsq) fused into the LDS-halo conv epilogue == statistics of the tensor it stored
+    (same bf16 values; fp64 reductions in a fixed order), bit-reproducible, ragged patches masked."""
+    packing, opsmod = sub("packing"), sub("ops")
+    T, H, W = 3, 37, 70
+    x = rnd(T, H, W, Cin)
+    w5 = rnd(Cout, Cin, 3, 3, 3, scale=1.0 / math.sqrt(Cin * 27), seed=2)
+    Wp = packing.pack_conv3d(w5, "cuda")
+    bias = rnd(Cout, dtype=torch.float32, seed=3)
+    geom = opsmod.Conv3dGeom(T, H, W, Cin, T, H, W, (3, 3, 3), (1, 1, 1), (2, 1, 1), None)
+    res = rnd(T, H, W, Cout, seed=11) if resid else None
+    kw = dict(N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, ldr=Cout,
+              epilogue=EPI_RESID_GATE if resid else EPI_BIAS, resid=res)
+    out = torch.empty(T, H, W, Cout, device="cuda", dtype=BF16)
+    got, stats = hip.gemm(x, Wp, out, gn_groups=32, **kw)
+    assert got is out and stats is not None and stats.shape == (T, 32, 2)
+    plain = torch.empty_like(out)
+    hip.gemm(x, Wp, plain, **kw)
+    assert torch.equal(out, plain)                         # the fused statistics do not change the output
+    want = ref.groupnorm_stats(out, torch.empty(T, 32, 2, device="cuda", dtype=torch.float64), 32)
+    assert torch.allclose(stats, want, rtol=1e-6, atol=1e-6)
+    _, again = hip.gemm(x, Wp, torch.empty_like(out), gn_groups=32, **kw)
+    assert torch.equal(stats, again)
+    # a geometry the halo kernel does not take: no fused statistics, the caller falls back
+    g2 = opsmod.Conv3dGeom(T, H, W, Cin, T, (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1, (1, 3, 3), (1, 2, 2), (0, 0, 0), None)
+    w2 = packing.pack_conv3d(rnd(Cout, Cin, 1, 3, 3, scale=0.05, seed=4), "cuda")
+    o2 = torch.empty(T, g2.Ho, g2.Wo, Cout, device="cuda", dtype=BF16)
+    _, none = hip.gemm(x, w2, o2, N=Cout, K=w2.shape[1], bias=bias, conv=g2, ldc=Cout, gn_groups=32)
+    assert none is None
+
+
 # ------------------------------------------------------------------ DiT side kernels
 @pytest.mark.parametrize("rows,dim", [(1000, 2560), (58, 2560), (333, 256), (7, 3072)])
 def test_rmsnorm_mod(hip, ref, rows, dim):
