@@ -1,0 +1,131 @@
+"""Colour correction after VAE decode: transfers the input clip's colours onto the
+upscaled frames.  Restated from src/utils/color_fix.py (results identical on the same inputs):
+
+  adaptive_instance_normalization   :72-120   per-channel mean / std transfer
+  wavelet_blur / _decomposition     :122-185  5-level a-trous pyramid, 3x3 binomial kernel, dilation 2^i capped at
+                                               min(H, W) // 8, replicate padding
+  wavelet_reconstruction            :187-247  content high frequencies + style low frequencies, clamp [-1, 1]
+  lab_color_transfer                :249-366  wavelet base -> CIELAB (D65) -> per-channel histogram matching
+                                               (a*, b* fully, L* blended with luminance_weight) -> RGB
+  _rgb_to_lab_batch / _lab_to_rgb_batch / _histogram_matching_channel   :368-522
+
+All tensors are [B, C, H, W] in [-1, 1]; the work is HBM / sort bound (no MFMA), so it stays torch glue on
+the device.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _resize_like(style: torch.Tensor, content: torch.Tensor) -> torch.Tensor:
+    if style.shape[-2:] == content.shape[-2:]:
+        return style
+    return F.interpolate(style.float(), size=content.shape[-2:], mode="bilinear", align_corners=False).to(style.dtype)
+
+
+def adaptive_instance_normalization(content: torch.Tensor, style: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    def mean_std(x):
+        b, c = x.shape[:2]
+        flat = x.reshape(b, c, -1)
+        return flat.mean(dim=2).reshape(b, c, 1, 1), (flat.var(dim=2) + eps).sqrt().reshape(b, c, 1, 1)
+
+    s_mean, s_std = mean_std(style)
+    c_mean, c_std = mean_std(content)
+    return (content - c_mean) / c_std * s_std + s_mean
+
+
+def wavelet_blur(image: torch.Tensor, radius: int) -> torch.Tensor:
+    radius = min(radius, max(1, min(image.shape[-2:]) // 8))
+    c = image.shape[1]
+    k = torch.tensor([[0.0625, 0.125, 0.0625], [0.125, 0.25, 0.125], [0.0625, 0.125, 0.0625]],
+                     dtype=image.dtype, device=image.device)[None, None].repeat(c, 1, 1, 1)
+    padded = F.pad(image, (radius, radius, radius, radius), mode="replicate")
+    return F.conv2d(padded, k, groups=c, dilation=radius)
+
+
+def wavelet_decomposition(image: torch.Tensor, levels: int = 5):
+    high = torch.zeros_like(image)
+    low = image
+    for i in range(levels):
+        low = wavelet_blur(image, 2 ** i)
+        high = high + image - low
+        image = low
+    return high, low
+
+
+def wavelet_reconstruction(content: torch.Tensor, style: torch.Tensor) -> torch.Tensor:
+    style = _resize_like(style, content)
+    high, _ = wavelet_decomposition(content)
+    _, low = wavelet_decomposition(style)
+    return (high + low).clamp(-1.0, 1.0)
+
+
+_RGB2XYZ = [[0.4124564, 0.3575761, 0.1804375], [0.2126729, 0.7151522, 0.0721750], [0.0193339, 0.1191920, 0.9503041]]
+_XYZ2RGB = [[3.2404542, -1.5371385, -0.4985314], [-0.9692660, 1.8760108, 0.0415560], [0.0556434, -0.2040259, 1.0572252]]
+_EPS, _KAPPA = 6.0 / 29.0, (29.0 / 3.0) ** 3
+
+
+def rgb_to_lab(rgb: torch.Tensor) -> torch.Tensor:
+    """[B, 3, H, W] sRGB in [0, 1] (fp32) -> CIELAB, D65."""
+    m = torch.tensor(_RGB2XYZ, dtype=torch.float32, device=rgb.device)
+    lin = torch.where(rgb > 0.04045, torch.pow((rgb + 0.055) / 1.055, 2.4), rgb / 12.92)
+    b, _, h, w = lin.shape
+    xyz = torch.matmul(lin.permute(0, 2, 3, 1).reshape(-1, 3), m.T).reshape(b, h, w, 3).permute(0, 3, 1, 2).clone()
+    xyz[:, 0] = xyz[:, 0] / 0.95047
+    xyz[:, 2] = xyz[:, 2] / 1.08883
+    f = torch.where(xyz > _EPS ** 3, torch.pow(xyz, 1.0 / 3.0), (xyz * _KAPPA + 16.0) / 116.0)
+    return torch.stack([f[:, 1] * 116.0 - 16.0, (f[:, 0] - f[:, 1]) * 500.0, (f[:, 1] - f[:, 2]) * 200.0], dim=1)
+
+
+def lab_to_rgb(lab: torch.Tensor) -> torch.Tensor:
+    m = torch.tensor(_XYZ2RGB, dtype=torch.float32, device=lab.device)
+    fy = (lab[:, 0] + 16.0) / 116.0
+    fx = lab[:, 1] / 500.0 + fy
+    fz = fy - lab[:, 2] / 200.0
+
+    def inv(f):
+        return torch.where(f > _EPS, torch.pow(f, 3.0), (f * 116.0 - 16.0) / _KAPPA)
+
+    xyz = torch.stack([inv(fx) * 0.95047, inv(fy), inv(fz) * 1.08883], dim=1)
+    b, _, h, w = xyz.shape
+    lin = torch.matmul(xyz.permute(0, 2, 3, 1).reshape(-1, 3), m.T).reshape(b, h, w, 3).permute(0, 3, 1, 2)
+    rgb = torch.where(lin > 0.0031308, torch.pow(torch.clamp(lin, min=0.0), 1.0 / 2.4) * 1.055 - 0.055, lin * 12.92)
+    return torch.clamp(rgb, 0.0, 1.0)
+
+
+def histogram_match(source: torch.Tensor, reference: torch.Tensor) -> torch.Tensor:
+    """Quantile mapping of ``source`` onto ``reference`` (any shapes): the k-th smallest source value becomes the
+    k-th smallest reference value (nearest-rank when the sizes differ)."""
+    shape = source.shape
+    src_sorted_idx = torch.sort(source.flatten()).indices
+    ref_sorted = torch.sort(reference.flatten()).values
+    n_s, n_r = src_sorted_idx.numel(), ref_sorted.numel()
+    if n_s != n_r:
+        q = torch.linspace(0, 1, n_s, device=source.device)
+        ref_sorted = ref_sorted[(q * (n_r - 1)).long().clamp_(0, n_r - 1)]
+    out = torch.empty_like(ref_sorted)
+    out[src_sorted_idx] = ref_sorted          # == matched_sorted[argsort(source_indices)]
+    return out.reshape(shape)
+
+
+def lab_color_transfer(content: torch.Tensor, style: torch.Tensor, luminance_weight: float = 0.8) -> torch.Tensor:
+    content = wavelet_reconstruction(content, style)
+    style = _resize_like(style, content)
+    dt = content.dtype
+    c = ((content.float() + 1.0) * 0.5).clamp(0.0, 1.0)
+    s = ((style.float() + 1.0) * 0.5).clamp(0.0, 1.0)
+    c_lab, s_lab = rgb_to_lab(c), rgb_to_lab(s)
+    a = histogram_match(c_lab[:, 1], s_lab[:, 1])
+    b = histogram_match(c_lab[:, 2], s_lab[:, 2])
+    if luminance_weight < 1.0:
+        L = c_lab[:, 0] * luminance_weight + histogram_match(c_lab[:, 0], s_lab[:, 0]) * (1.0 - luminance_weight)
+    else:
+        L = c_lab[:, 0]
+    rgb = lab_to_rgb(torch.stack([L, a, b], dim=1))
+    return (rgb * 2.0 - 1.0).to(dt)
+
+
+METHODS = {
+    "lab": lambda c, s: lab_color_transfer(c, s, luminance_weight=0.8),
+    "wavelet": wavelet_reconstruction,
+    "adain": adaptive_instance_normalization,
+}

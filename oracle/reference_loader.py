@@ -100,3 +100,65 @@ def build_reference_vae(state_dict=None, dtype=None, block_out_channels=None, sl
         vae.set_causal_slicing(split_size=4, memory_device="same")
         vae.set_memory_limit(conv_max_mem=0.5, norm_max_mem=0.5)
     return vae
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Phase-glue functions.  Their modules import torchvision / omegaconf / cv2, which are
+# not installed here, so the *function definitions* are compiled straight from the reference source files
+# (unmodified text, selected by name with ``ast``) into a namespace that only provides what they touch.
+def _extract(path: str, names, namespace: dict) -> dict:
+    import ast
+    src = open(os.path.join(REFERENCE_ROOT, path)).read()
+    tree = ast.parse(src)
+    picked = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    missing = set(names) - {n.name for n in picked}
+    if missing:
+        raise ImportError(f"{path}: {sorted(missing)} not found")
+    mod = ast.Module(body=picked, type_ignores=[])
+    exec(compile(mod, os.path.join(REFERENCE_ROOT, path), "exec"), namespace)
+    return namespace
+
+
+def reference_glue():
+    """dict with the reference's pad_video_temporal, blend_overlapping_frames, SideResize, DivisiblePad and the
+    colour-fix functions.  ``TVF.resize`` is bound to the restatement of torchvision's tensor path (third-party,
+    un-vendored: see transforms.py header) -- everything else runs from the reference text."""
+    import typing
+    import torch
+    import torch.nn.functional as F
+    from PIL import Image
+
+    class _Interp:          # torchvision.transforms.InterpolationMode stand-in
+        BICUBIC, BILINEAR = "bicubic", "bilinear"
+
+    class _TVF:
+        @staticmethod
+        def resize(img, size, interpolation=_Interp.BICUBIC, antialias=True):
+            h, w = img.shape[-2:]
+            if isinstance(size, int):
+                short, long = (w, h) if w <= h else (h, w)
+                new_short, new_long = size, int(size * long / short)
+                size = (new_long, new_short) if w <= h else (new_short, new_long)
+            dt = img.dtype
+            x = img if dt in (torch.float32, torch.float64) else img.float()
+            squeeze = x.dim() == 3
+            if squeeze:
+                x = x.unsqueeze(0)
+            y = F.interpolate(x, size=list(size), mode=interpolation, align_corners=False, antialias=antialias)
+            return (y.squeeze(0) if squeeze else y).to(dt)
+
+    ns = {"torch": torch, "F": F, "Tensor": torch.Tensor, "Image": Image, "Union": typing.Union,
+          "Optional": typing.Optional, "Dict": typing.Dict, "Any": typing.Any, "InterpolationMode": _Interp,
+          "TVF": _TVF, "is_mps_available": lambda: False,
+          "safe_pad_operation": lambda x, pad, mode="constant", value=0.0: F.pad(x, pad, mode=mode, value=value)
+          if mode == "constant" else F.pad(x, pad, mode=mode),
+          "safe_interpolate_operation": lambda x, **kw: F.interpolate(x, **kw),
+          "ensure_float32_precision": lambda t: (t.float(), t.dtype)}
+    _extract("src/core/generation_utils.py", ["pad_video_temporal", "blend_overlapping_frames"], ns)
+    _extract("src/data/image/transforms/side_resize.py", ["SideResize"], ns)
+    _extract("src/data/image/transforms/divisible_crop.py", ["DivisiblePad"], ns)
+    _extract("src/utils/color_fix.py",
+             ["calc_mean_std", "adaptive_instance_normalization", "wavelet_blur", "wavelet_decomposition",
+              "wavelet_reconstruction", "lab_color_transfer", "_rgb_to_lab_batch", "_lab_to_rgb_batch",
+              "_histogram_matching_channel"], ns)
+    return ns
