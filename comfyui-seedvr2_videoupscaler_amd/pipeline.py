@@ -66,7 +66,8 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
             temporal_overlap: int = 0, prepend_frames: int = 0, color_correction: str = "lab",
             input_noise_scale: float = 0.0, latent_noise_scale: float = 0.0, seed: int = 42,
             batch_filter: Optional[Callable[[int], bool]] = None,
-            progress: Optional[Callable[[str, int, int], None]] = None) -> torch.Tensor:
+            progress: Optional[Callable[[str, int, int], None]] = None,
+            noise_provider: Optional[Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None) -> torch.Tensor:
     """images [T, H, W, 3] in [0, 1] (any float dtype, on the runner's device) -> upscaled [T, H', W', 3] in [0, 1].
 
     ``batch_filter(i)`` restricts phases 1-3 to the temporal batches a rank owns (data parallelism over
@@ -102,8 +103,12 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
         torch.manual_seed(seed)                        # identical RNG state for every batch (generation_phases.py:663)
         if dev.type == "cuda":
             torch.cuda.manual_seed(seed)
-        base_noise = torch.randn_like(latent)
-        aug_noise = base_noise * 0.1 + torch.randn_like(base_noise) * 0.05
+        if noise_provider is None:
+            base_noise = torch.randn_like(latent)
+            extra = torch.randn_like(base_noise)
+        else:
+            base_noise, extra = (t.to(device=dev, dtype=dt) for t in noise_provider(latent))
+        aug_noise = base_noise * 0.1 + extra * 0.05
         blur = latent
         if latent_noise_scale != 0.0:
             t = torch.tensor([1000.0], device=dev, dtype=dt) * latent_noise_scale

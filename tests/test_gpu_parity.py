@@ -148,3 +148,32 @@ def test_dit_window_attention_properties_full_size(hip):
         hip.attn_varlen(qkv, out, seq, dst, cu, L, heads, D, 1 / math.sqrt(D))
         outs.append(out[-Lt:].float())
     assert rel_err(outs[1], outs[0]) < 4e-3
+
+
+def test_pipeline_four_phases_gpu_vs_fp32_double(hip):
+    """The whole N1-N3 + hot path chain (batching, 4n+1 padding, transform, encode, one-step DiT, decode, overlap blend,
+    LAB colour fix) on the GPU against the same pipeline driving fp32 torch doubles of the engines on the CPU,
+    same weights, same noise: PSNR >= 30 dB on the [0, 1] output frames (bf16 storage end to end)."""
+    from ops_reference import TorchOps
+    config, weights, dit, vae, runner, pipeline = (sub(n) for n in ("config", "weights", "dit", "vae", "runner", "pipeline"))
+    dcfg, vcfg = config.DIT_TINY, config.VAEConfig(block_out_channels=(128, 128, 128, 128))   # GroupNorm kernels need >= 4 ch / group
+    dsd, vsd = weights.synth_dit_state_dict(dcfg, seed=21), weights.synth_vae_state_dict(vcfg, seed=22)
+    txt = weights.synth_text_embedding()
+    g = torch.Generator().manual_seed(4)
+    images = torch.rand(11, 24, 40, 3, generator=g)
+
+    def noise(lat):
+        gg = torch.Generator().manual_seed(lat.numel())
+        return torch.randn(lat.shape, generator=gg), torch.randn(lat.shape, generator=gg)
+
+    outs = []
+    for ops, dev in ((hip, "cuda"), (TorchOps("cpu", act_dtype=torch.float32), "cpu")):
+        r = runner.VideoDiffusionInfer(runner.default_config(dcfg, vcfg))
+        r.dit, r.vae = dit.NaDiTEngine(dcfg, dsd, ops), vae.VideoVAEEngine(vcfg, vsd, ops)
+        out = pipeline.upscale(images.to(dev), r, txt.to(dev), resolution=48, batch_size=5, uniform_batch_size=True,
+                               temporal_overlap=2, color_correction="lab", noise_provider=noise)
+        outs.append(out.float().cpu())
+    assert outs[0].shape == outs[1].shape == (11, 48, 80, 3)
+    p = psnr(outs[0], outs[1])
+    print(f"pipeline GPU vs fp32 double: PSNR {p:.1f} dB")
+    assert p > 30
