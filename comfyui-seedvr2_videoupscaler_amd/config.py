@@ -24,11 +24,23 @@ class DiTConfig:
     window: Tuple[int, int, int] = (4, 3, 3)
     rope_dim: int = 128              # rope_type mmrope3d: 3 axes x (128 // 3 = 42) dims
     expand_ratio: int = 4
+    # ---- the 7B family (configs_7b/main.yaml:11-33, src/models/dit_7b) differs in exactly these:
+    mlp_type: str = "swiglu"         # "normal": Linear+bias -> GELU(tanh) -> Linear+bias, hidden = 4 d (dit_7b/mlp.py:28-43)
+    rope_type: str = "mmrope3d"      # "rope3d": video tokens only, "pixel" frequencies linspace(1, 128, 10) * pi,
+                                     # positions linspace(-1, 1, n) along each window axis, 3 x 20 dims (dit_7b/rope.py)
+    out_norm: bool = True            # 3B: vid_out_norm + vid_out_ada before the output projection; 7B: none
+    last_vid_only: bool = True       # 3B: the last block's ada / mlp are video-only (mmsr_block.py:73-81); 7B: full block
 
     @property
-    def mlp_hidden(self) -> int:     # src/models/dit_3b/mlp.py:53-54
+    def mlp_hidden(self) -> int:     # src/models/dit_3b/mlp.py:53-54 / dit_7b/mlp.py:35
+        if self.mlp_type == "normal":
+            return self.vid_dim * self.expand_ratio
         h = int(2 * self.vid_dim * self.expand_ratio / 3)
         return 256 * ((h + 255) // 256)
+
+    @property
+    def rope_freqs(self) -> int:     # frequencies per axis
+        return (self.head_dim // 2 // 3) // 2 if self.rope_type == "rope3d" else (self.rope_dim // 3) // 2
 
     @property
     def emb_dim(self) -> int:
@@ -52,6 +64,10 @@ class DiTConfig:
 
 
 DIT_3B = DiTConfig()
+DIT_7B = DiTConfig(vid_dim=3072, heads=24, num_layers=36, mm_layers=36, mlp_type="normal", rope_type="rope3d",
+                   out_norm=False, last_vid_only=False)
+DIT_7B_TINY = DiTConfig(vid_dim=256, heads=2, num_layers=4, mm_layers=4, mlp_type="normal", rope_type="rope3d",
+                        out_norm=False, last_vid_only=False)
 # Reduced-width config used by fast parity tests (same code path: 2 separate + 2 shared
 # layers, last layer vid-only MLP, regular + shifted windows).
 DIT_TINY = DiTConfig(vid_dim=256, heads=2, num_layers=4, mm_layers=2)

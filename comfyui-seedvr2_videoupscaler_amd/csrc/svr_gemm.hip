@@ -53,6 +53,9 @@ SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f
     if (epi == SVR_EPI_BIAS_SILU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
+    } else if (epi == SVR_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
     } else if (epi == SVR_EPI_RESID_GATE) {
         if (a.gate) {
 #pragma unroll

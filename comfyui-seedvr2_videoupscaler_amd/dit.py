@@ -16,6 +16,12 @@ Design (MI355X-first, not a module-by-module translation):
     SiLU(gate)*in inside the MLP-in GEMM epilogue (weights interleaved at load);
   * the reference's ``vid_out_ada`` cache-key collision (it modulates with the *attn* slot of the
     timestep embedding) is reproduced deliberately.
+
+The 7B family (src/models/dit_7b) runs through the same engine: ``cfg.mm_layers ==
+num_layers`` (separate vid / txt weights everywhere), ``mlp_type "normal"`` (bias + GELU(tanh) fused into the
+MLP-in GEMM epilogue, bias + gate + residual into MLP-out), ``rope_type "rope3d"`` (video tokens only; the
+fractional window positions linspace(-1, 1, n) become rows of a per-layer cos/sin table, so the same in-place
+q/k-norm + RoPE kernel serves both families), ``out_norm False`` and a full last block.
 """
 import math
 from dataclasses import dataclass
@@ -26,7 +32,7 @@ import torch
 
 from . import windows
 from .config import DiTConfig
-from .ops import EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU
+from .ops import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU
 from .packing import pack_matrix, pack_swiglu, pack_vec
 
 BF16 = torch.bfloat16
@@ -73,7 +79,7 @@ class NaDiTEngine:
         self.txt_in = lin("txt_in")
         self.emb_in = [lin("emb_in.proj_in"), lin("emb_in.proj_hid"), lin("emb_in.proj_out")]
         self.vid_out = lin("vid_out.proj")
-        self.out_norm_w = pack_vec(sd["vid_out_norm.weight"], dev)
+        self.out_norm_w = pack_vec(sd["vid_out_norm.weight"], dev) if cfg.out_norm else None
         self.kpad_in = self.vid_in.k
 
         # ---- per-block weights
@@ -98,9 +104,13 @@ class NaDiTEngine:
                 s["out"] = lin(p + f"attn.proj_out.{b}")
                 s["wq"] = pack_vec(sd[p + f"attn.norm_q.{b}.weight"], dev)
                 s["wk"] = pack_vec(sd[p + f"attn.norm_k.{b}.weight"], dev)
-                wg, wi = sd[p + f"mlp.{b}.proj_in_gate.weight"], sd[p + f"mlp.{b}.proj_in.weight"]
-                s["mlp_in"] = _Lin(pack_swiglu(wg, wi, dev), None, 2 * wg.shape[0], wg.shape[1])
-                s["mlp_out"] = lin(p + f"mlp.{b}.proj_out", bias=False)
+                if cfg.mlp_type == "normal":
+                    s["mlp_in"] = lin(p + f"mlp.{b}.proj_in")
+                    s["mlp_out"] = lin(p + f"mlp.{b}.proj_out")
+                else:
+                    wg, wi = sd[p + f"mlp.{b}.proj_in_gate.weight"], sd[p + f"mlp.{b}.proj_in.weight"]
+                    s["mlp_in"] = _Lin(pack_swiglu(wg, wi, dev), None, 2 * wg.shape[0], wg.shape[1])
+                    s["mlp_out"] = lin(p + f"mlp.{b}.proj_out", bias=False)
                 # AdaSingle parameters; slot = l*3 + g with l in (attn, mlp), g in (shift, scale, gate)
                 s["ada"] = {}
                 for l, lname in enumerate(("attn", "mlp")):
@@ -109,9 +119,9 @@ class NaDiTEngine:
                 blk[stream] = s
             blk["freqs"] = sd[p + "attn.rope.rope.freqs"].float().cpu()
             self.blocks.append(blk)
-        # output modulation reuses the attn slot (l = 0) of the embedding: shift g=0, scale g=1
-        self.ada_out_shift = add_ada("vid_out_ada.out_shift", 0)
-        self.ada_out_scale = add_ada("vid_out_ada.out_scale", 1)
+        if cfg.out_norm:   # output modulation reuses the attn slot (l = 0) of the embedding: shift g=0, scale g=1
+            self.ada_out_shift = add_ada("vid_out_ada.out_shift", 0)
+            self.ada_out_scale = add_ada("vid_out_ada.out_scale", 1)
         self.ada_params = torch.stack(ada_rows).to(dev).contiguous()
         self.ada_slots = torch.tensor(ada_slots, dtype=torch.int32, device=dev)
         self._plan_cache = {}
@@ -145,8 +155,29 @@ class NaDiTEngine:
         res = dict(n_win=n_win, max_len=int(lens.max()) + Lt,
                    seq_rows=torch.from_numpy(seq_rows).to(dev), out_rows=torch.from_numpy(out_rows).to(dev),
                    cu=torch.from_numpy(cu).to(dev), pos=torch.from_numpy(plan.pos.copy()).to(dev))
+        if self.cfg.rope_type == "rope3d":
+            # 7B: position along an axis of extent n is linspace(-1, 1, n)[idx]; one table row per (n, idx), row 0 = angle 0
+            extents = sorted({int(v) for v in np.unique(plan.shapes)})
+            offs, values = {}, [0.0]
+            for n in extents:
+                offs[n] = len(values)
+                values.extend(torch.linspace(-1, 1, steps=n).tolist())
+            rows = np.zeros((N, 3), dtype=np.int16)
+            for wi in range(n_win):
+                tok = plan.tok[plan.cu[wi]:plan.cu[wi + 1]]
+                for a in range(3):
+                    rows[tok, a] = offs[int(plan.shapes[wi][a])] + plan.pos[tok, a]
+            res["pos"] = torch.from_numpy(rows).to(dev)
+            res["pos_values"] = torch.tensor(values, dtype=torch.float32)
         self._plan_cache[key] = res
         return res
+
+    def _rope3d_tables(self, freqs: torch.Tensor, values: torch.Tensor):
+        key = (tuple(freqs.tolist()), tuple(values.tolist()))
+        if key not in self._rope_cache:
+            ang = values[:, None] * freqs[None, :]                                      # fp32, as the reference
+            self._rope_cache[key] = (ang.cos().to(self.device).contiguous(), ang.sin().to(self.device).contiguous())
+        return self._rope_cache[key]
 
     def _rope_tables(self, freqs: torch.Tensor, n_pos: int):
         key = (tuple(freqs.tolist()), n_pos)
@@ -196,13 +227,20 @@ class NaDiTEngine:
         pos_t = torch.stack([jt, jt, jt], dim=-1).contiguous().to(self.device)
         scale = 1.0 / math.sqrt(hd)
 
+        rope3d = cfg.rope_type == "rope3d"
+        if rope3d:
+            pos_t = torch.zeros(Lt, 3, dtype=torch.int16, device=self.device)           # table row 0: no rotation
         for li, blk in enumerate(self.blocks):
-            last = li == cfg.num_layers - 1
+            final = li == cfg.num_layers - 1          # after this block's attention the text stream is dead
+            last = final and cfg.last_vid_only        # 3B: the last block's text branch is not modulated
             shared = blk["shared"]
             sv, st = blk["vid"], blk["txt"]
             plan = self._plan((t, h, w), cfg.window_method(li), Lt)
             n_win = plan["n_win"]
-            cos_t, sin_t = self._rope_tables(blk["freqs"], max(Lt + t, h, w) + 16)
+            if rope3d:
+                cos_t, sin_t = self._rope3d_tables(blk["freqs"], plan["pos_values"])
+            else:
+                cos_t, sin_t = self._rope_tables(blk["freqs"], max(Lt + t, h, w) + 16)
 
             # ---- attention branch
             ops.rmsnorm_mod(hid[:N], xn[:N], eps, scale=mod[sv["ada"][("attn", "scale")]],
@@ -217,48 +255,55 @@ class NaDiTEngine:
             else:
                 ops.gemm(xn[:N], sv["qkv"].w, qkv[:N], N=3 * inner, K=d)
                 ops.gemm(xn[N:], st["qkv"].w, qkv[N:], N=3 * inner, K=d)
-            ops.qknorm_rope(qkv[:N], heads, plan["pos"], Lt, cos_t, sin_t, sv["wq"], sv["wk"], eps)
+            ops.qknorm_rope(qkv[:N], heads, plan["pos"], 0 if rope3d else Lt, cos_t, sin_t, sv["wq"], sv["wk"], eps)
             ops.qknorm_rope(qkv[N:], heads, pos_t, 0, cos_t, sin_t, st["wq"], st["wk"], eps)
             att = ops.empty(R + n_win * Lt, inner)
             ops.attn_varlen(qkv, att, plan["seq_rows"], plan["out_rows"], plan["cu"], plan["max_len"], heads, hd, scale)
             ops.rows_mean(att[R:], att[N:R], n_win, Lt)
             g_v = mod[sv["ada"][("attn", "gate")]]
-            if shared and not last:
+            if shared and not final:
                 ops.gemm(att[:R], sv["out"].w, hid, N=d, K=inner, bias=sv["out"].b, epilogue=EPI_RESID_GATE,
                          gate=g_v, resid=hid)
             else:
                 ops.gemm(att[:N], sv["out"].w, hid[:N], N=d, K=inner, bias=sv["out"].b, epilogue=EPI_RESID_GATE,
                          gate=g_v, resid=hid[:N])
-                if not last:   # the text stream is dead after the last block's attention
+                if not final:  # the text stream is dead after the last block's attention
                     ops.gemm(att[N:R], st["out"].w, hid[N:], N=d, K=inner, bias=st["out"].b,
                              epilogue=EPI_RESID_GATE, gate=mod[st["ada"][("attn", "gate")]], resid=hid[N:])
             del att
 
-            # ---- MLP branch (SwiGLU); vid-only in the last block
+            # ---- MLP branch (3B: SwiGLU, 7B: GELU); video only in the last block (its text output is never read)
             hm = cfg.mlp_hidden
             ops.rmsnorm_mod(hid[:N], xn[:N], eps, scale=mod[sv["ada"][("mlp", "scale")]],
                             shift=mod[sv["ada"][("mlp", "shift")]])
-            if not last:
+            if not final:
                 ops.rmsnorm_mod(hid[N:], xn[N:], eps, scale=mod[st["ada"][("mlp", "scale")]],
                                 shift=mod[st["ada"][("mlp", "shift")]])
             gm_v = mod[sv["ada"][("mlp", "gate")]]
-            if shared and not last:
-                ops.gemm(xn, sv["mlp_in"].w, h1, N=2 * hm, K=d, epilogue=EPI_SWIGLU)
-                ops.gemm(h1, sv["mlp_out"].w, hid, N=d, K=hm, epilogue=EPI_RESID_GATE, gate=gm_v, resid=hid)
+
+            def mlp(rows, s_, gate):
+                if cfg.mlp_type == "normal":
+                    ops.gemm(xn[rows], s_["mlp_in"].w, h1[rows], N=hm, K=d, bias=s_["mlp_in"].b, epilogue=EPI_BIAS_GELU)
+                else:
+                    ops.gemm(xn[rows], s_["mlp_in"].w, h1[rows], N=2 * hm, K=d, epilogue=EPI_SWIGLU)
+                ops.gemm(h1[rows], s_["mlp_out"].w, hid[rows], N=d, K=hm, bias=s_["mlp_out"].b,
+                         epilogue=EPI_RESID_GATE, gate=gate, resid=hid[rows])
+
+            if shared and not final:
+                mlp(slice(0, R), sv, gm_v)
             else:
-                ops.gemm(xn[:N], sv["mlp_in"].w, h1[:N], N=2 * hm, K=d, epilogue=EPI_SWIGLU)
-                ops.gemm(h1[:N], sv["mlp_out"].w, hid[:N], N=d, K=hm, epilogue=EPI_RESID_GATE, gate=gm_v,
-                         resid=hid[:N])
-                if not last:
-                    ops.gemm(xn[N:], st["mlp_in"].w, h1[N:], N=2 * hm, K=d, epilogue=EPI_SWIGLU)
-                    ops.gemm(h1[N:], st["mlp_out"].w, hid[N:], N=d, K=hm, epilogue=EPI_RESID_GATE,
-                             gate=mod[st["ada"][("mlp", "gate")]], resid=hid[N:])
+                mlp(slice(0, N), sv, gm_v)
+                if not final:
+                    mlp(slice(N, R), st, mod[st["ada"][("mlp", "gate")]])
 
         # ---- output head
-        ops.rmsnorm_mod(hid[:N], xn[:N], eps, w=self.out_norm_w, scale=mod[self.ada_out_scale],
-                        shift=mod[self.ada_out_shift])
         pred = ops.empty(N, cfg.patch_out_dim)
-        ops.gemm(xn[:N], self.vid_out.w, pred, N=cfg.patch_out_dim, K=d, bias=self.vid_out.b)
+        if cfg.out_norm:
+            ops.rmsnorm_mod(hid[:N], xn[:N], eps, w=self.out_norm_w, scale=mod[self.ada_out_scale],
+                            shift=mod[self.ada_out_shift])
+            ops.gemm(xn[:N], self.vid_out.w, pred, N=cfg.patch_out_dim, K=d, bias=self.vid_out.b)
+        else:
+            ops.gemm(hid[:N], self.vid_out.w, pred, N=cfg.patch_out_dim, K=d, bias=self.vid_out.b)
         out = ops.empty(T, H, W, cfg.vid_out_channels)
         ops.unpatchify_euler(pred, None if x_t is None else x_t.contiguous(), out)
         return out

@@ -19,7 +19,8 @@ def dit_flops(cfg: DiTConfig, grid: Tuple[int, int, int], Lt: int = 58) -> dict:
     t, h, w = grid
     N = t * h * w
     d, hm = cfg.vid_dim, cfg.mlp_hidden
-    linear = cfg.num_layers * N * (2 * d * 3 * d + 2 * d * d + 3 * 2 * d * hm)
+    mlp = (2 if cfg.mlp_type == "normal" else 3) * 2 * d * hm          # 7B: two GEMMs of 4d; 3B: SwiGLU, three of 2.7d
+    linear = cfg.num_layers * N * (2 * d * 3 * d + 2 * d * d + mlp)
     linear += 2 * N * cfg.patch_in_dim * d + 2 * N * d * cfg.patch_out_dim
     attn = 0
     for li in range(cfg.num_layers):

@@ -16,7 +16,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "seedvr2_hip.h")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                "-mllvm", "-pragma-unroll-threshold=1000000"]
 
-EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU = 0, 1, 2, 3
+EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU, EPI_BIAS_GELU = 0, 1, 2, 3, 4
 
 
 class ConvGeom(C.Structure):

@@ -9,7 +9,7 @@ from typing import Optional
 import torch
 
 from . import hip_lib
-from .hip_lib import EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU  # noqa: F401 (re-export)
+from .hip_lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU  # noqa: F401 (re-export)
 
 BF16 = torch.bfloat16
 

@@ -53,6 +53,12 @@ def rope_freqs_lang(dim: int = 42, theta: float = 10000.0) -> torch.Tensor:
     return 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
 
 
+def rope_freqs_pixel(dim: int = 21, max_freq: float = 256.0) -> torch.Tensor:
+    """rotary_embedding_torch ``freqs_for='pixel'``: linspace(1, max_freq / 2, dim // 2) * pi.
+    The 7B NaRotaryEmbedding3d uses dim = (128 // 2) // 3 = 21 -> 10 freqs (dit_7b/rope.py:28-33, mmsr_block.py:64)."""
+    return torch.linspace(1.0, max_freq / 2, dim // 2) * math.pi
+
+
 def synth_dit_state_dict(cfg: DiTConfig, device="cpu", seed: int = SEED_WEIGHTS) -> Dict[str, torch.Tensor]:
     mk = _Maker(device, seed)
     d, hd = cfg.vid_dim, cfg.head_dim
@@ -81,20 +87,30 @@ def synth_dit_state_dict(cfg: DiTConfig, device="cpu", seed: int = SEED_WEIGHTS)
             sd[p + f"attn.norm_q.{b}.weight"] = mk.gain(hd)
         for b in branches:
             sd[p + f"attn.norm_k.{b}.weight"] = mk.gain(hd)
-        sd[p + "attn.rope.rope.freqs"] = rope_freqs_lang(cfg.rope_dim // 3).to(mk.device)
+        if cfg.rope_type == "rope3d":
+            sd[p + "attn.rope.rope.freqs"] = rope_freqs_pixel((hd // 2) // 3).to(mk.device)
+        else:
+            sd[p + "attn.rope.rope.freqs"] = rope_freqs_lang(cfg.rope_dim // 3).to(mk.device)
         for b in branches:
-            sd[p + f"mlp.{b}.proj_in_gate.weight"] = mk.linear_w(hid, d)
-            sd[p + f"mlp.{b}.proj_out.weight"] = mk.linear_w(d, hid)
-            sd[p + f"mlp.{b}.proj_in.weight"] = mk.linear_w(hid, d)
+            if cfg.mlp_type == "normal":
+                sd[p + f"mlp.{b}.proj_in.weight"] = mk.linear_w(hid, d)
+                sd[p + f"mlp.{b}.proj_in.bias"] = mk.bias(hid)
+                sd[p + f"mlp.{b}.proj_out.weight"] = mk.linear_w(d, hid)
+                sd[p + f"mlp.{b}.proj_out.bias"] = mk.bias(d)
+            else:
+                sd[p + f"mlp.{b}.proj_in_gate.weight"] = mk.linear_w(hid, d)
+                sd[p + f"mlp.{b}.proj_out.weight"] = mk.linear_w(d, hid)
+                sd[p + f"mlp.{b}.proj_in.weight"] = mk.linear_w(hid, d)
         for b in branches:
             for layer in ("attn", "mlp"):
                 # AdaSingle init, dit_3b/modulation.py:58-63
                 sd[p + f"ada.{b}.{layer}_shift"] = mk.normal((d,), 1.0 / math.sqrt(d))
                 sd[p + f"ada.{b}.{layer}_scale"] = mk.normal((d,), 1.0 / math.sqrt(d), mean=1.0)
                 sd[p + f"ada.{b}.{layer}_gate"] = mk.normal((d,), 1.0 / math.sqrt(d))
-    sd["vid_out_norm.weight"] = mk.gain(d)
-    sd["vid_out_ada.out_shift"] = mk.normal((d,), 1.0 / math.sqrt(d))
-    sd["vid_out_ada.out_scale"] = mk.normal((d,), 1.0 / math.sqrt(d), mean=1.0)
+    if cfg.out_norm:
+        sd["vid_out_norm.weight"] = mk.gain(d)
+        sd["vid_out_ada.out_shift"] = mk.normal((d,), 1.0 / math.sqrt(d))
+        sd["vid_out_ada.out_scale"] = mk.normal((d,), 1.0 / math.sqrt(d), mean=1.0)
     sd["vid_out.proj.weight"] = mk.linear_w(cfg.patch_out_dim, d)
     sd["vid_out.proj.bias"] = mk.bias(cfg.patch_out_dim)
     return sd

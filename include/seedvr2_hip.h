@@ -26,6 +26,7 @@ extern "C" {
 #define SVR_EPI_BIAS_SILU   1   /* C = silu(acc + bias)                 embedding.py:56-61     */
 #define SVR_EPI_RESID_GATE  2   /* C = resid + gate * (acc + bias)      mmsr_block.py:108-109,
                                    125-126 (AdaSingle "out" + residual); attn_video_vae.py:360 */
+#define SVR_EPI_BIAS_GELU   4   /* C = gelu_tanh(acc + bias)            dit_7b/mlp.py:36-41    */
 #define SVR_EPI_SWIGLU      3   /* C[:, h] = silu(acc[:, gate h]) * acc[:, in h]; W rows are
                                    interleaved in blocks of 16 (gate16 | in16)  mlp.py:60-61   */
 

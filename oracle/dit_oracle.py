@@ -20,6 +20,10 @@ Reference functions restated (file:line under /root/reference):
   SwiGLUMLP.forward                 src/models/dit_3b/mlp.py:46-62
   window partition                  src/models/dit_3b/window.py:28-83 (via the package's windows.py,
                                     which is separately checked against the reference functions)
+The 7B family (src/models/dit_7b: nadit.py:39-200, nablocks/mmsr_block.py:33-250, rope.py:28-111, mlp.py:28-43) is the
+same graph with: separate vid / txt weights in every block, a full last block, a biased GELU(tanh) MLP, RoPE on the
+video tokens only ("pixel" frequencies, positions linspace(-1, 1, n) per window axis, 60 of 128 dims) and no output
+norm / modulation -- selected by cfg.mlp_type / rope_type / out_norm / last_vid_only.
 The "vid_out_ada" cache-key collision is reproduced: the output
 modulation reuses the *attn* slot of the timestep embedding.
 """
@@ -108,7 +112,7 @@ def dit_forward(sd: Dict[str, torch.Tensor], cfg, vid: torch.Tensor, txt: torch.
     scale = 1.0 / math.sqrt(hd)
     for li in range(cfg.num_layers):
         shared = li >= cfg.mm_layers
-        last = li == cfg.num_layers - 1
+        last = li == cfg.num_layers - 1 and getattr(cfg, "last_vid_only", True)
         bv, bt = ("all", "all") if shared else ("vid", "txt")
         p = f"blocks.{li}."
         plan = windows_mod.plan_windows((t, h, w), tuple(cfg.window), cfg.window_method(li))
@@ -126,12 +130,26 @@ def dit_forward(sd: Dict[str, torch.Tensor], cfg, vid: torch.Tensor, txt: torch.
         kt = rms_norm(qkv_t[:, 1], eps, _w(sd, p + f"attn.norm_k.{bt}.weight", dtype))
         vv, vt = qkv_v[:, 2], qkv_t[:, 2]
         freqs = sd[p + "attn.rope.rope.freqs"].float()
-        pos_v = torch.from_numpy(plan.pos.astype("int64")).clone()
-        pos_v[:, 0] += Lt                  # video tokens sit after the text on the temporal axis
-        jt = torch.arange(Lt)
-        pos_t = torch.stack([jt, jt, jt], dim=-1)
-        qv, kv = apply_rope(qv, rope_angles(freqs, pos_v)), apply_rope(kv, rope_angles(freqs, pos_v))
-        qt, kt = apply_rope(qt, rope_angles(freqs, pos_t)), apply_rope(kt, rope_angles(freqs, pos_t))
+        if getattr(cfg, "rope_type", "mmrope3d") == "rope3d":
+            # 7B: get_axial_freqs(f, h, w) of each window, pos = linspace(-1, 1, n); text tokens are not rotated
+            ang = torch.zeros(N, 6 * freqs.numel())
+            tokl = torch.from_numpy(plan.tok.astype("int64"))
+            for wi in range(plan.n_win):
+                rows = tokl[plan.cu[wi]:plan.cu[wi + 1]]
+                parts = []
+                for a in range(3):
+                    lin = torch.linspace(-1, 1, steps=int(plan.shapes[wi][a]))
+                    idx = torch.from_numpy(plan.pos[rows.numpy(), a].astype("int64"))
+                    parts.append((lin[idx][:, None] * freqs[None, :]).repeat_interleave(2, dim=-1))
+                ang[rows] = torch.cat(parts, dim=-1)
+            qv, kv = apply_rope(qv, ang), apply_rope(kv, ang)
+        else:
+            pos_v = torch.from_numpy(plan.pos.astype("int64")).clone()
+            pos_v[:, 0] += Lt              # video tokens sit after the text on the temporal axis
+            jt = torch.arange(Lt)
+            pos_t = torch.stack([jt, jt, jt], dim=-1)
+            qv, kv = apply_rope(qv, rope_angles(freqs, pos_v)), apply_rope(kv, rope_angles(freqs, pos_v))
+            qt, kt = apply_rope(qt, rope_angles(freqs, pos_t)), apply_rope(kt, rope_angles(freqs, pos_t))
 
         out_v = torch.empty(N, H, hd, dtype=dtype)
         out_t = torch.zeros(Lt, H, hd, dtype=dtype)
@@ -155,6 +173,10 @@ def dit_forward(sd: Dict[str, torch.Tensor], cfg, vid: torch.Tensor, txt: torch.
 
         # ---- MLP branch
         def mlp(hid, b):
+            if getattr(cfg, "mlp_type", "swiglu") == "normal":
+                u = F.linear(hid, _w(sd, p + f"mlp.{b}.proj_in.weight", dtype), _w(sd, p + f"mlp.{b}.proj_in.bias", dtype))
+                return F.linear(F.gelu(u, approximate="tanh"), _w(sd, p + f"mlp.{b}.proj_out.weight", dtype),
+                                _w(sd, p + f"mlp.{b}.proj_out.bias", dtype))
             g = F.linear(hid, _w(sd, p + f"mlp.{b}.proj_in_gate.weight", dtype))
             u = F.linear(hid, _w(sd, p + f"mlp.{b}.proj_in.weight", dtype))
             return F.linear(F.silu(g) * u, _w(sd, p + f"mlp.{b}.proj_out.weight", dtype))
@@ -167,9 +189,10 @@ def dit_forward(sd: Dict[str, torch.Tensor], cfg, vid: torch.Tensor, txt: torch.
             capture[f"block{li}.txt"] = y.clone()
 
     # --- output head (attn-slot modulation: cache-key collision in the reference, A9)
-    x = rms_norm(x, eps, _w(sd, "vid_out_norm.weight", dtype))
-    x = x * (emb[:, 0, 1] + _w(sd, "vid_out_ada.out_scale", dtype)) \
-        + (emb[:, 0, 0] + _w(sd, "vid_out_ada.out_shift", dtype))
+    if getattr(cfg, "out_norm", True):
+        x = rms_norm(x, eps, _w(sd, "vid_out_norm.weight", dtype))
+        x = x * (emb[:, 0, 1] + _w(sd, "vid_out_ada.out_scale", dtype)) \
+            + (emb[:, 0, 0] + _w(sd, "vid_out_ada.out_shift", dtype))
     x = F.linear(x, _w(sd, "vid_out.proj.weight", dtype), _w(sd, "vid_out.proj.bias", dtype))
     co = cfg.vid_out_channels
     x = x.reshape(t, h, w, ph, pw, co).permute(0, 1, 3, 2, 4, 5).reshape(T, Hh, Ww, co)

@@ -8,6 +8,7 @@ Fixtures (all tensors small; weights are NOT stored -- they are regenerated from
 ``<package>.weights`` on whichever machine runs the tests):
   text_pos_emb.pt     the reference's shipped prompt embedding (pos_emb.pt, [58,5120] bf16), data only
   dit_tiny.pt         DIT_TINY  forward, latent 3x24x40          (regular + shifted ragged windows)
+  dit7b_tiny.pt       DIT_7B_TINY forward (the dit_7b model code), latent 3x24x40
   dit3b_cfg1.pt       full SeedVR2-3B forward, latent 1x32x32    (BASELINE config 1 shape)
   vae_small.pt        full VAE encode/decode of a 5x64x96 clip, untiled and tiled (32x48 / 16)
 """
@@ -68,6 +69,14 @@ def main():
     torch.save({"vid": vid, "out": out, "seed_weights": weights.SEED_WEIGHTS, "config": "DIT_TINY"},
                os.path.join(GOLD, "dit_tiny.pt"))
     print("dit_tiny", tuple(out.shape), float(out.std()))
+
+    # ---- DiT 7B family (src/models/dit_7b), reduced width
+    cfg = config.DIT_7B_TINY
+    sd = weights.synth_dit_state_dict(cfg)
+    out = run_reference_dit(rl, cfg, sd, vid, txt)
+    torch.save({"vid": vid, "out": out, "seed_weights": weights.SEED_WEIGHTS, "config": "DIT_7B_TINY"},
+               os.path.join(GOLD, "dit7b_tiny.pt"))
+    print("dit7b_tiny", tuple(out.shape), float(out.std()))
 
     # ---- DiT 3B, BASELINE config 1
     if not args.skip_3b:

@@ -46,9 +46,33 @@ def reference_vae_class():
     return VideoAutoencoderKLWrapper
 
 
+def build_reference_dit_7b(cfg: dict, state_dict=None):
+    """The 7B family (src/models/dit_7b/nadit.py:39, configs_7b/main.yaml:11-33) at the given width / depth."""
+    import torch
+    _prepare()
+    with contextlib.redirect_stdout(io.StringIO()):
+        from src.models.dit_7b.nadit import NaDiT
+    L = cfg["num_layers"]
+    with torch.device("meta") if state_dict is not None else contextlib.nullcontext():
+        m = NaDiT(
+            vid_in_channels=cfg["vid_in_channels"], vid_out_channels=cfg["vid_out_channels"],
+            vid_dim=cfg["vid_dim"], txt_in_dim=cfg["txt_in_dim"], txt_dim=cfg["vid_dim"], emb_dim=6 * cfg["vid_dim"],
+            heads=cfg["heads"], head_dim=cfg["head_dim"], expand_ratio=4, norm="fusedrms",
+            norm_eps=cfg["norm_eps"], ada="single", qk_bias=False, qk_rope=True, qk_norm="fusedrms",
+            patch_size=[1, 2, 2], num_layers=L, shared_mlp=False, shared_qkv=False, mlp_type="normal",
+            block_type=["mmdit_sr"] * L, window=[(4, 3, 3)] * L,
+            window_method=(["720pwin_by_size_bysize", "720pswin_by_size_bysize"] * L)[:L],
+        )
+    if state_dict is not None:
+        m.load_state_dict(state_dict, strict=True, assign=True)
+    return m.eval().requires_grad_(False)
+
+
 def build_reference_dit(cfg: dict, state_dict=None, dtype=None):
     """cfg uses the keys of configs_3b/main.yaml:11-36 (see dit_config() in the package)."""
     import torch
+    if cfg.get("rope_type") == "rope3d":
+        return build_reference_dit_7b(cfg, state_dict)
     NaDiT = reference_nadit_class()
     L = cfg["num_layers"]
     with torch.device("meta") if state_dict is not None else contextlib.nullcontext():

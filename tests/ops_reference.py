@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 BF16 = torch.bfloat16
-EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU = 0, 1, 2, 3
+EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU, EPI_BIAS_GELU = 0, 1, 2, 3, 4
 
 
 class TorchOps:
@@ -65,7 +65,9 @@ class TorchOps:
             res = acc
             if bias is not None:
                 res = res + bias[:N].float()
-            if epilogue == EPI_BIAS_SILU:
+            if epilogue == EPI_BIAS_GELU:
+                res = F.gelu(res, approximate="tanh")
+            elif epilogue == EPI_BIAS_SILU:
                 res = F.silu(res)
             elif epilogue == EPI_RESID_GATE:
                 if gate is not None:

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from conftest import sub, rel_err
-from ops_reference import TorchOps, EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU
+from ops_reference import TorchOps, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
@@ -100,7 +100,7 @@ def test_gemm_epilogues(hip, ref):
     bias = rnd(N, dtype=torch.float32, seed=3)
     gate = rnd(N, dtype=torch.float32, seed=4)
     resid = rnd(M, N, seed=5)
-    for epi, kw in ((EPI_BIAS_SILU, {}), (EPI_RESID_GATE, dict(gate=gate, resid=resid)),
+    for epi, kw in ((EPI_BIAS_SILU, {}), (EPI_BIAS_GELU, {}), (EPI_RESID_GATE, dict(gate=gate, resid=resid)),
                     (EPI_RESID_GATE, dict(resid=resid)), (EPI_RESID_GATE, dict(gate=gate))):
         out = torch.empty(M, N, device="cuda", dtype=BF16)
         hip.gemm(A, W, out, N=N, K=K, bias=bias, epilogue=epi, **kw)

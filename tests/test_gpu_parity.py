@@ -43,6 +43,19 @@ def test_dit_tiny_vs_reference_golden(hip):
     assert rel_err(out, g["out"]) < 2.0e-2 and psnr(out, g["out"]) > 50
 
 
+def test_dit_7b_family_vs_reference_golden(hip):
+    """SeedVR2-7B graph (dit_7b: separate weights in every block, GELU MLP fused into the GEMM epilogue, pixel RoPE
+    through the table-driven q/k-norm + RoPE kernel, no output norm) at reduced width."""
+    config, weights, dit = sub("config"), sub("weights"), sub("dit")
+    g, txt = _golden("dit7b_tiny.pt"), _golden("text_pos_emb.pt")
+    cfg = config.DIT_7B_TINY
+    eng = dit.NaDiTEngine(cfg, weights.synth_dit_state_dict(cfg, seed=g["seed_weights"]), hip)
+    out = eng.forward(g["vid"].cuda(), txt.cuda(), 1000.0).float().cpu()
+    e, p = rel_err(out, g["out"]), psnr(out, g["out"])
+    print(f"DiT-7B family (tiny): rel-err {e:.3e}, PSNR {p:.1f} dB")
+    assert e < 2.0e-2 and p > 50
+
+
 def test_dit_3b_cfg1_vs_reference_golden(hip):
     """BASELINE config 1 shape (latent 1x32x32), full 32-layer SeedVR2-3B, synthetic weights."""
     config, weights, dit = sub("config"), sub("weights"), sub("dit")

@@ -34,6 +34,21 @@ def test_dit_engine_host_logic_matches_reference_golden():
     assert torch.equal(o2.reshape(T, H, W, -1), out)
 
 
+def test_dit_engine_7b_family_matches_reference_golden_and_oracle():
+    config, weights, dit, windows = sub("config"), sub("weights"), sub("dit"), sub("windows")
+    cfg = config.DIT_7B_TINY
+    g = torch.load(os.path.join(GOLDEN, "dit7b_tiny.pt"), weights_only=True)
+    txt = torch.load(os.path.join(GOLDEN, "text_pos_emb.pt"), weights_only=True)
+    eng = dit.NaDiTEngine(cfg, weights.synth_dit_state_dict(cfg), TorchOps("cpu", torch.float32))
+    assert rel_err(eng.forward(g["vid"].float(), txt.float(), 1000.0), g["out"]) < 1e-5
+    sd = weights.synth_dit_state_dict(cfg, seed=11)                                 # ragged grid: shifted sliver windows
+    eng = dit.NaDiTEngine(cfg, sd, TorchOps("cpu", torch.float32))
+    torch.manual_seed(0)
+    vid, t2 = torch.randn(5, 36, 60, 33), torch.randn(58, 5120)
+    want = dit_oracle.dit_forward(sd, cfg, vid, t2, 1000.0, windows_mod=windows)
+    assert rel_err(eng.forward(vid, t2, 1000.0), want) < 1e-5
+
+
 def test_dit_engine_ragged_grid_vs_oracle():
     config, weights, dit, windows = sub("config"), sub("weights"), sub("dit"), sub("windows")
     cfg = config.DIT_TINY
