@@ -70,3 +70,43 @@ def gather_batches(owned: Sequence[torch.Tensor], owned_idx: Sequence[int], n_ba
             if b < n_batches:
                 result[b] = gathered[r * F:(r + 1) * F]
     return result
+
+
+def upscale_sharded(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, **kw) -> torch.Tensor:
+    """pipeline.upscale() with the temporal batches dealt round-robin to the ranks of the default process group;
+    every rank returns the complete clip, identical to the single-rank result (same batch boundaries, the overlap
+    blend done by the owner of the blended frames).  Collectives: one small all-reduce of the overlap heads (only
+    with temporal_overlap > 0) and ONE all-gather of the upscaled bf16 frames."""
+    from . import pipeline
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return pipeline.upscale(images_thwc, runner, text_pos, **kw)
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def exchange(heads: dict, n_batches: int, shape: tuple) -> dict:
+        dense = torch.zeros((n_batches,) + tuple(shape), dtype=torch.float32, device=images_thwc.device)
+        for i, h in heads.items():
+            dense[i] = h.float()                                   # disjoint owners: the sum is an exact copy
+        dist.all_reduce(dense)
+        return {i: dense[i] for i in range(n_batches)}
+
+    final, spans = pipeline.upscale(images_thwc, runner, text_pos, batch_filter=lambda i: i % world == rank,
+                                    exchange_heads=exchange, return_spans=True, **kw)
+    # all-gather the frames each rank produced (padded to the largest share), then place them by span
+    mine = torch.cat([final[a:b] for _, (a, b) in sorted(spans.items())], dim=0) if spans else final[:0]
+    counts = torch.zeros(world, dtype=torch.int64, device=final.device)
+    counts[rank] = mine.shape[0]
+    dist.all_reduce(counts)
+    cap = int(counts.max())
+    padded = torch.zeros((cap,) + tuple(final.shape[1:]), dtype=final.dtype, device=final.device)
+    padded[:mine.shape[0]] = mine
+    gathered = all_gather_frames(padded).reshape((world, cap) + tuple(final.shape[1:]))
+    table = torch.full((final.shape[0],), -1, dtype=torch.int64, device=final.device)          # frame -> owner rank
+    for _, (a, b) in spans.items():
+        table[a:b] = rank
+    owner = table.clone()
+    dist.all_reduce(owner, op=dist.ReduceOp.MAX)
+    out = torch.empty_like(final)
+    for r in range(world):
+        idx = (owner == r).nonzero(as_tuple=True)[0]             # ascending = the order rank r concatenated them in
+        out[idx] = gathered[r, :idx.numel()]
+    return out

@@ -67,7 +67,9 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
             input_noise_scale: float = 0.0, latent_noise_scale: float = 0.0, seed: int = 42,
             batch_filter: Optional[Callable[[int], bool]] = None,
             progress: Optional[Callable[[str, int, int], None]] = None,
-            noise_provider: Optional[Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None) -> torch.Tensor:
+            noise_provider: Optional[Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None,
+            exchange_heads: Optional[Callable[[dict, int, tuple], dict]] = None,
+            return_spans: bool = False):
     """images [T, H, W, 3] in [0, 1] (any float dtype, on the runner's device) -> upscaled [T, H', W', 3] in [0, 1].
 
     ``batch_filter(i)`` restricts phases 1-3 to the temporal batches a rank owns (data parallelism over
@@ -121,9 +123,10 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
 
     # ---- phase 3: decode, trim, blend into the output clip ([-1, 1] until phase 4)
     final = torch.zeros(total, true_h, true_w, 3, dtype=dt, device=dev)
-    spans = {}
+    spans, heads, starts = {}, {}, {}
     write = 0
     for i, plan in enumerate(plans):
+        starts[i] = write
         ori = plan.end - plan.start
         n_new = ori if (i == 0 or overlap == 0) else max(ori - overlap, 0)
         if i in upscaled:
@@ -132,16 +135,23 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
                 sample = sample.unsqueeze(1)
             sample = sample.permute(1, 2, 3, 0)[:ori, :true_h, :true_w]                   # T H W C, padding trimmed
             if i > 0 and 0 < overlap < sample.shape[0] and write >= overlap:
-                prev_written = (i - 1) in spans
-                if prev_written:                                                          # both sides are on this rank
+                if (i - 1) in spans:                                                      # both sides are on this rank
                     final[write - overlap:write] = transforms.blend_overlapping_frames(
                         final[write - overlap:write], sample[:overlap], overlap)
+                else:
+                    heads[i] = sample[:overlap].contiguous()                              # blended by the previous batch's owner
                 sample = sample[overlap:]
             final[write:write + sample.shape[0]] = sample
             spans[i] = (write, write + sample.shape[0])
             if progress:
                 progress("decode", len(spans), len(mine))
         write += n_new
+
+    if exchange_heads is not None and overlap > 0:
+        for i, head in exchange_heads(heads, len(plans), (overlap, true_h, true_w, 3)).items():
+            if (i - 1) in spans and i not in spans:
+                w = starts[i]
+                final[w - overlap:w] = transforms.blend_overlapping_frames(final[w - overlap:w], head.to(final), overlap)
 
     # ---- phase 4: colour correction against the re-transformed input, [-1, 1] -> [0, 1]
     for i, (w0, w1) in spans.items():
@@ -159,4 +169,5 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
         final[w0:w1] = sample.permute(0, 2, 3, 1).clamp(-1, 1).mul(0.5).add(0.5).to(dt)
     if prepend_frames > 0:
         final = final[prepend_frames:]
-    return final
+        spans = {i: (max(a - prepend_frames, 0), max(b - prepend_frames, 0)) for i, (a, b) in spans.items()}
+    return (final, spans) if return_spans else final

@@ -61,3 +61,42 @@ def test_split_frames_and_round_robin():
     d = sub("dist")
     assert d.split_frames(128, 17) == [(i * 17, min((i + 1) * 17, 128)) for i in range(8)]
     assert d.batch_indices(8, 3, 8) == [3] and d.batch_indices(5, 1, 2) == [1, 3]
+
+
+def _pipeline_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from conftest import sub as _sub
+    from test_glue import _IdentityRunner
+    d = _sub("dist")
+    d.init_from_env(backend="gloo")
+    images = torch.rand(23, 16, 24, 3, generator=torch.Generator().manual_seed(5))
+    kw = dict(resolution=32, batch_size=7, uniform_batch_size=True, temporal_overlap=2, color_correction="wavelet")
+    out = d.upscale_sharded(images, _IdentityRunner(), torch.zeros(58, 8), **kw)
+    q.put((rank, out.float()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pipeline_equals_single_rank_with_overlap_blend():
+    """Sharded four-phase pipeline (batches dealt round-robin, overlap heads exchanged, frames all-gathered)
+    == the single-rank pipeline, bit for bit, on both ranks."""
+    from test_glue import _IdentityRunner
+    pipeline = sub("pipeline")
+    images = torch.rand(23, 16, 24, 3, generator=torch.Generator().manual_seed(5))
+    want = pipeline.upscale(images, _IdentityRunner(), torch.zeros(58, 8), resolution=32, batch_size=7,
+                            uniform_batch_size=True, temporal_overlap=2, color_correction="wavelet").float()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, out in res:
+        assert out.shape == want.shape and torch.equal(out, want)
