@@ -214,11 +214,11 @@ def main():
         try:     # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload (never measured live)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_cfg3_pmc_traffic.json")))
             if pmc.get("workload") == args.workload and "conv_halo" in kern:
-                traffic = pmc["kernels"]["svr::conv_halo_kernel<128, 0>"]["hbm_bytes_per_launch"]
+                traffic = pmc["kernels"][pmc.get("dominant", "svr::conv_halo2_kernel")]["hbm_bytes_per_launch"]
                 traffic_note = "bytes/launch, FETCH_SIZE*2 + WRITE_SIZE from profiles/r1_cfg3_pmc_traffic.json"
         except (OSError, KeyError, ValueError):
             pass
-        roof = {"bound": "mfma", "kernel": "svr::conv_halo_kernel<128> (LDS-halo implicit-GEMM causal Conv3d, 3x3 spatial taps)",
+        roof = {"bound": "mfma", "kernel": "svr::conv_halo2_kernel (LDS-halo implicit-GEMM causal Conv3d, 16x32-voxel patches, 3x3 spatial taps)",
                 "achieved": c_flops / max(c_sec, 1e-12) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": c_flops / max(c_sec, 1e-12) / 1e12 / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "traffic_note": traffic_note,

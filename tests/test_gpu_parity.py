@@ -190,3 +190,20 @@ def test_pipeline_four_phases_gpu_vs_fp32_double(hip):
     p = psnr(outs[0], outs[1])
     print(f"pipeline GPU vs fp32 double: PSNR {p:.1f} dB")
     assert p > 30
+
+
+def test_vae_full_tile_size_properties(hip):
+    """BASELINE cfg3's working size (one 1024-px tile, 17 frames): properties that do not need an oracle run --
+    temporal slicing is bit-invisible through the LDS-halo conv kernels, fused GroupNorm statistics and attention;
+    the encoder is deterministic; latent scaling is the only difference between encode() and encode_clip()."""
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    cfg = config.VAE_V3
+    eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg, device="cuda"), hip)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = (torch.rand(3, 17, 1024, 1024, generator=g, device="cuda") * 2 - 1).to(BF16)
+    a = eng.encode(x)
+    assert a.shape == (5, 128, 128, 16) and bool(torch.isfinite(a.float()).all())
+    assert torch.equal(a, eng.encode(x, frames_per_slice=8)) and torch.equal(a, eng.encode(x))
+    z = (torch.randn(5, 64, 64, 16, generator=g, device="cuda")).to(BF16)        # 512-px tile through the decoder
+    d = eng.decode(z)
+    assert d.shape == (3, 17, 512, 512) and torch.equal(d, eng.decode(z, latents_per_slice=2))
