@@ -117,6 +117,16 @@ int svr_attn_varlen(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, 
     return check(rc, "svr_attn_varlen");
 }
 
+int svr_softmax_rows(const float* S, void* P, int64_t rows, int32_t cols, int64_t ld_s, int64_t ld_p, float scale,
+                     void* stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    if (cols % 4 || cols > 256 * SM_MAXV * 4 || ld_s % 4 || ld_p % 4)
+        return fail("svr_softmax_rows: cols must be a multiple of 4 and <= 16384, leading dimensions multiples of 4");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, (bf16_t*)P, cols,
+                       ld_s, ld_p, scale * 1.4426950408889634f);
+    return check(hipGetLastError(), "svr_softmax_rows");
+}
+
 int svr_rows_mean(const void* src, void* dst, int32_t n_groups, int32_t rows_per_group, int32_t dim, void* stream) {
     if (n_groups <= 0 || rows_per_group <= 0) return 0;
     if (dim % 8) return fail("svr_rows_mean: dim must be a multiple of 8");

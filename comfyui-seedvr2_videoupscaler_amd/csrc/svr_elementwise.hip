@@ -313,6 +313,58 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row softmax of fp32 scores -> bf16 probabilities: P[r, :] = softmax(scale * S[r, :]).  One 256-thread block
+// per row, the row lives in registers (cols <= 16384), one read and one write of the matrix.  Used by the VAE
+// mid-block attention (single 512-wide head over H*W tokens, attn_video_vae.py:659-665), which runs as
+// Q K^T (MFMA GEMM, fp32 out) -> this kernel -> P V (MFMA GEMM).
+// ------------------------------------------------------------------------------------------------
+constexpr int SM_MAXV = 16;   // float4 per thread -> 256 * 16 * 4 = 16384 columns
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, bf16_t* __restrict__ P, int cols,
+                                                           int64_t ld_s, int64_t ld_p, float scale_log2) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4* sp = (const float4*)(S + (int64_t)blockIdx.x * ld_s);
+    const int nv = cols >> 2;
+    float4 v[SM_MAXV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nv) {
+            v[i] = sp[c];
+            v[i].x *= scale_log2; v[i].y *= scale_log2; v[i].z *= scale_log2; v[i].w *= scale_log2;
+            mx = fmaxf(fmaxf(mx, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nv) {
+            v[i].x = fast_exp2(v[i].x - mx); v[i].y = fast_exp2(v[i].y - mx);
+            v[i].z = fast_exp2(v[i].z - mx); v[i].w = fast_exp2(v[i].w - mx);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    uint2* pp = (uint2*)(P + (int64_t)blockIdx.x * ld_p);
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nv) pp[c] = make_uint2(pack2bf(v[i].x * inv, v[i].y * inv), pack2bf(v[i].z * inv, v[i].w * inv));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // im2col for thin causal convs (Cin = 4 (RGB padded) / 16): one thread per (voxel, tap), 8-byte units
 // ------------------------------------------------------------------------------------------------
 __global__ void im2col_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, svr_conv_geom g, int kpad) {

@@ -57,6 +57,7 @@ SYMBOLS = {
     "svr_ada_combine": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "svr_qknorm_rope": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _f, _vp]),
     "svr_attn_varlen": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f, _vp]),
+    "svr_softmax_rows": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _i64, _f, _vp]),
     "svr_rows_mean": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "svr_patchify": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "svr_unpatchify_euler": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

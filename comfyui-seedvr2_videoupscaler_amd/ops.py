@@ -191,6 +191,14 @@ class HipOps:
                                                scale, self._stream()), "svr_attn_varlen")
         return out
 
+    def softmax_rows(self, S, P, scale):
+        """P[r] = softmax(scale * S[r]); S fp32 [rows, cols], P bf16 [rows, cols]."""
+        self._chk(S, torch.float32, "S"); self._chk(P, BF16, "P")
+        rows, cols = S.shape
+        hip_lib.check(self.lib.svr_softmax_rows(_ptr(S), _ptr(P), rows, cols, S.stride(0), P.stride(0), scale,
+                                                self._stream()), "svr_softmax_rows")
+        return P
+
     def rows_mean(self, src, dst, n_groups, rows_per_group):
         self._chk(src, BF16, "src"); self._chk(dst, BF16, "dst")
         hip_lib.check(self.lib.svr_rows_mean(_ptr(src), _ptr(dst), n_groups, rows_per_group, src.shape[-1],

@@ -145,6 +145,7 @@ class VideoVAEEngine:
             return (resnet(name + ".resnets.0"), attn(name + ".attentions.0"), resnet(name + ".resnets.1"))
 
         # ---- encoder (Encoder3D, attn_video_vae.py:671-856)
+        self.attn_as_gemm = True            # mid-block attention as QK^T GEMM -> softmax -> PV GEMM (see _attention)
         self.enc_conv_in = conv("encoder.conv_in", cin_pad=4)
         self.enc_down = []
         for i in range(n):
@@ -237,20 +238,41 @@ class VideoVAEEngine:
         return self._conv(rb.conv2, h, st, first, resid=sc, gn=True)
 
     def _attention(self, ab: _Attn, x):
+        """Per-frame spatial self-attention of the mid block (1 head x C=512 over n = H*W tokens).
+        n <= 16384 (every tiled call): Q K^T as an MFMA GEMM with fp32 scores, row softmax, P V as a second GEMM --
+        1 KiB of K/V fragments per MFMA makes the fused single-pass kernel LDS-bound at head_dim 512, two plain
+        GEMMs around a materialised score matrix (1 GiB fp32 per frame, 288 GB of HBM) are ~2x faster.
+        Larger n (untiled 4K frames) uses the fused variable-length kernel."""
         ops = self.ops
         T, H, W, Cc = x.shape
         n = H * W
         y = self._gn(ab.norm, x, False)
-        qkv = ops.empty(T * n, 3 * Cc)
-        ops.gemm(y.reshape(T * n, Cc), ab.qkv_w, qkv, N=3 * Cc, K=Cc, bias=ab.qkv_b)
-        key = (T, n)
-        if key not in self._iota:
-            self._iota[key] = (torch.arange(T * n, dtype=torch.int32, device=self.device),
-                               (torch.arange(T + 1, dtype=torch.int32, device=self.device) * n).contiguous())
-        rows, cu = self._iota[key]
-        att = ops.empty(T * n, Cc)
-        ops.attn_varlen(qkv, att, rows, rows, cu, n, 1, Cc, 1.0 / math.sqrt(Cc))
         out = ops.empty(T, H, W, Cc)
+        if self.attn_as_gemm and n <= 16384 and n % 64 == 0:
+            npad = (n + 255) // 256 * 256
+            q, v = ops.empty(T * n, Cc), ops.empty(T * n, Cc)
+            k = ops.empty(T * n + npad, Cc)                               # slack: the GEMM reads whole 256-row W panels
+            y2 = y.reshape(T * n, Cc)
+            for dst, j in ((q, 0), (k, 1), (v, 2)):                       # (qkv_w rows are q | k | v blocks of C)
+                ops.gemm(y2, ab.qkv_w[j * Cc:(j + 1) * Cc], dst[:T * n], N=Cc, K=Cc, bias=ab.qkv_b[j * Cc:(j + 1) * Cc].contiguous())
+            S = ops.empty(n, n, dtype=torch.float32)
+            P = ops.empty(n, n)
+            att = ops.empty(T * n, Cc)
+            for t in range(T):
+                ops.gemm(q[t * n:(t + 1) * n], k[t * n:t * n + npad], S, N=n, K=Cc, out_f32=True)
+                ops.softmax_rows(S, P, 1.0 / math.sqrt(Cc))
+                vt = v[t * n:(t + 1) * n].t().contiguous()               # layout only: V^T [C, n] is the K-contiguous W operand
+                ops.gemm(P, vt, att[t * n:(t + 1) * n], N=Cc, K=n)
+        else:
+            qkv = ops.empty(T * n, 3 * Cc)
+            ops.gemm(y.reshape(T * n, Cc), ab.qkv_w, qkv, N=3 * Cc, K=Cc, bias=ab.qkv_b)
+            key = (T, n)
+            if key not in self._iota:
+                self._iota[key] = (torch.arange(T * n, dtype=torch.int32, device=self.device),
+                                   (torch.arange(T + 1, dtype=torch.int32, device=self.device) * n).contiguous())
+            rows, cu = self._iota[key]
+            att = ops.empty(T * n, Cc)
+            ops.attn_varlen(qkv, att, rows, rows, cu, n, 1, Cc, 1.0 / math.sqrt(Cc))
         ops.gemm(att, ab.out_w, out, N=Cc, K=Cc, M=T * n, bias=ab.out_b, epilogue=EPI_RESID_GATE,
                  resid=x, ldc=Cc, ldr=Cc)
         return out

@@ -144,6 +144,11 @@ int svr_groupnorm_reduce(const void* partial, double* stats, int32_t T, int32_t 
 int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float* gamma, const float* beta,
                         int32_t T, int64_t HW, int32_t C, int32_t groups, float eps, int32_t apply_silu,
                         void* stream);
+/* P[r, :] = softmax(scale * S[r, :]): fp32 scores [rows, cols] (ld_s) -> bf16 probabilities (ld_p); cols <= 16384.
+ * The softmax of the VAE mid-block attention (diffusers Attention, 1 head x 512; attn_video_vae.py:659-665) when it is
+ * run as two MFMA GEMMs around a materialised score matrix.                                            */
+int svr_softmax_rows(const float* S, void* P, int64_t rows, int32_t cols, int64_t ld_s, int64_t ld_p, float scale,
+                     void* stream);
 /* im2col for thin-input causal convs (Cin = 3 / 16): out bf16 [To*Ho*Wo, kpad].                    */
 int svr_im2col_causal(const void* in, void* out, const svr_conv_geom* g, int32_t kpad, void* stream);
 /* acc[T, y0:y0+h, x0:x0+w, C] += tile * wy[h] * wx[w]  (fp32 accumulator; tiled_encode/decode

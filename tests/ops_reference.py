@@ -122,6 +122,10 @@ class TorchOps:
         qkv.copy_(v.reshape(rows, -1).to(qkv.dtype))
         return qkv
 
+    def softmax_rows(self, S, P, scale):
+        P.copy_(torch.softmax(S.float() * scale, dim=-1).to(P.dtype))
+        return P
+
     def attn_varlen(self, qkv, out, seq_rows, out_rows, cu, max_len, heads, head_dim, scale):
         q3 = qkv.float().reshape(qkv.shape[0], 3, heads, head_dim)
         cu_l = cu.tolist()

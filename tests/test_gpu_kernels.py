@@ -431,3 +431,44 @@ def test_blend_and_affine(hip, ref):
     o = torch.empty(50, 16, device="cuda", dtype=BF16)
     hip.affine_slice(inp, o, 1 / 0.9152, -0.05)
     assert rel_err(o.float(), ref.affine_slice(inp, torch.empty(50, 16, device="cuda"), 1 / 0.9152, -0.05)) < TOL_BF16
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 64), (100, 4416), (33, 16384), (7, 260)])
+def test_softmax_rows(hip, rows, cols):
+    g = torch.Generator(device="cuda").manual_seed(rows + cols)
+    S = torch.randn(rows, cols, device="cuda", generator=g) * 30.0
+    P = hip.empty(rows, cols)
+    hip.softmax_rows(S, P, 0.044)
+    want = torch.softmax(S * 0.044, dim=-1)
+    assert torch.isfinite(P.float()).all()
+    assert (P.float() - want).abs().max() <= 2 ** -8 * want.max() + 1e-6         # bf16 rounding of the output
+    assert (P.float().sum(-1) - 1).abs().max() < 2e-2
+
+
+def test_vae_attention_gemm_path_matches_fused_kernel(hip):
+    """Mid-block attention run as QK^T GEMM -> softmax -> PV GEMM vs the fused variable-length kernel and fp32 torch."""
+    from conftest import sub
+    vae_mod, weights, config = sub("vae"), sub("weights"), sub("config")
+    cfg = config.VAEConfig(block_out_channels=(128, 128, 128, 128))
+    sd = weights.synth_vae_state_dict(cfg, seed=3)
+    eng = vae_mod.VideoVAEEngine(cfg, sd, hip)
+    ab = eng.enc_mid[1]
+    x = (torch.randn(2, 16, 24, 128, device="cuda") * 0.7).bfloat16()
+    got = eng._attention(ab, x).float()
+    eng.attn_as_gemm = False
+    fused = eng._attention(ab, x).float()
+    # fp32 torch restatement of the block (GroupNorm -> q,k,v -> softmax(q k^T / sqrt(C)) v -> out proj + residual)
+    name = "encoder.mid_block.attentions.0"
+    w = {k: sd[f"{name}.{k}"].float().cuda() for k in
+         ("group_norm.weight", "group_norm.bias", "to_q.weight", "to_q.bias", "to_k.weight", "to_k.bias",
+          "to_v.weight", "to_v.bias", "to_out.0.weight", "to_out.0.bias")}
+    xf = x.float()
+    y = torch.nn.functional.group_norm(xf.permute(0, 3, 1, 2), 32, w["group_norm.weight"], w["group_norm.bias"], 1e-6)
+    y = y.permute(0, 2, 3, 1).reshape(2, -1, 128)
+    q, k, v = (y @ w[f"to_{c}.weight"].T + w[f"to_{c}.bias"] for c in "qkv")
+    o = torch.softmax(q @ k.transpose(1, 2) / 128 ** 0.5, -1) @ v
+    want = (o @ w["to_out.0.weight"].T + w["to_out.0.bias"]).reshape(xf.shape) + xf
+    for name_, t in (("gemm", got), ("fused", fused)):
+        err = (t - want).abs()
+        assert err.max() < 0.08 and err.mean() < 6e-3, (name_, float(err.max()), float(err.mean()))
+    assert (got - fused).abs().max() < 0.08
