@@ -37,6 +37,7 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "gemm_impl")) { g_gemm_impl = value; return 0; }
     if (!strcmp(key, "pipe_abl")) { g_pipe_abl = value; return 0; }
     if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
+    if (!strcmp(key, "conv_lds")) { g_conv_lds_dbg = value; return 0; }
     return fail("svr_set_option: unknown key");
 }
 
@@ -115,6 +116,15 @@ int svr_attn_varlen(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, 
                                  scale, (hipStream_t)stream, &why);
     if (why) return fail(why);
     return check(rc, "svr_attn_varlen");
+}
+
+int svr_conv_pack_frag(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t Cin, void* stream) {
+    if (N <= 0 || N % 32 || Cin <= 0 || Cin % 32 || kt < 1 || kt > 3 || K != kt * 9 * Cin)
+        return fail("svr_conv_pack_frag: need N % 32 == 0, Cin % 32 == 0, kt in 1..3, K == kt * 9 * Cin");
+    const int64_t chunks = (int64_t)N * K / 8;
+    hipLaunchKernelGGL(conv_pack_frag_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)W, (uint4*)out, N, K, kt, Cin);
+    return check(hipGetLastError(), "svr_conv_pack_frag");
 }
 
 int svr_softmax_rows(const float* S, void* P, int64_t rows, int32_t cols, int64_t ld_s, int64_t ld_p, float scale,

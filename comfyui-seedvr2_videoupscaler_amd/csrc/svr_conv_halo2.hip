@@ -19,29 +19,54 @@
 // a bijection per image row).
 // Pipeline as in the first kernel: one interval per tap, one raw s_barrier per interval, loads issued
 // CG_D intervals ahead with counted vmcnt, the two waves of a SIMD in opposite order.
+//
+// WREG variant (args.W_frag set): the weights do not pass through LDS at all.  svr_conv_pack_frag() stores them
+// once in MFMA-fragment order -- [32-cout block][interval][k-step][lane][8 bf16], 1 KiB per wave instruction --
+// and every wave streams its own 64 couts x 32 k per interval straight into registers with four coalesced
+// global_load_dwordx4, two intervals ahead (three rotating register sets).  The four waves that share a cout
+// half hit the same lines in L1/L2.  That halves the fragment reads on the LDS port, removes the weight ring,
+// its LDS-DMA issues and the per-interval workgroup barrier: the only synchronisation left is one barrier per
+// A step (9 intervals) for the halo double buffer, so the two waves of a SIMD drift into opposite phases on their
+// own (group 0 runs its MFMA burst at a higher priority to break the tie after each barrier).
 #include "svr_common.h"
 #include "../../include/seedvr2_hip.h"
 #include <type_traits>
 
 namespace svr {
 
-constexpr int CG_TY = 16, CG_TX = 32;
-constexpr int CG_HX = CG_TX + 2, CG_HY = CG_TY + 2;
-constexpr int CG_ROWS = CG_HX * CG_HY;                    // 612 halo pixels
-constexpr int CG_ABUF = CG_ROWS * 64;                     // 39 168 B: 32 channels per pixel
-constexpr int CG_ACHUNKS = CG_ROWS * 4;                   // 2448 16-byte chunks
-constexpr int CG_PIECES = (CG_ACHUNKS + 511) / 512;       // 5 (the last one partial)
+constexpr int CG_TX = 32, CG_HX = CG_TX + 2;
 constexpr int CG_BUNIT = 128 * 64;                        // 128 couts x 32 k = 8 KiB
 constexpr int CG_NB = 8;                                  // weight ring
-constexpr int CG_BOFF = 2 * CG_ABUF;                      // 78 336
-constexpr int CG_LDS = CG_BOFF + CG_NB * CG_BUNIT;        // 143 872 B (the epilogue reuses the first 135 168)
 constexpr int CG_D = 4;                                   // weight prefetch distance (intervals)
 static_assert(CG_D < CG_NB, "ring slot of unit k + D must not hold a unit still being read");
-static_assert(CG_PIECES <= 7, "the next halo must have landed before interval 8");
+
+// Patch geometry: TY rows x 32 columns, TY * 32 threads (one wave per 4 rows x 64 couts).
+//   TY = 16, weights through the LDS ring   : 512 threads, 140.5 KiB LDS, one workgroup per CU
+//   TY =  8, weights in registers (WREG)    : 256 threads, 66 KiB LDS, 228 VGPRs -> TWO independent workgroups per CU:
+//            the prologue / epilogue of one overlaps the K loop of the other (what limited 128-channel layers)
+template <int TY, bool WREG> struct cg_geom {
+    static constexpr int NT = TY * 32;                    // threads
+    static constexpr int HY = TY + 2;
+    static constexpr int ROWS = CG_HX * HY;               // halo pixels (612 / 340)
+    static constexpr int ABUF = ROWS * 64;                // 32 channels per pixel
+    static constexpr int ACHUNKS = ROWS * 4;              // 16-byte chunks
+    static constexpr int PIECES = (ACHUNKS + NT - 1) / NT;
+    static constexpr int BOFF = 2 * ABUF;
+    static constexpr int EP_ROWS = WREG ? 4 : 8;          // patch rows per epilogue pass
+    static constexpr int EP_BYTES = EP_ROWS * 32 * 528;
+    static constexpr int MAIN = WREG ? BOFF : BOFF + CG_NB * CG_BUNIT;
+    static constexpr int LDS = MAIN > EP_BYTES ? MAIN : EP_BYTES;
+    static_assert(PIECES <= 7, "the next halo must have landed before interval 8");
+};
 
 template <int N> SVR_DEVICE void cg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) {
+// DBG (builds with -DSVR_ABLATIONS only; results invalid): 1 no weight loads, 2 no halo LDS-DMA, 4 no global stores
+template <int TY, bool WREG, int DBG = 0>
+__global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_args a) {
+    typedef cg_geom<TY, WREG> G;
+    constexpr int CG_TY = TY, CG_ROWS = G::ROWS, CG_ABUF = G::ABUF, CG_ACHUNKS = G::ACHUNKS, CG_PIECES = G::PIECES,
+                  CG_BOFF = G::BOFF, NT = G::NT;
     constexpr int MTW = 4, NTW = 2;                       // 32-voxel rows / 32-cout blocks per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -50,7 +75,7 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;                            // the two waves of a SIMD are in different groups
+    const int grp = wave >> 2;                            // (TY = 16) the two waves of a SIMD are in different groups
     const int wm = wave >> 1, wn = wave & 1;              // rows 4 wm .. 4 wm + 3, couts 64 wn .. 64 wn + 63
 
     // ---- tile id -> (frame, patch row, patch column, cout tile); XCD-contiguous bands
@@ -82,7 +107,7 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) 
     uint32_t akeys = 0;                                   // halo piece -> swizzled source chunk (2 bits each)
 #pragma unroll
     for (int q = 0; q < CG_PIECES; ++q) {
-        const int row = q * 128 + srow;
+        const int row = q * (NT / 4) + srow;
         const int hy = row / CG_HX, hx = row - hy * CG_HX;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         const bool ok = row < CG_ROWS && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
@@ -105,11 +130,12 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) 
     };
     auto stage_a_piece = [&](auto qc, const char* fptr, int buf) {
         constexpr int Q = decltype(qc)::value;
-        if (Q * 512 + wave * 64 >= CG_ACHUNKS) return false;         // wave-uniform: nothing of this piece
+        if (Q * NT + wave * 64 >= CG_ACHUNKS) return false;          // wave-uniform: nothing of this piece
         const int ck = (akeys >> (2 * Q)) & 3;
         const char* src = poff[Q] == 0xffffffffu ? (const char*)g.zeros
                                                  : fptr + ((int64_t)poff[Q] * g.Cin + ck * 8) * 2;
-        if (Q * 512 + tid < CG_ACHUNKS) glds16(src, wave_dst + buf * CG_ABUF + Q * 8192);
+        if constexpr (!(DBG & 2))
+            if (Q * NT + tid < CG_ACHUNKS) glds16(src, wave_dst + buf * CG_ABUF + Q * (NT * 16));
         return true;
     };
     // weight unit (A step s, tap) -> ring slot: one chunk per thread
@@ -183,6 +209,123 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) 
         else mfma_core(ar2, ar3, ar4, ar5);
     };
 
+    if constexpr (WREG) {
+        // ---- weights straight from global memory in fragment order
+        const int64_t nstride = (int64_t)P * 2048;                                          // bytes per 32-cout block
+        const char* wp0 = (const char*)a.W_frag + (int64_t)(n0 / 32 + wn * 2) * nstride;   // wave-uniform (SGPR pair)
+        const char* wp1 = wp0 + nstride;
+        const int voff = lane * 16;
+        bf16x8 w0[NTW][2], w1[NTW][2], w2[NTW][2];          // weights of intervals k = 0, 1, 2 (mod 3)
+        // issued as inline asm: hipcc's own waitcnt insertion falls back to vmcnt(0) around the conditional LDS-DMA
+        // issues, which would expose the full load latency; the waits below are counted by hand instead
+        // (vmcnt retires in issue order)
+        auto wload = [&](bf16x8 (&w)[NTW][2], int k) {
+            const char* p0 = wp0 + (int64_t)min(k, P - 1) * 2048;     // (the last two intervals re-load the final unit)
+            const char* p1 = wp1 + (int64_t)min(k, P - 1) * 2048;
+            if constexpr (DBG & 1) {
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                w[0][0] = z; w[0][1] = z; w[1][0] = z; w[1][1] = z;
+                return;
+            }
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[0][0]) : "v"(voff), "s"(p0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(w[0][1]) : "v"(voff), "s"(p0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[1][0]) : "v"(voff), "s"(p1) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(w[1][1]) : "v"(voff), "s"(p1) : "memory");
+        };
+        auto reads_a = [&](auto jc, int s) {
+            constexpr int J = decltype(jc)::value;
+            constexpr int DY = J % 3, DX = J / 3;
+            int ra = rd_a0[DX] + (s & 1) * CG_ABUF;
+            asm volatile("" : "+v"(ra));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const char* pa = smem + (ra ^ (ks << 5));
+                if constexpr (DY == 0) {
+                    ar0[ks] = *(const bf16x8*)(pa + (0 * CG_HX + DX) * 64);
+                    ar1[ks] = *(const bf16x8*)(pa + (1 * CG_HX + DX) * 64);
+                    ar2[ks] = *(const bf16x8*)(pa + (2 * CG_HX + DX) * 64);
+                    ar3[ks] = *(const bf16x8*)(pa + (3 * CG_HX + DX) * 64);
+                } else if constexpr (DY == 1) {
+                    ar4[ks] = *(const bf16x8*)(pa + (4 * CG_HX + DX) * 64);
+                } else {
+                    ar5[ks] = *(const bf16x8*)(pa + (5 * CG_HX + DX) * 64);
+                }
+            }
+        };
+        auto mfma_w = [&](const bf16x8 (&w)[NTW][2], const bf16x8 (&r0)[2], const bf16x8 (&r1)[2],
+                          const bf16x8 (&r2)[2], const bf16x8 (&r3)[2]) {
+#define SVR_MM(KS, R, MT, NT) \
+            acc[MT][NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[NT][KS], R[KS], acc[MT][NT], 0, 0, 0)
+            SVR_MM(0, r0, 0, 0); SVR_MM(0, r0, 0, 1); SVR_MM(0, r1, 1, 0); SVR_MM(0, r1, 1, 1);
+            SVR_MM(0, r2, 2, 0); SVR_MM(0, r2, 2, 1); SVR_MM(0, r3, 3, 0); SVR_MM(0, r3, 3, 1);
+            SVR_MM(1, r0, 0, 0); SVR_MM(1, r0, 0, 1); SVR_MM(1, r1, 1, 0); SVR_MM(1, r1, 1, 1);
+            SVR_MM(1, r2, 2, 0); SVR_MM(1, r2, 2, 1); SVR_MM(1, r3, 3, 0); SVR_MM(1, r3, 3, 1);
+#undef SVR_MM
+        };
+        bool a_prev3 = false;
+        auto interval3 = [&](auto jc, int s, const char* fnext, const bf16x8 (&wc)[NTW][2], bf16x8 (&wn_)[NTW][2]) {
+            constexpr int J = decltype(jc)::value;
+            constexpr int DY = J % 3;
+            const int k = s * 9 + J;
+            bool a_issued = false;
+            if constexpr (J < CG_PIECES) {
+                if (s + 1 < nA) a_issued = stage_a_piece(std::integral_constant<int, (J < CG_PIECES ? J : 0)>{}, fnext, (s + 1) & 1);
+            }
+            wload(wn_, k + 2);
+            reads_a(jc, s);
+            // weights of this interval were issued two intervals ago; younger: 2 x 4 weight loads + the halo pieces of
+            // this and the previous interval
+            {
+                const int n = 8 + (a_issued ? 1 : 0) + (a_prev3 ? 1 : 0);
+                if (n == 10) cg_wait_vmcnt<10>(); else if (n == 9) cg_wait_vmcnt<9>(); else cg_wait_vmcnt<8>();
+            }
+            a_prev3 = a_issued;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+            if constexpr (DY == 0) mfma_w(wc, ar0, ar1, ar2, ar3);
+            else if constexpr (DY == 1) mfma_w(wc, ar1, ar2, ar3, ar4);
+            else mfma_w(wc, ar2, ar3, ar4, ar5);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (J == 8) {
+                // the halo of step s+1 (issued in intervals 0..4, before the last 8 weight loads) must have landed for
+                // every wave, and every wave must be done reading this step's buffer before it is refilled
+                // (last step: drain the hand-issued weight loads -- hipcc does not know they are in flight and would
+                // reuse their destination registers in the epilogue while the data is still on its way)
+                if (s + 1 < nA) cg_wait_vmcnt<8>(); else cg_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        {
+            const char* f0 = frame_ptr(0);
+            stage_a_piece(std::integral_constant<int, 0>{}, f0, 0);
+            stage_a_piece(std::integral_constant<int, 1>{}, f0, 0);
+            stage_a_piece(std::integral_constant<int, 2>{}, f0, 0);
+            stage_a_piece(std::integral_constant<int, 3>{}, f0, 0);
+            stage_a_piece(std::integral_constant<int, 4>{}, f0, 0);
+            if constexpr (CG_PIECES > 5) stage_a_piece(std::integral_constant<int, (CG_PIECES > 5 ? 5 : 0)>{}, f0, 0);
+            static_assert(CG_PIECES <= 6, "prologue stages at most six pieces");
+            wload(w0, 0);
+            wload(w1, 1);
+            cg_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int s = 0; s < nA; ++s) {
+            const char* fnext = frame_ptr(min(s + 1, nA - 1));
+            interval3(std::integral_constant<int, 0>{}, s, fnext, w0, w2);
+            interval3(std::integral_constant<int, 1>{}, s, fnext, w1, w0);
+            interval3(std::integral_constant<int, 2>{}, s, fnext, w2, w1);
+            interval3(std::integral_constant<int, 3>{}, s, fnext, w0, w2);
+            interval3(std::integral_constant<int, 4>{}, s, fnext, w1, w0);
+            interval3(std::integral_constant<int, 5>{}, s, fnext, w2, w1);
+            interval3(std::integral_constant<int, 6>{}, s, fnext, w0, w2);
+            interval3(std::integral_constant<int, 7>{}, s, fnext, w1, w0);
+            interval3(std::integral_constant<int, 8>{}, s, fnext, w2, w1);
+        }
+    } else {
     // ---- prologue: halo of step 0, weight units 0 .. CG_D-1
     {
         const char* f0 = frame_ptr(0);
@@ -256,8 +399,10 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) 
         interval(std::integral_constant<int, 8>{}, s, fnext);
     }
 
-    // ---- epilogue through LDS, two passes of 256 voxels (patch rows 0-7: waves with wm < 2, rows 8-15: wm >= 2):
-    // the fp32 tile (+ bias) is parked in LDS [256 voxels][132 floats] and written back row-contiguous
+    }
+
+    // ---- epilogue through LDS, two passes of EP_ROWS patch rows (TY = 16: rows 0-7 are the waves with wm < 2, rows 8-15
+    // wm >= 2; TY = 8: one wave row per pass): the fp32 tile (+ bias) is parked in LDS [voxels][132 floats] and written back row-contiguous
     // (16 lanes cover one voxel's 128 couts; every global access is a full 16-byte lane / 256-byte row).
     constexpr int EP_PITCH = 528;                         // 128 floats + 16 B pad: conflict-free b128 writes
     const int hi4 = hi * 4;
@@ -273,12 +418,14 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) 
     // fused GroupNorm statistics of the stored (bf16-rounded) output: this thread always stores the same
     // 8-cout chunk (tid & 15), so it keeps two quad sums over its 16 voxels
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+    constexpr int EP_ROWS = G::EP_ROWS, EP_WM = EP_ROWS / MTW;      // patch rows / wave rows per pass
+    static_assert(TY / EP_ROWS == 2 && EP_ROWS * 32 * 16 == 8 * NT, "two passes, eight store iterations each");
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        if ((wm >> 1) == pass) {
+        if (wm / EP_WM == pass) {
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
-                char* row = smem + (((wm & 1) * MTW + mt) * 32 + l31) * EP_PITCH;
+                char* row = smem + (((wm % EP_WM) * MTW + mt) * 32 + l31) * EP_PITCH;
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     const f32x16_t v = acc[mt][nt];
@@ -295,10 +442,11 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) 
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int id = it * 512 + tid;
+            const int id = it * NT + tid;
             const int vox = id >> 4, ch = id & 15;        // voxel of the half patch, 8-cout chunk
-            const int y = y0 + pass * 8 + (vox >> 5), x = x0 + (vox & 31);
+            const int y = y0 + pass * EP_ROWS + (vox >> 5), x = x0 + (vox & 31);
             if (y >= g.H || x >= g.W) continue;
+            if constexpr ((DBG & 4) != 0) continue;
             const int64_t m = ((int64_t)to * g.H + y) * g.W + x;
             const int n = n0 + ch * 8;
             const f32x4 lo = *(const f32x4*)(smem + vox * EP_PITCH + ch * 32);
@@ -338,14 +486,14 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) 
     }
     if (a.gn_partial) {                                   // fixed-order reduction: thread -> quad -> group
         __syncthreads();
-        float4* red = (float4*)smem;                      // [512]
+        float4* red = (float4*)smem;                      // [NT]
         double2* qsum = (double2*)(smem + 8192);          // [32 quads]
         red[tid] = make_float4(gs0, gq0, gs1, gq1);
         __syncthreads();
         if (tid < 32) {                                   // quad = 2 * chunk + half; rows tid' with tid' & 15 == chunk
             const int c = tid >> 1, h = tid & 1;
             double s = 0.0, q = 0.0;
-            for (int j = 0; j < 32; ++j) {
+            for (int j = 0; j < NT / 16; ++j) {
                 const float4 v = red[(j << 4) | c];
                 s += (double)(h ? v.z : v.x);
                 q += (double)(h ? v.w : v.y);
@@ -363,29 +511,65 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(const svr_gemm_args a) 
     }
 }
 
-static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
+int g_conv_lds_dbg = 0;    // measurement knob: dynamic LDS bytes to request (forces one workgroup per CU when > 80 KiB)
+static bool conv_halo2_wreg(const svr_gemm_args& a) { return a.W_frag != nullptr && g_conv_impl == 0; }
+
+template <int TY, bool WREG, int DBG = 0> static int launch_conv_halo2_t(const svr_gemm_args& a, hipStream_t s) {
+    typedef cg_geom<TY, WREG> G;
     const svr_conv_geom& g = a.conv;
-    const int tiles = g.To * ((g.H + CG_TY - 1) / CG_TY) * ((g.W + CG_TX - 1) / CG_TX) * (a.N / 128);
+    const int tiles = g.To * ((g.H + TY - 1) / TY) * ((g.W + CG_TX - 1) / CG_TX) * (a.N / 128);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CG_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo2_kernel<TY, WREG, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_halo2_kernel, dim3(tiles), dim3(512), CG_LDS, s, a);
+    hipLaunchKernelGGL((conv_halo2_kernel<TY, WREG, DBG>), dim3(tiles), dim3(G::NT), g_conv_lds_dbg > G::LDS ? g_conv_lds_dbg : G::LDS, s, a);
     return (int)hipGetLastError();
 }
 
+static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
+#ifdef SVR_ABLATIONS
+    if (conv_halo2_wreg(a)) switch (g_pipe_abl) {
+        case 1: return launch_conv_halo2_t<8, true, 1>(a, s);
+        case 2: return launch_conv_halo2_t<8, true, 2>(a, s);
+        case 4: return launch_conv_halo2_t<8, true, 4>(a, s);
+        case 7: return launch_conv_halo2_t<8, true, 7>(a, s);
+        default: break;
+    }
+#endif
+    return conv_halo2_wreg(a) ? launch_conv_halo2_t<8, true>(a, s) : launch_conv_halo2_t<16, false>(a, s);
+}
+
 static int conv_gn_blocks(const svr_gemm_args& a) {
-    if (g_conv_impl != 0 || !conv_halo_eligible(a) || (a.N % 128) != 0 || a.conv.Cin % 32 != 0 || a.out_f32) return 0;
+    if ((g_conv_impl != 0 && g_conv_impl != 3) || !conv_halo_eligible(a) || (a.N % 128) != 0 || a.conv.Cin % 32 != 0 || a.out_f32) return 0;
     const int cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 0;          // channels per group: 4, 8 or 16
     if (cpg < 4 || (cpg & 3) || a.N % a.gn_groups || 128 % cpg) return 0;
-    return ((a.conv.H + CG_TY - 1) / CG_TY) * ((a.conv.W + CG_TX - 1) / CG_TX);
+    const int ty = conv_halo2_wreg(a) ? 8 : 16;
+    return ((a.conv.H + ty - 1) / ty) * ((a.conv.W + CG_TX - 1) / CG_TX);
 }
 
 // what conv_halo_eligible() accepts with 128-cout tiles and channels in 32-slices
 static bool conv_halo2_eligible(const svr_gemm_args& a) {
     return conv_halo_eligible(a) && (a.N % 128) == 0 && a.conv.Cin % 32 == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight re-pack for the WREG variant: W [N, K = (dt, dy, dx, c)] -> [N / 32][k = (dt * Cin/32 + slice) * 9 + dx * 3 + dy]
+// [k-step 2][lane 64][8 bf16]; lane l of a v_mfma_f32_32x32x16_bf16 operand holds cout (l & 31), k (l >> 5) * 8 .. + 8.
+// One thread per 16-byte chunk; done once per checkpoint.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_pack_frag_kernel(const bf16_t* __restrict__ W, uint4* __restrict__ out, int N, int K,
+                                                             int kt, int Cin) {
+    const int cpk = Cin / 32, P = kt * cpk * 9;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)(N / 32) * P * 128) return;
+    const int lane = (int)(idx & 63), ks = (int)((idx >> 6) & 1);
+    const int kk = (int)((idx >> 7) % P), n32 = (int)((idx >> 7) / P);
+    const int s = kk / 9, J = kk - s * 9;
+    const int dt = s / cpk, cs = s - dt * cpk, dy = J % 3, dx = J / 3;
+    const int n = n32 * 32 + (lane & 31), c = cs * 32 + ks * 16 + (lane >> 5) * 8;
+    out[idx] = *(const uint4*)(W + (int64_t)n * K + ((dt * 9 + dy * 3 + dx) * Cin + c));
 }
 
 }  // namespace svr

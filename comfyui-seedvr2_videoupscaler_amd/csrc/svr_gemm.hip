@@ -293,7 +293,7 @@ template <int BN> static int launch_conv_halo(const svr_gemm_args& a, hipStream_
 static bool conv_halo_eligible(const svr_gemm_args& a);
 static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s);
 static bool conv_halo2_eligible(const svr_gemm_args& a);
-int g_conv_impl = [] { const char* e = getenv("SVR_CONV_IMPL"); return e ? atoi(e) : 0; }();   // 0 auto, 1 generic, 2 first halo kernel
+int g_conv_impl = [] { const char* e = getenv("SVR_CONV_IMPL"); return e ? atoi(e) : 0; }();   // 0 auto, 1 generic, 2 first halo kernel, 3 second halo kernel without W_frag
 
 // Kernel selection (svr_set_option("gemm_impl", v); env SVR_GEMM_IMPL seeds it): 0 = auto (the
 // measured-best kernel per problem class), 1 = one-barrier-per-K-tile kernel everywhere,
@@ -326,7 +326,7 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
         *why = "svr_gemm_bf16: bad pixel-shuffle geometry"; return -1;
     }
     if (a.gn_partial && conv_gn_blocks(a) == 0) { *why = "svr_gemm_bf16: gn_partial set but this launch cannot produce fused GroupNorm statistics"; return -1; }
-    if (g_conv_impl == 0 && conv_halo2_eligible(a)) return launch_conv_halo2(a, s);
+    if ((g_conv_impl == 0 || g_conv_impl == 3) && conv_halo2_eligible(a)) return launch_conv_halo2(a, s);
     if (g_conv_impl != 1 && conv_halo_eligible(a))
         return a.N <= 32 ? launch_conv_halo<32>(a, s) : launch_conv_halo<128>(a, s);
     if (pipe_eligible(a) && use_pipe_kernel(a))

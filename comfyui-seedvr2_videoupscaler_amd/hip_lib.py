@@ -44,13 +44,15 @@ class GemmArgs(C.Structure):
                 ("resid", C.c_void_p), ("ldr", C.c_int64),
                 ("epilogue", C.c_int32), ("out_f32", C.c_int32),
                 ("conv", ConvGeom), ("ps", PixelShuffle),
-                ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32)]
+                ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
+                ("W_frag", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/seedvr2_hip.h
 _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
     "svr_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "svr_conv_pack_frag": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "svr_gemm_gn_blocks": (C.c_int32, [C.POINTER(GemmArgs)]),
     "svr_groupnorm_reduce": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "svr_rmsnorm_mod": (C.c_int, [_vp, _vp, _i64, _i32, _f, _vp, _vp, _vp, _vp]),
@@ -128,7 +130,7 @@ def lib():
         except AttributeError as e:
             raise HipLibraryError(f"{LIB_PATH} does not export {name} (stale build?)") from e
         fn.restype, fn.argtypes = res, args
-    if handle.svr_abi_version() != 2:
+    if handle.svr_abi_version() != 3:
         raise HipLibraryError("libseedvr2_hip.so ABI version mismatch; rebuild")
     _lib = handle
     return _lib

@@ -84,9 +84,20 @@ class HipOps:
         return torch.empty(*shape, dtype=dtype or BF16, device=self.device)
 
     # ------------------------------------------------------------------ GEMM / conv
+    def pack_conv_frag(self, W, kt: int, Cin: int, N: int):
+        """Fragment-ordered copy of packed conv weights W [Npad, kt*9*Cin] for gemm(..., W_frag=) (3x3 spatial taps,
+        stride 1, Cin % 32 == 0, N % 128 == 0); None when the geometry is not served by that kernel."""
+        if Cin % 64 or N % 128 or W.shape[1] != kt * 9 * Cin:
+            return None
+        self._chk(W, BF16, "W")
+        out = torch.empty(N * W.shape[1], dtype=BF16, device=self.device)
+        hip_lib.check(self.lib.svr_conv_pack_frag(_ptr(W), _ptr(out), N, W.shape[1], kt, Cin, self._stream()),
+                      "svr_conv_pack_frag")
+        return out
+
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
              out_f32=False, conv: Optional[Conv3dGeom] = None, ps: Optional[PixelShuffleGeom] = None,
-             lda=None, ldc=None, ldr=None, gn_groups: int = 0):
+             lda=None, ldc=None, ldr=None, gn_groups: int = 0, W_frag=None):
         """out[M, N] = A[M, K] @ W[:N, :K]^T with fused epilogue.  W is [Npad, K] bf16 (Npad % 128 == 0).
         With ``gn_groups`` > 0 (conv mode) returns ``(out, stats)``: per-frame GroupNorm (sum, sumsq) of the stored
         output [To, groups, 2] fp64 fused into the conv epilogue, or ``None`` when the kernel serving this
@@ -136,6 +147,8 @@ class HipOps:
             a.resid = resid.data_ptr()
             a.ldr = ldr if ldr is not None else (resid.stride(0) if resid.dim() == 2 else N)
         a.epilogue, a.out_f32 = epilogue, int(out_f32)
+        if W_frag is not None and conv is not None:
+            a.W_frag = self._chk(W_frag, BF16, "W_frag").data_ptr()
         stats = None
         if gn_groups > 0 and conv is not None:
             a.gn_groups = gn_groups

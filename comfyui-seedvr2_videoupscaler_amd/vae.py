@@ -41,6 +41,7 @@ class _Conv:
     pad_lo: int = 1     # spatial zero pad, low side
     pad_hi: int = 1     # spatial zero pad, high side
     thin: bool = False  # Cin < 64: im2col + plain GEMM
+    w_frag: Optional[torch.Tensor] = None   # MFMA-fragment-ordered copy of w for the LDS-halo conv kernel (ops.pack_conv_frag)
 
 
 @dataclass
@@ -123,8 +124,13 @@ class VideoVAEEngine:
             thin = ci < 64
             if thin:
                 cin_pad = cin_pad or (ci + 3) // 4 * 4
-            return _Conv(name, pack_conv3d(w, dev, cin_pad), pack_vec(sd[name + ".bias"], dev),
-                         cin_pad or ci, co, (kt, kh, kw), stride, pad[0] if kh > 1 else 0, pad[1] if kh > 1 else 0, thin)
+            wp = pack_conv3d(w, dev, cin_pad)
+            frag = None
+            if (kh, kw) == (3, 3) and tuple(stride) == (1, 1, 1) and tuple(pad) == (1, 1) and not thin \
+                    and hasattr(ops, "pack_conv_frag"):
+                frag = ops.pack_conv_frag(wp, kt, ci, co)
+            return _Conv(name, wp, pack_vec(sd[name + ".bias"], dev),
+                         cin_pad or ci, co, (kt, kh, kw), stride, pad[0] if kh > 1 else 0, pad[1] if kh > 1 else 0, thin, frag)
 
         def norm(name):
             return _Norm(pack_vec(sd[name + ".weight"], dev), pack_vec(sd[name + ".bias"], dev))
@@ -207,10 +213,10 @@ class VideoVAEEngine:
                      lda=K, ldc=cw.cout, ldr=cw.cout)
         elif gn:
             _, stats = ops.gemm(x, cw.w, out, N=cw.cout, K=K, bias=cw.b, epilogue=epi, resid=resid, conv=geom,
-                                ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups)
+                                ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups, W_frag=cw.w_frag)
         else:
             ops.gemm(x, cw.w, out, N=cw.cout, K=K, bias=cw.b, epilogue=epi, resid=resid, conv=geom,
-                     ldc=cw.cout, ldr=cw.cout)
+                     ldc=cw.cout, ldr=cw.cout, W_frag=cw.w_frag)
         if carry > 0:                                       # per-conv memory for the next slice
             if T >= carry:
                 st[cw.name] = x[T - carry:].clone()

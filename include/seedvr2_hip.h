@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SVR_ABI_VERSION 2
+#define SVR_ABI_VERSION 3
 
 /* ---- GEMM / implicit-GEMM convolution epilogues ------------------------------------------ */
 #define SVR_EPI_BIAS        0   /* C = acc + bias                                              */
@@ -74,7 +74,15 @@ typedef struct svr_gemm_args {
      * reduction order, like svr_groupnorm_stats.  NULL / 0: off.                                          */
     void* gn_partial;
     int32_t gn_groups;
+    /* Optional (conv mode, 3x3 spatial taps, stride 1, Cin % 32 == 0, N % 128 == 0): the same weights in
+     * MFMA-fragment order as written by svr_conv_pack_frag().  When set, the LDS-halo conv kernel streams the
+     * weights from this copy straight into registers instead of staging W through LDS.  NULL: off.        */
+    const void* W_frag;
 } svr_gemm_args;
+
+/* W [N, K = kt * 9 * Cin] (conv weight rows, K order (dt, dy, dx, c)) -> out (same byte size, N * K bf16) in the
+ * fragment order svr_gemm_args.W_frag expects.  N % 32 == 0, Cin % 32 == 0.  Done once per checkpoint.     */
+int svr_conv_pack_frag(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t Cin, void* stream);
 
 /* Number of per-frame partial blocks the launch described by `args` will write to args->gn_partial
  * (0: the kernel that serves this problem does not produce fused statistics -- use svr_groupnorm_stats). */
@@ -165,8 +173,10 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
 
 /* ---- misc ------------------------------------------------------------------------------------ */
 /* Tuning / measurement knobs (no effect on results): "gemm_impl" 0 auto | 1 simple | 2 pipelined,
- * "conv_impl" 0 auto (LDS-halo kernel for stride-1 3x3 convs) | 1 generic implicit GEMM everywhere,
- * "pipe_abl" measurement-only ablations of the pipelined kernel (non-zero values give garbage). */
+ * "conv_impl" 0 auto (LDS-halo kernels for stride-1 3x3 convs; register-streamed weights when W_frag is given)
+ * | 1 generic implicit GEMM everywhere | 2 first (8x32-patch) halo kernel | 3 second halo kernel ignoring W_frag,
+ * "conv_lds" dynamic LDS bytes to request for the halo kernel (> 80 KiB forces one workgroup per CU),
+ * "pipe_abl" measurement-only ablations in -DSVR_ABLATIONS builds (non-zero values give garbage). */
 int svr_set_option(const char* key, int32_t value);
 const char* svr_last_error(void);
 int svr_abi_version(void);

@@ -29,7 +29,7 @@ class TorchOps:
 
     # ------------------------------------------------------------------ GEMM / conv
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
-             out_f32=False, conv=None, ps=None, lda=None, ldc=None, ldr=None, gn_groups=0):
+             out_f32=False, conv=None, ps=None, lda=None, ldc=None, ldr=None, gn_groups=0, W_frag=None):
         """``gn_groups`` > 0: return ``(out, None)`` like a HIP launch whose kernel cannot fuse the statistics."""
         if gn_groups > 0:
             return self.gemm(A, W, out, N=N, K=K, M=M, bias=bias, epilogue=epilogue, gate=gate, resid=resid,

@@ -154,19 +154,20 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("conv_impl", [0, 2], ids=["halo16x32", "halo8x32"])
+@pytest.mark.parametrize("conv_impl", [0, 2, -1], ids=["halo16x32", "halo8x32", "halo16x32_wreg"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3d_implicit_gemm(hip, ref, case, conv_impl):
     """conv_impl 0: the library's choice (16x32-voxel LDS-halo kernel where eligible), 2: the first (8x32) halo
-    kernel; geometries neither accepts run on the generic implicit-GEMM kernel in both."""
-    hip.set_option("conv_impl", conv_impl)
+    kernel; geometries neither accepts run on the generic implicit-GEMM kernel in both.  "wreg": the library's
+    choice with the fragment-ordered weight copy supplied (weights streamed to registers, not through LDS)."""
+    hip.set_option("conv_impl", max(conv_impl, 0))
     try:
-        _conv_case(hip, ref, case)
+        _conv_case(hip, ref, case, frag=conv_impl < 0)
     finally:
         hip.set_option("conv_impl", 0)
 
 
-def _conv_case(hip, ref, case):
+def _conv_case(hip, ref, case, frag=False):
     packing, opsmod = sub("packing"), sub("ops")
     Cin, Cout, k, stride, (plo, phi), T, H, W, hf = case
     kt, kh, kw = k
@@ -182,8 +183,9 @@ def _conv_case(hip, ref, case):
     geom = opsmod.Conv3dGeom(T, H, W, Cin, To, Ho, Wo, k, stride, (pt, plo, plo), halo)
     resid = rnd(To, Ho, Wo, Cout, seed=11)
     out = torch.empty(To, Ho, Wo, Cout, device="cuda", dtype=BF16)
+    Wf = hip.pack_conv_frag(Wp, kt, Cin, Cout) if frag and (kh, kw) == (3, 3) else None
     hip.gemm(x, Wp, out, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, epilogue=EPI_RESID_GATE, resid=resid,
-             ldc=Cout, ldr=Cout)
+             ldc=Cout, ldr=Cout, W_frag=Wf)
     want = ref.gemm(x, Wp, torch.empty(To, Ho, Wo, Cout, device="cuda"), N=Cout, K=Wp.shape[1], bias=bias,
                     conv=geom, epilogue=EPI_RESID_GATE, resid=resid)
     # independent check of the reference double itself against F.conv3d semantics of the causal conv
@@ -213,6 +215,12 @@ def test_conv3d_halo_kernel_race_screen_and_generic_agreement(hip):
         outs.append(out)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # weights streamed to registers from the fragment-ordered copy: same MFMAs in the same order -> same bits
+    Wf = hip.pack_conv_frag(Wp, 3, Cin, Cout)
+    for _ in range(3):
+        out = torch.empty(T, H, W, Cout, device="cuda", dtype=torch.float32)
+        hip.gemm(x, Wp, out, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, out_f32=True, W_frag=Wf)
+        assert torch.equal(out, outs[0])
     hip.set_option("conv_impl", 1)
     try:
         gen = torch.empty(T, H, W, Cout, device="cuda", dtype=torch.float32)

@@ -37,6 +37,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="conv,gemm,attn,side")
+    ap.add_argument("--match", default="", help="conv: only shapes whose name contains this substring")
+    ap.add_argument("--no-frag", action="store_true", help="conv: do not supply the fragment-ordered weight copy")
     args = ap.parse_args()
     only = set(args.only.split(","))
     ops_mod, packing = sub("ops"), sub("packing")
@@ -67,12 +69,15 @@ def main():
                                       ("conv3x3x3 128->128 @1024x992", 5, 1024, 992, 128, 128),
                                       ("conv3x3x3 256->256 @512x544", 9, 512, 544, 256, 256),
                                       ("conv3x3x3 128->3 @1024^2 (decoder conv_out)", 5, 1024, 1024, 128, 3)):
+            if args.match and args.match not in name:
+                continue
             x = rnd(T, H, W, Ci)
             w = packing.pack_conv3d(torch.randn(Co, Ci, 3, 3, 3, generator=g, device=dev) / math.sqrt(27 * Ci), dev)
             b = torch.zeros(Co, dtype=torch.float32, device=dev)
             y = ops.empty(T, H, W, Co)
             geom = ops_mod.Conv3dGeom(T, H, W, Ci, T, H, W, (3, 3, 3), (1, 1, 1), (2, 1, 1), None)
-            sec = timeit(lambda: ops.gemm(x, w, y, N=Co, K=27 * Ci, bias=b, conv=geom, ldc=Co), args.reps)
+            wf = None if args.no_frag else ops.pack_conv_frag(w, 3, Ci, Co)
+            sec = timeit(lambda: ops.gemm(x, w, y, N=Co, K=27 * Ci, bias=b, conv=geom, ldc=Co, W_frag=wf), args.reps)
             report(name, sec, flops=2.0 * T * H * W * Co * 27 * Ci)
             del x, w, y
     if "gemm" in only:
