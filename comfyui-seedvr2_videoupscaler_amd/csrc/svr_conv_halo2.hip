@@ -44,7 +44,7 @@ static_assert(CG_D < CG_NB, "ring slot of unit k + D must not hold a unit still 
 //   TY = 16, weights through the LDS ring   : 512 threads, 140.5 KiB LDS, one workgroup per CU
 //   TY =  8, weights in registers (WREG)    : 256 threads, 66 KiB LDS, 228 VGPRs -> TWO independent workgroups per CU:
 //            the prologue / epilogue of one overlaps the K loop of the other (what limited 128-channel layers)
-template <int TY, bool WREG> struct cg_geom {
+template <int TY, int MODE> struct cg_geom {          // MODE 0 weights through the LDS ring, 1 in registers, 2 thin input
     static constexpr int NT = TY * 32;                    // threads
     static constexpr int HY = TY + 2;
     static constexpr int ROWS = CG_HX * HY;               // halo pixels (612 / 340)
@@ -52,9 +52,10 @@ template <int TY, bool WREG> struct cg_geom {
     static constexpr int ACHUNKS = ROWS * 4;              // 16-byte chunks
     static constexpr int PIECES = (ACHUNKS + NT - 1) / NT;
     static constexpr int BOFF = 2 * ABUF;
-    static constexpr int EP_ROWS = WREG ? 4 : 8;          // patch rows per epilogue pass
+    static constexpr int EP_ROWS = MODE ? 4 : 8;          // patch rows per epilogue pass
     static constexpr int EP_BYTES = EP_ROWS * 32 * 528;
-    static constexpr int MAIN = WREG ? BOFF : BOFF + CG_NB * CG_BUNIT;
+    static constexpr int THIN_PITCH = 272;                // im2col row of the thin-input variant: 128 k + 16 B pad
+    static constexpr int MAIN = MODE == 2 ? TY * 32 * THIN_PITCH : (MODE == 1 ? BOFF : BOFF + CG_NB * CG_BUNIT);
     static constexpr int LDS = MAIN > EP_BYTES ? MAIN : EP_BYTES;
     static_assert(PIECES <= 7, "the next halo must have landed before interval 8");
 };
@@ -62,9 +63,10 @@ template <int TY, bool WREG> struct cg_geom {
 template <int N> SVR_DEVICE void cg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // DBG (builds with -DSVR_ABLATIONS only; results invalid): 1 no weight loads, 2 no halo LDS-DMA, 4 no global stores
-template <int TY, bool WREG, int DBG = 0>
+template <int TY, int MODE, int DBG = 0>
 __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_args a) {
-    typedef cg_geom<TY, WREG> G;
+    typedef cg_geom<TY, MODE> G;
+    constexpr bool WREG = MODE == 1, THIN = MODE == 2;
     constexpr int CG_TY = TY, CG_ROWS = G::ROWS, CG_ABUF = G::ABUF, CG_ACHUNKS = G::ACHUNKS, CG_PIECES = G::PIECES,
                   CG_BOFF = G::BOFF, NT = G::NT;
     constexpr int MTW = 4, NTW = 2;                       // 32-voxel rows / 32-cout blocks per wave
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
     const int to = rr / tiles_y;
     const int y0 = ty * CG_TY, x0 = tx * CG_TX, n0 = tn * 128;
 
-    const int cpk = g.Cin / 32;                           // 32-channel slices per tap
+    const int cpk = THIN ? 1 : g.Cin / 32;                // 32-channel slices per tap
     const int nA = g.kt * cpk;                            // A steps
     const int P = nA * 9;                                 // intervals
     const int64_t frame_bytes = (int64_t)g.H * g.W * g.Cin * 2;
@@ -209,6 +211,57 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
         else mfma_core(ar2, ar3, ar4, ar5);
     };
 
+    if constexpr (THIN) {
+        // ---- thin input (Cin = 4: RGB padded; encoder conv_in): the whole K = kt * 9 * 4 <= 128 fits one im2col image of
+        // the patch in LDS ([256 voxels][128 k], 272-byte rows); one thread gathers one voxel's taps (8 bytes each, the
+        // input is tiny and L2-resident), then 4 x 2 x (K / 16) MFMAs per wave with the weights read straight from
+        // their [N, 128] rows.  HBM-bound on the 128-channel output, which leaves through the shared epilogue below
+        // (fused GroupNorm statistics included) -- replaces an im2col pass + a K = 128 GEMM.
+        constexpr int TP = G::THIN_PITCH;
+        static_assert(NT == 256, "one voxel per thread");
+        const int taps = g.kt * 9;
+        {
+            const int y = y0 + (tid >> 5), x = x0 + (tid & 31);
+            char* rowp = smem + tid * TP;
+            const int64_t fpix = (int64_t)g.H * g.W;
+#pragma unroll 4
+            for (int tap = 0; tap < 32; ++tap) {
+                uint2 v = make_uint2(0u, 0u);
+                if (tap < taps) {
+                    const int dt = tap / 9, r = tap - dt * 9, dy = r / 3, dx = r - dy * 3;
+                    const int ys = y + dy - 1, xs = x + dx - 1;
+                    if ((unsigned)ys < (unsigned)g.H && (unsigned)xs < (unsigned)g.W) {
+                        int f = to + dt - g.pt;
+                        const char* basep = (const char*)a.A;
+                        if (f < 0) {
+                            if (g.halo != nullptr) { basep = (const char*)g.halo; f += g.halo_frames; }
+                            else f = 0;
+                        }
+                        v = *(const uint2*)(basep + ((int64_t)f * fpix + (int64_t)ys * g.W + xs) * 8);
+                    }
+                }
+                *(uint2*)(rowp + tap * 8) = v;
+            }
+        }
+        __syncthreads();
+        const int nks = (taps * 4 + 15) >> 4;             // 16-wide k steps that hold real taps (7 for 3x3x3)
+        const char* wrow0 = (const char*)a.W + ((int64_t)(n0 + wn * 64 + l31) * a.K + hi * 8) * 2;
+        const char* arow0 = smem + ((wm * MTW) * 32 + l31) * TP + hi * 16;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks < nks) {
+                const bf16x8 b0 = *(const bf16x8*)(wrow0 + ks * 32);
+                const bf16x8 b1 = *(const bf16x8*)(wrow0 + (int64_t)32 * a.K * 2 + ks * 32);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const bf16x8 av = *(const bf16x8*)(arow0 + mt * 32 * TP + ks * 32);
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, av, acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, av, acc[mt][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                  // the epilogue reuses the im2col image's LDS
+    } else
     if constexpr (WREG) {
         // ---- weights straight from global memory in fragment order
         const int64_t nstride = (int64_t)P * 2048;                                          // bytes per 32-cout block
@@ -514,34 +567,49 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
 int g_conv_lds_dbg = 0;    // measurement knob: dynamic LDS bytes to request (forces one workgroup per CU when > 80 KiB)
 static bool conv_halo2_wreg(const svr_gemm_args& a) { return a.W_frag != nullptr && g_conv_impl == 0; }
 
-template <int TY, bool WREG, int DBG = 0> static int launch_conv_halo2_t(const svr_gemm_args& a, hipStream_t s) {
-    typedef cg_geom<TY, WREG> G;
+template <int TY, int MODE, int DBG = 0> static int launch_conv_halo2_t(const svr_gemm_args& a, hipStream_t s) {
+    typedef cg_geom<TY, MODE> G;
     const svr_conv_geom& g = a.conv;
     const int tiles = g.To * ((g.H + TY - 1) / TY) * ((g.W + CG_TX - 1) / CG_TX) * (a.N / 128);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo2_kernel<TY, WREG, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_halo2_kernel<TY, MODE, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_halo2_kernel<TY, WREG, DBG>), dim3(tiles), dim3(G::NT), g_conv_lds_dbg > G::LDS ? g_conv_lds_dbg : G::LDS, s, a);
+    hipLaunchKernelGGL((conv_halo2_kernel<TY, MODE, DBG>), dim3(tiles), dim3(G::NT), g_conv_lds_dbg > G::LDS ? g_conv_lds_dbg : G::LDS, s, a);
     return (int)hipGetLastError();
 }
 
 static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
 #ifdef SVR_ABLATIONS
     if (conv_halo2_wreg(a)) switch (g_pipe_abl) {
-        case 1: return launch_conv_halo2_t<8, true, 1>(a, s);
-        case 2: return launch_conv_halo2_t<8, true, 2>(a, s);
-        case 4: return launch_conv_halo2_t<8, true, 4>(a, s);
-        case 7: return launch_conv_halo2_t<8, true, 7>(a, s);
+        case 1: return launch_conv_halo2_t<8, 1, 1>(a, s);
+        case 2: return launch_conv_halo2_t<8, 1, 2>(a, s);
+        case 4: return launch_conv_halo2_t<8, 1, 4>(a, s);
+        case 7: return launch_conv_halo2_t<8, 1, 7>(a, s);
         default: break;
     }
 #endif
-    return conv_halo2_wreg(a) ? launch_conv_halo2_t<8, true>(a, s) : launch_conv_halo2_t<16, false>(a, s);
+    return conv_halo2_wreg(a) ? launch_conv_halo2_t<8, 1>(a, s) : launch_conv_halo2_t<16, 0>(a, s);
 }
 
+// thin-input variant: Cin = 4 (RGB padded), 3x3 spatial taps, stride 1, the whole K in one 128-wide image
+static bool conv_thin_eligible(const svr_gemm_args& a) {
+    const svr_conv_geom& g = a.conv;
+    return g.enabled && g.Cin == 4 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.st == 1 &&
+           g.ph == 1 && g.pw == 1 && g.Ho == g.H && g.Wo == g.W && g.kt >= 1 && g.kt <= 3 && a.K == 128 &&
+           g.To == g.T + g.pt - g.kt + 1 && !a.ps.enabled && a.epilogue != SVR_EPI_SWIGLU && (a.N % 128) == 0 &&
+           (a.ldc % 8) == 0 && (!a.resid || (a.ldr % 8) == 0);
+}
+static int launch_conv_thin(const svr_gemm_args& a, hipStream_t s) { return launch_conv_halo2_t<8, 2>(a, s); }
+
 static int conv_gn_blocks(const svr_gemm_args& a) {
+    if (conv_thin_eligible(a) && !a.out_f32 && a.gn_groups > 0) {
+        const int cpg = a.N / a.gn_groups;
+        if (cpg < 4 || (cpg & 3) || a.N % a.gn_groups || 128 % cpg) return 0;
+        return ((a.conv.H + 7) / 8) * ((a.conv.W + CG_TX - 1) / CG_TX);
+    }
     if ((g_conv_impl != 0 && g_conv_impl != 3) || !conv_halo_eligible(a) || (a.N % 128) != 0 || a.conv.Cin % 32 != 0 || a.out_f32) return 0;
     const int cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 0;          // channels per group: 4, 8 or 16
     if (cpg < 4 || (cpg & 3) || a.N % a.gn_groups || 128 % cpg) return 0;

@@ -293,6 +293,8 @@ template <int BN> static int launch_conv_halo(const svr_gemm_args& a, hipStream_
 static bool conv_halo_eligible(const svr_gemm_args& a);
 static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s);
 static bool conv_halo2_eligible(const svr_gemm_args& a);
+static bool conv_thin_eligible(const svr_gemm_args& a);
+static int launch_conv_thin(const svr_gemm_args& a, hipStream_t s);
 int g_conv_impl = [] { const char* e = getenv("SVR_CONV_IMPL"); return e ? atoi(e) : 0; }();   // 0 auto, 1 generic, 2 first halo kernel, 3 second halo kernel without W_frag
 
 // Kernel selection (svr_set_option("gemm_impl", v); env SVR_GEMM_IMPL seeds it): 0 = auto (the
@@ -315,8 +317,10 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     if (a.K <= 0 || (a.K % BK) != 0) { *why = "svr_gemm_bf16: K must be a positive multiple of 64"; return -1; }
     if (a.conv.enabled) {
         const svr_conv_geom& g = a.conv;
-        if (g.Cin % BK != 0) { *why = "svr_gemm_bf16(conv): Cin must be a multiple of 64"; return -1; }
-        if (a.K != g.kt * g.kh * g.kw * g.Cin) { *why = "svr_gemm_bf16(conv): K != taps*Cin"; return -1; }
+        if (!conv_thin_eligible(a)) {       // (thin input: Cin = 4, K = taps * 4 zero-padded to 128)
+            if (g.Cin % BK != 0) { *why = "svr_gemm_bf16(conv): Cin must be a multiple of 64 (or the thin Cin = 4, 3x3, stride-1 geometry)"; return -1; }
+            if (a.K != g.kt * g.kh * g.kw * g.Cin) { *why = "svr_gemm_bf16(conv): K != taps*Cin"; return -1; }
+        }
         if (a.M != g.To * g.Ho * g.Wo) { *why = "svr_gemm_bf16(conv): M != To*Ho*Wo"; return -1; }
         if (!g.zeros) { *why = "svr_gemm_bf16(conv): zero page missing"; return -1; }
         if (g.halo && g.halo_frames < g.pt) { *why = "svr_gemm_bf16(conv): halo shorter than causal pad"; return -1; }
@@ -326,6 +330,7 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
         *why = "svr_gemm_bf16: bad pixel-shuffle geometry"; return -1;
     }
     if (a.gn_partial && conv_gn_blocks(a) == 0) { *why = "svr_gemm_bf16: gn_partial set but this launch cannot produce fused GroupNorm statistics"; return -1; }
+    if (conv_thin_eligible(a)) return launch_conv_thin(a, s);
     if ((g_conv_impl == 0 || g_conv_impl == 3) && conv_halo2_eligible(a)) return launch_conv_halo2(a, s);
     if (g_conv_impl != 1 && conv_halo_eligible(a))
         return a.N <= 32 ? launch_conv_halo<32>(a, s) : launch_conv_halo<128>(a, s);

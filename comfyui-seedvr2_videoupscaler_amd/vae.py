@@ -206,7 +206,13 @@ class VideoVAEEngine:
         K = cw.w.shape[1]
         epi = EPI_RESID_GATE if resid is not None else EPI_BIAS
         stats = None
-        if cw.thin:
+        if cw.thin and cw.cin == 4 and tuple(cw.k[1:]) == (3, 3) and tuple(cw.stride) == (1, 1, 1) and K == 128 \
+                and cw.cout % 128 == 0 and (cw.pad_lo, cw.pad_hi) == (1, 1):
+            # RGB input (encoder conv_in): the fused thin-input kernel builds the im2col image of each patch in LDS
+            r = ops.gemm(x, cw.w, out, N=cw.cout, K=K, bias=cw.b, epilogue=epi, resid=resid, conv=geom,
+                         ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups if gn else 0)
+            stats = r[1] if gn else None
+        elif cw.thin:
             cols = ops.empty(To * Ho * Wo, K)
             ops.im2col_causal(x, cols, geom)
             ops.gemm(cols, cw.w, out, N=cw.cout, K=K, M=To * Ho * Wo, bias=cw.b, epilogue=epi, resid=resid,

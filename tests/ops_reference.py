@@ -48,7 +48,7 @@ class TorchOps:
             ph_hi = max(0, (g.Ho - 1) * sh + kh - g.H - ph)
             pw_hi = max(0, (g.Wo - 1) * sw + kw - g.W - pw)
             xin = F.pad(xin, (pw, pw_hi, ph, ph_hi))
-            w5 = Wf.reshape(N, kt, kh, kw, g.Cin).permute(0, 4, 1, 2, 3)
+            w5 = Wf[:, :kt * kh * kw * g.Cin].reshape(N, kt, kh, kw, g.Cin).permute(0, 4, 1, 2, 3)   # (thin: K zero-padded)
             y = F.conv3d(xin, w5, stride=(st, sh, sw))[0]                       # [N, To', Ho', Wo']
             y = y[:, :g.To, :g.Ho, :g.Wo]
             assert y.shape[1:] == (g.To, g.Ho, g.Wo), (y.shape, g)

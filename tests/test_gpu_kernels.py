@@ -230,6 +230,45 @@ def test_conv3d_halo_kernel_race_screen_and_generic_agreement(hip):
     assert rel_err(outs[0], gen) < 1e-5
 
 
+@pytest.mark.parametrize("kt,T,H,W,hf,resid_on", [(3, 3, 21, 70, 0, False), (3, 2, 9, 33, 2, True), (1, 2, 8, 32, 0, False),
+                                                   (3, 5, 64, 96, 0, True)])
+def test_conv3d_thin_input_fused(hip, ref, kt, T, H, W, hf, resid_on):
+    """RGB (Cin 3 -> padded 4) 3x3 conv served by the thin-input variant of the LDS-halo kernel (im2col image built in
+    LDS) == the im2col + GEMM route == fp32 F.conv3d; fused GroupNorm statistics == statistics of the stored tensor."""
+    packing, opsmod = sub("packing"), sub("ops")
+    Cout = 128
+    x = rnd(T, H, W, 4)
+    x[..., 3] = 0
+    halo = rnd(hf, H, W, 4, seed=9) if hf else None
+    w5 = rnd(Cout, 3, kt, 3, 3, scale=1.0 / math.sqrt(27 * 3), seed=2)
+    Wp = packing.pack_conv3d(w5, "cuda", 4)
+    assert Wp.shape == (128, 128) if kt == 3 else Wp.shape[1] % 64 == 0
+    if Wp.shape[1] != 128:
+        Wp = torch.nn.functional.pad(Wp, (0, 128 - Wp.shape[1]))
+    bias = rnd(Cout, dtype=torch.float32, seed=3)
+    pt = hf if hf else kt - 1
+    To = T + pt - kt + 1
+    geom = opsmod.Conv3dGeom(T, H, W, 4, To, H, W, (kt, 3, 3), (1, 1, 1), (pt, 1, 1), halo)
+    resid = rnd(To, H, W, Cout, seed=11) if resid_on else None
+    epi = EPI_RESID_GATE if resid_on else EPI_BIAS
+    out = torch.empty(To, H, W, Cout, device="cuda", dtype=BF16)
+    _, stats = hip.gemm(x, Wp, out, N=Cout, K=128, bias=bias, conv=geom, epilogue=epi, resid=resid, ldc=Cout, ldr=Cout,
+                        gn_groups=32)
+    want = ref.gemm(x, Wp, torch.empty(To, H, W, Cout, device="cuda"), N=Cout, K=128, bias=bias, conv=geom,
+                    epilogue=epi, resid=resid)
+    assert rel_err(out.float(), want) < TOL_BF16
+    # the older route: explicit im2col + plain GEMM
+    cols = torch.empty(To * H * W, 128, device="cuda", dtype=BF16)
+    hip.im2col_causal(x, cols, geom)
+    out2 = torch.empty_like(out)
+    hip.gemm(cols, Wp, out2, N=Cout, K=128, M=To * H * W, bias=bias, epilogue=epi, resid=resid, lda=128, ldc=Cout, ldr=Cout)
+    assert rel_err(out.float(), out2.float()) < TOL_BF16
+    assert stats is not None
+    o = out.double().reshape(To, H * W, 32, Cout // 32)
+    want_stats = torch.stack([o.sum(dim=(1, 3)), (o * o).sum(dim=(1, 3))], dim=-1)
+    assert torch.allclose(stats, want_stats, rtol=1e-6, atol=1e-3)
+
+
 @pytest.mark.parametrize("rz,drop", [(1, False), (2, False), (2, True)])
 def test_upscale_pixel_shuffle_epilogue(hip, ref, rz, drop):
     packing, opsmod = sub("packing"), sub("ops")
