@@ -8,6 +8,11 @@ upscaled frames.  Restated from src/utils/color_fix.py (results identical on the
   lab_color_transfer                :249-366  wavelet base -> CIELAB (D65) -> per-channel histogram matching
                                                (a*, b* fully, L* blended with luminance_weight) -> RGB
   _rgb_to_lab_batch / _lab_to_rgb_batch / _histogram_matching_channel   :368-522
+  hsv_saturation_histogram_match    :524-612  HSV; saturation histogram-matched per 30-degree hue bin (bins with
+                                               <= 100 pixels on either side are left alone), H and V kept
+  _rgb_to_hsv_batch / _hsv_to_rgb_batch / _hue_conditional_saturation_match / _histogram_match_1d   :614-770
+  wavelet_adaptive_color_correction :772-856  wavelet base, HSV result blended in where content is oversaturated
+                                               (sigmoid(5 (dS - 0.15)), gated by the wavelet result's own excess)
 
 All tensors are [B, C, H, W] in [-1, 1]; the work is HBM / sort bound (no MFMA), so it stays torch glue on
 the device.
@@ -124,8 +129,86 @@ def lab_color_transfer(content: torch.Tensor, style: torch.Tensor, luminance_wei
     return (rgb * 2.0 - 1.0).to(dt)
 
 
+def rgb_to_hsv(rgb: torch.Tensor) -> torch.Tensor:
+    """[B, 3, H, W] in [0, 1] -> (h, s, v) in [0, 1]; ties between channels resolve blue > green > red."""
+    r, g, b = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+    maxc, minc = rgb.max(dim=1).values, rgb.min(dim=1).values
+    rng = maxc - minc
+    colour = rng > 1e-10
+    d = torch.where(colour, rng, torch.ones_like(rng))
+    h = torch.where((maxc == r) & colour, torch.remainder((g - b) / d, 6.0), torch.zeros_like(maxc))
+    h = torch.where((maxc == g) & colour, (b - r) / d + 2.0, h)
+    h = torch.where((maxc == b) & colour, (r - g) / d + 4.0, h)
+    s = torch.where(maxc > 1e-10, rng / maxc.clamp(min=1e-10), torch.zeros_like(maxc))
+    return torch.stack([h / 6.0, s, maxc], dim=1)
+
+
+def hsv_to_rgb(hsv: torch.Tensor) -> torch.Tensor:
+    h6, s, v = hsv[:, 0] * 6.0, hsv[:, 1], hsv[:, 2]
+    sector = torch.floor(h6).long() % 6
+    f = h6 - torch.floor(h6)
+    p, q, t = v * (1.0 - s), v * (1.0 - s * f), v * (1.0 - s * (1.0 - f))
+    table = ((v, t, p), (q, v, p), (p, v, t), (p, q, v), (t, p, v), (v, p, q))     # (r, g, b) of sectors 0..5
+    out = []
+    for ch in range(3):
+        x = torch.zeros_like(v)
+        for k in range(6):
+            x = torch.where(sector == k, table[k][ch], x)
+        out.append(x)
+    return torch.stack(out, dim=1)
+
+
+def hue_conditional_saturation_match(c_h, c_s, s_h, s_s, bins: int = 12, min_pixels: int = 100) -> torch.Tensor:
+    """Saturation of the content pixels of each hue bin histogram-matched to the style pixels of the same bin (bin 0
+    also collects h >= 1 - 1/bins: the red wrap-around, so those pixels may be matched twice, last bin winning)."""
+    width = 1.0 / bins
+    out = c_s.clone()
+    for k in range(bins):
+        lo, hi = k * width, (k + 1) * width
+        if k == 0:
+            cm = ((c_h >= 0) & (c_h < hi)) | (c_h >= 1.0 - width)
+            sm = ((s_h >= 0) & (s_h < hi)) | (s_h >= 1.0 - width)
+        else:
+            cm, sm = (c_h >= lo) & (c_h < hi), (s_h >= lo) & (s_h < hi)
+        cs, ss = c_s[cm], s_s[sm]
+        if cs.numel() > min_pixels and ss.numel() > min_pixels:
+            out[cm] = histogram_match(cs, ss)
+    return out
+
+
+def hsv_saturation_histogram_match(content: torch.Tensor, style: torch.Tensor) -> torch.Tensor:
+    style = _resize_like(style, content)
+    dt = content.dtype
+    c = rgb_to_hsv(((content.float() + 1.0) * 0.5).clamp(0.0, 1.0))
+    s = rgb_to_hsv(((style.float() + 1.0) * 0.5).clamp(0.0, 1.0))
+    sat = hue_conditional_saturation_match(c[:, 0], c[:, 1], s[:, 0], s[:, 1])
+    rgb = hsv_to_rgb(torch.stack([c[:, 0], sat, c[:, 2]], dim=1)).clamp(0.0, 1.0)
+    return (rgb * 2.0 - 1.0).to(dt)
+
+
+def saturation_map(x: torch.Tensor) -> torch.Tensor:
+    rgb = ((x + 1.0) * 0.5).clamp(0.0, 1.0)
+    maxc, minc = rgb.max(dim=1, keepdim=True).values, rgb.min(dim=1, keepdim=True).values
+    return torch.where(maxc > 1e-10, (maxc - minc) / maxc.clamp(min=1e-10), torch.zeros_like(maxc))
+
+
+def wavelet_adaptive_color_correction(content: torch.Tensor, style: torch.Tensor, threshold: float = 0.15,
+                                      sharpness: float = 5.0) -> torch.Tensor:
+    style = _resize_like(style, content)
+    dt = content.dtype
+    content, style = content.float(), style.float()
+    base = wavelet_reconstruction(content, style)
+    hsv = hsv_saturation_histogram_match(content, style)
+    s_sat = saturation_map(style)
+    w = torch.sigmoid(sharpness * (saturation_map(content) - s_sat - threshold))
+    w = (w * ((saturation_map(base) - s_sat) > threshold * 0.5).float()).clamp(0.0, 1.0)
+    return (base * (1.0 - w) + hsv * w).to(dt)
+
+
 METHODS = {
     "lab": lambda c, s: lab_color_transfer(c, s, luminance_weight=0.8),
+    "wavelet_adaptive": wavelet_adaptive_color_correction,
+    "hsv": hsv_saturation_histogram_match,
     "wavelet": wavelet_reconstruction,
     "adain": adaptive_instance_normalization,
 }

@@ -184,5 +184,7 @@ def reference_glue():
     _extract("src/utils/color_fix.py",
              ["calc_mean_std", "adaptive_instance_normalization", "wavelet_blur", "wavelet_decomposition",
               "wavelet_reconstruction", "lab_color_transfer", "_rgb_to_lab_batch", "_lab_to_rgb_batch",
-              "_histogram_matching_channel"], ns)
+              "_histogram_matching_channel", "hsv_saturation_histogram_match", "_rgb_to_hsv_batch", "_hsv_to_rgb_batch",
+              "_hue_conditional_saturation_match", "_histogram_match_1d", "wavelet_adaptive_color_correction",
+              "_get_saturation_map"], ns)
     return ns

@@ -84,13 +84,21 @@ def test_resized_output_size_matches_interpolate_shapes():
 
 # ------------------------------------------------------------------ colour correction
 @needs_ref
-@pytest.mark.parametrize("method", ["adain", "wavelet", "lab"])
+@pytest.mark.parametrize("method", ["adain", "wavelet", "lab", "hsv", "wavelet_adaptive"])
 def test_colorfix_equals_reference(ref, method):
     cf = sub("colorfix")
     g = torch.Generator().manual_seed(7)
     content = (torch.rand(2, 3, 48, 72, generator=g) * 2 - 1) * 0.9
     style = (torch.rand(2, 3, 48, 72, generator=g) * 2 - 1) * 0.6 + 0.1
-    if method == "adain":
+    if method in ("hsv", "wavelet_adaptive"):
+        class _Dbg:
+            def log(self, *a, **k):
+                pass
+        content[:, :, :8, :8] = 0.3                     # grey block: the zero-range (hue 0, saturation 0) branch
+        content[:, 0, 8:16] = content[:, 1, 8:16]       # r == g ties
+        fn = ref["hsv_saturation_histogram_match" if method == "hsv" else "wavelet_adaptive_color_correction"]
+        want = fn(content.clone(), style.clone(), _Dbg())
+    elif method == "adain":
         want = ref["adaptive_instance_normalization"](content.clone(), style.clone())
     elif method == "wavelet":
         want = ref["wavelet_reconstruction"](content.clone(), style.clone())
