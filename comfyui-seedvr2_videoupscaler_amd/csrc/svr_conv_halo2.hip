@@ -62,7 +62,8 @@ template <int TY, int MODE> struct cg_geom {          // MODE 0 weights through 
 
 template <int N> SVR_DEVICE void cg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// DBG (builds with -DSVR_ABLATIONS only; results invalid): 1 no weight loads, 2 no halo LDS-DMA, 4 no global stores
+// DBG (builds with -DSVR_ABLATIONS only; results invalid): 1 no weight loads, 2 no halo LDS-DMA, 4 no global stores,
+// 8 no workgroup barrier in the K loop, 16 halo staged once in the prologue (real data) and never again
 template <int TY, int MODE, int DBG = 0>
 __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_args a) {
     typedef cg_geom<TY, MODE> G;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             constexpr int DY = J % 3;
             const int k = s * 9 + J;
             bool a_issued = false;
-            if constexpr (J < CG_PIECES) {
+            if constexpr (J < CG_PIECES && !(DBG & 16)) {
                 if (s + 1 < nA) a_issued = stage_a_piece(std::integral_constant<int, (J < CG_PIECES ? J : 0)>{}, fnext, (s + 1) & 1);
             }
             wload(wn_, k + 2);
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
                 // (last step: drain the hand-issued weight loads -- hipcc does not know they are in flight and would
                 // reuse their destination registers in the epilogue while the data is still on its way)
                 if (s + 1 < nA) cg_wait_vmcnt<8>(); else cg_wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
+                if constexpr (!(DBG & 8)) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -360,6 +361,14 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             stage_a_piece(std::integral_constant<int, 4>{}, f0, 0);
             if constexpr (CG_PIECES > 5) stage_a_piece(std::integral_constant<int, (CG_PIECES > 5 ? 5 : 0)>{}, f0, 0);
             static_assert(CG_PIECES <= 6, "prologue stages at most six pieces");
+            if constexpr ((DBG & 16) != 0) {          // measurement: both halo buffers hold real data, no staging in the loop
+                stage_a_piece(std::integral_constant<int, 0>{}, f0, 1);
+                stage_a_piece(std::integral_constant<int, 1>{}, f0, 1);
+                stage_a_piece(std::integral_constant<int, 2>{}, f0, 1);
+                stage_a_piece(std::integral_constant<int, 3>{}, f0, 1);
+                stage_a_piece(std::integral_constant<int, 4>{}, f0, 1);
+                if constexpr (CG_PIECES > 5) stage_a_piece(std::integral_constant<int, (CG_PIECES > 5 ? 5 : 0)>{}, f0, 1);
+            }
             wload(w0, 0);
             wload(w1, 1);
             cg_wait_vmcnt<0>();
@@ -588,6 +597,8 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
         case 2: return launch_conv_halo2_t<8, 1, 2>(a, s);
         case 4: return launch_conv_halo2_t<8, 1, 4>(a, s);
         case 7: return launch_conv_halo2_t<8, 1, 7>(a, s);
+        case 8: return launch_conv_halo2_t<8, 1, 8>(a, s);
+        case 16: return launch_conv_halo2_t<8, 1, 16>(a, s);
         default: break;
     }
 #endif
