@@ -298,17 +298,33 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
     const int64_t nchunks = HW * cchunks;
     const bf16_t* xb = x + (int64_t)t * HW * C;
     bf16_t* yb = y + (int64_t)t * HW * C;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)(i % cchunks) * 8;
-        const uint4 v = *(const uint4*)(xb + i * 8);
-        float f[8];
-        unpack8(v, f);
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    auto act = [&](float u) { return apply_silu ? silu(u) : u; };
+    if ((256 % cchunks) == 0) {
+        // every chunk this thread touches starts at the same channel (the grid stride is a multiple of C / 8):
+        // its 8 scale / offset pairs live in registers, no per-chunk index arithmetic or LDS reads
+        const int c0 = (threadIdx.x % cchunks) * 8;
+        float sa[8], sb[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float u = f[e] * a_s[c0 + e] + b_s[c0 + e];
-            f[e] = apply_silu ? silu(u) : u;
+        for (int e = 0; e < 8; ++e) { sa[e] = a_s[c0 + e]; sb[e] = b_s[c0 + e]; }
+        for (int64_t i = i0; i < nchunks; i += stride) {
+            const uint4 v = *(const uint4*)(xb + i * 8);
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = act(f[e] * sa[e] + sb[e]);
+            *(uint4*)(yb + i * 8) = pack8(f);
         }
-        *(uint4*)(yb + i * 8) = pack8(f);
+    } else {
+        for (int64_t i = i0; i < nchunks; i += stride) {
+            const int c0 = (int)(i % cchunks) * 8;
+            const uint4 v = *(const uint4*)(xb + i * 8);
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = act(f[e] * a_s[c0 + e] + b_s[c0 + e]);
+            *(uint4*)(yb + i * 8) = pack8(f);
+        }
     }
 }
 
