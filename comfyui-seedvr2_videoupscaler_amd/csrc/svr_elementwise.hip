@@ -307,7 +307,22 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
         float sa[8], sb[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sa[e] = a_s[c0 + e]; sb[e] = b_s[c0 + e]; }
-        for (int64_t i = i0; i < nchunks; i += stride) {
+        // streaming pass (the tensor is far larger than L2): non-temporal accesses, two chunks in flight per thread
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        int64_t i = i0;
+        for (; i + stride < nchunks; i += 2 * stride) {
+            const u32x4 v0 = __builtin_nontemporal_load((const u32x4*)(xb + i * 8));
+            const u32x4 v1 = __builtin_nontemporal_load((const u32x4*)(xb + (i + stride) * 8));
+            float f[8], h[8];
+            unpack8(make_uint4(v0.x, v0.y, v0.z, v0.w), f);
+            unpack8(make_uint4(v1.x, v1.y, v1.z, v1.w), h);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[e] = act(f[e] * sa[e] + sb[e]); h[e] = act(h[e] * sa[e] + sb[e]); }
+            const uint4 o0 = pack8(f), o1 = pack8(h);
+            __builtin_nontemporal_store(u32x4{o0.x, o0.y, o0.z, o0.w}, (u32x4*)(yb + i * 8));
+            __builtin_nontemporal_store(u32x4{o1.x, o1.y, o1.z, o1.w}, (u32x4*)(yb + (i + stride) * 8));
+        }
+        for (; i < nchunks; i += stride) {
             const uint4 v = *(const uint4*)(xb + i * 8);
             float f[8];
             unpack8(v, f);
