@@ -218,7 +218,7 @@ def main():
                 traffic_note = "bytes/launch, FETCH_SIZE*2 + WRITE_SIZE from profiles/r1_cfg3_pmc_traffic.json"
         except (OSError, KeyError, ValueError):
             pass
-        roof = {"bound": "mfma", "kernel": "svr::conv_halo2_kernel (LDS-halo implicit-GEMM causal Conv3d, 16x32-voxel patches, 3x3 spatial taps)",
+        roof = {"bound": "mfma", "kernel": "svr::conv_halo2_kernel<8, register-streamed weights> (LDS-halo implicit-GEMM causal Conv3d, 8x32-voxel patches x 128 couts, 3x3 spatial taps)",
                 "achieved": c_flops / max(c_sec, 1e-12) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": c_flops / max(c_sec, 1e-12) / 1e12 / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "traffic_note": traffic_note,

@@ -336,7 +336,10 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
         return a.N <= 32 ? launch_conv_halo<32>(a, s) : launch_conv_halo<128>(a, s);
     if (pipe_eligible(a) && use_pipe_kernel(a))
         return a.conv.enabled ? launch_pipe<true>(a, s) : launch_pipe<false>(a, s);
-    const bool wide = (a.N % 256) == 0;     // otherwise W is padded to a multiple of 128 rows
+    // 256-wide tiles when N allows it (otherwise W is padded to a multiple of 128 rows) -- unless they would leave CUs idle:
+    // the VAE attention's P V product (16384 x 512 x 16384) has only 128 such tiles for 256 CUs
+    const bool wide = (a.N % 256) == 0 &&
+                      (int64_t)((a.M + 255) / 256) * (a.N / 256) >= (a.conv.enabled ? 0 : 256);
     if (a.conv.enabled) {
         return wide ? launch<256, 256, 128, 64, true>(a, s) : launch<256, 128, 64, 64, true>(a, s);
     }

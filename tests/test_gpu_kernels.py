@@ -51,7 +51,9 @@ def packed(n, k, seed=1):
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 256), (257, 64, 192), (1, 2560, 256),
                                    (513, 384, 64), (2048, 1536, 2560),
                                    # pipelined 256x256 kernel (N % 256 == 0): 1, 3 and 5 K tiles, ragged M
-                                   (300, 256, 64), (700, 512, 192), (255, 512, 320), (58, 2560, 5120)])
+                                   (300, 256, 64), (700, 512, 192), (255, 512, 320), (58, 2560, 5120),
+                                   # >= 256 tiles of 256x256: the wide-tile kernel (fewer tiles run 256x128 so no CU idles)
+                                   (4100, 4096, 128), (16384, 512, 256)])
 @pytest.mark.parametrize("out_f32", [False, True])
 def test_gemm_bias(hip, ref, M, N, K, out_f32):
     A = rnd(M, K)

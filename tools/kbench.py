@@ -126,6 +126,21 @@ def main():
         sec = timeit(lambda: ops.attn_varlen(qkv, att, rows, rows, cu, n, 1, Cc, 1 / math.sqrt(Cc)), max(1, args.reps // 2))
         report("attn VAE mid (9 x 16384 tokens, d=512)", sec, flops=4.0 * Cc * n * n * T)
         del qkv, att
+        # the same attention as the VAE engine runs it at tile sizes: Q K^T (fp32 scores) -> row softmax -> P V, one frame
+        q, k, v = rnd(n, Cc), rnd(n + 256, Cc), rnd(n, Cc)
+        S = ops.empty(n, n, dtype=torch.float32)
+        P = ops.empty(n, n)
+        o = ops.empty(n, Cc)
+        vt = v.t().contiguous()
+        sec = timeit(lambda: ops.gemm(q, k[:n], S, N=n, K=Cc, out_f32=True), args.reps)
+        report("VAE mid attn, 1 frame: S = Q K^T (16384^2 x 512, fp32 out)", sec, flops=2.0 * n * n * Cc)
+        sec = timeit(lambda: ops.softmax_rows(S, P, 1 / math.sqrt(Cc)), args.reps)
+        report("VAE mid attn, 1 frame: softmax rows 16384^2", sec, bytes_=n * n * 6)
+        sec = timeit(lambda: ops.gemm(P, vt, o, N=Cc, K=n), args.reps)
+        report("VAE mid attn, 1 frame: O = P V (16384 x 512 x 16384)", sec, flops=2.0 * n * n * Cc)
+        sec = timeit(lambda: v.t().contiguous(), args.reps)
+        report("VAE mid attn, 1 frame: V^T copy (torch)", sec, bytes_=n * Cc * 4)
+        del q, k, v, S, P, o, vt
     if "side" in only:
         T, H, W, Cc = 5, 1024, 1024, 128
         x = rnd(T, H, W, Cc)
