@@ -1,0 +1,59 @@
+"""-m "not gpu": static resource checks of the hand-scheduled kernels (hipcc cross-compiles without a GPU).
+
+The LDS-halo conv kernels issue loads as inline asm and count ``vmcnt`` by hand: a register spill (scratch traffic is
+VMEM) or a register budget above 256 (one wave per SIMD instead of two) would silently break the schedule, so the
+kernel metadata is pinned here."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT, sub
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    hip_lib = sub("hip_lib")
+    out = tmp_path_factory.mktemp("asm") / "svr_api.s"
+    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc"] + [f for f in hip_lib.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + \
+          ["-S", "--cuda-device-only", os.path.join(hip_lib.CSRC, "svr_api.hip"), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out.read_text()
+
+
+def _kernels(asm):
+    """name -> metadata dict from the amdhsa.kernels YAML block."""
+    meta = {}
+    for blk in re.split(r"\n  - \.agpr_count:", asm)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if not name:
+            continue
+        get = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", blk).group(1))
+        meta[name.group(1)] = {k: get(k) for k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count",
+                                                   "private_segment_fixed_size", "max_flat_workgroup_size")}
+    return meta
+
+
+def test_hand_scheduled_kernels_do_not_spill_and_keep_two_waves_per_simd(device_asm):
+    meta = _kernels(device_asm)
+    halo = {k: v for k, v in meta.items() if "conv_halo2_kernel" in k or "conv_halo_kernel" in k}
+    assert len(halo) >= 4, sorted(meta)[:10]
+    for name, m in halo.items():
+        # (SGPR spills go to VGPR lanes with v_writelane: no memory traffic, allowed)
+        assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (name, m)
+        assert m["vgpr_count"] <= 256, (name, m)          # two waves per SIMD (512 registers per lane)
+    shipped = [v for k, v in halo.items() if "conv_halo2_kernelILi8ELi1ELi0E" in k]
+    assert shipped and shipped[0]["max_flat_workgroup_size"] == 256
+
+
+def test_no_kernel_uses_scratch(device_asm):
+    """None of the library's kernels may spill: every one of them is bandwidth- or MFMA-bound by design."""
+    bad = {k: v for k, v in _kernels(device_asm).items() if k.startswith("_ZN3svr") and v["private_segment_fixed_size"]}
+    assert not bad, bad
