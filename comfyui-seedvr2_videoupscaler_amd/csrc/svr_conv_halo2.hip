@@ -63,7 +63,8 @@ template <int TY, int MODE> struct cg_geom {          // MODE 0 weights through 
 template <int N> SVR_DEVICE void cg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // DBG (builds with -DSVR_ABLATIONS only; results invalid): 1 no weight loads, 2 no halo LDS-DMA, 4 no global stores,
-// 8 no workgroup barrier in the K loop, 16 halo staged once in the prologue (real data) and never again
+// 8 no workgroup barrier in the K loop, 16 halo staged once in the prologue (real data) and never again,
+// 32 weights always from the same four (L1-hot) units, 64 halo-row fragments read from LDS in the first A step only, 128 halo re-staged every step but always from the same (cache-hot) addresses
 template <int TY, int MODE, int DBG = 0>
 __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_args a) {
     typedef cg_geom<TY, MODE> G;
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
         // issues, which would expose the full load latency; the waits below are counted by hand instead
         // (vmcnt retires in issue order)
         auto wload = [&](bf16x8 (&w)[NTW][2], int k) {
+            if constexpr ((DBG & 32) != 0) k &= 3;                  // measurement: weights always from the same 4 L1-hot units
             const char* p0 = wp0 + (int64_t)min(k, P - 1) * 2048;     // (the last two intervals re-load the final unit)
             const char* p1 = wp1 + (int64_t)min(k, P - 1) * 2048;
             if constexpr (DBG & 1) {
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
         auto reads_a = [&](auto jc, int s) {
             constexpr int J = decltype(jc)::value;
             constexpr int DY = J % 3, DX = J / 3;
+            if constexpr ((DBG & 64) != 0) { if (s > 0) return; }  // measurement: halo-row fragments read in the first step only
             int ra = rd_a0[DX] + (s & 1) * CG_ABUF;
             asm volatile("" : "+v"(ra));
 #pragma unroll
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             __builtin_amdgcn_sched_barrier(0);
         }
         for (int s = 0; s < nA; ++s) {
-            const char* fnext = frame_ptr(min(s + 1, nA - 1));
+            const char* fnext = frame_ptr((DBG & 128) ? 0 : min(s + 1, nA - 1));     // (128: always the same, cache-hot halo)
             interval3(std::integral_constant<int, 0>{}, s, fnext, w0, w2);
             interval3(std::integral_constant<int, 1>{}, s, fnext, w1, w0);
             interval3(std::integral_constant<int, 2>{}, s, fnext, w2, w1);
@@ -599,6 +602,11 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
         case 7: return launch_conv_halo2_t<8, 1, 7>(a, s);
         case 8: return launch_conv_halo2_t<8, 1, 8>(a, s);
         case 16: return launch_conv_halo2_t<8, 1, 16>(a, s);
+        case 32: return launch_conv_halo2_t<8, 1, 32>(a, s);
+        case 64: return launch_conv_halo2_t<8, 1, 64>(a, s);
+        case 48: return launch_conv_halo2_t<8, 1, 48>(a, s);
+        case 112: return launch_conv_halo2_t<8, 1, 112>(a, s);
+        case 128: return launch_conv_halo2_t<8, 1, 128>(a, s);
         default: break;
     }
 #endif
