@@ -118,6 +118,15 @@ int svr_attn_varlen(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, 
     return check(rc, "svr_attn_varlen");
 }
 
+#ifdef SVR_ABLATIONS
+extern "C" int svr_debug_conv_timeline(void* dst_host, int64_t bytes) {     // measurement builds only (not in the public header)
+    return check(hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_conv_tl), (size_t)bytes), "svr_debug_conv_timeline");
+}
+extern "C" int svr_debug_conv_epilogue(void* dst_host, int64_t bytes) {
+    return check(hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_conv_ep), (size_t)bytes), "svr_debug_conv_epilogue");
+}
+#endif
+
 int svr_conv_pack_frag(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t Cin, void* stream) {
     if (N <= 0 || N % 32 || Cin <= 0 || Cin % 32 || kt < 1 || kt > 3 || K != kt * 9 * Cin)
         return fail("svr_conv_pack_frag: need N % 32 == 0, Cin % 32 == 0, kt in 1..3, K == kt * 9 * Cin");

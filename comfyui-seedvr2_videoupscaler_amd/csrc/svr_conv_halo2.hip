@@ -62,6 +62,10 @@ template <int TY, int MODE> struct cg_geom {          // MODE 0 weights through 
 
 template <int N> SVR_DEVICE void cg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+#ifdef SVR_ABLATIONS
+__device__ unsigned long long g_conv_tl[4096][4];
+__device__ unsigned long long g_conv_ep[4096][8];      // DBG 256: stamps inside the epilogue (thread 0)       // DBG 256: s_memtime at kernel start / after prologue / after K loop / end
+#endif
 // DBG (builds with -DSVR_ABLATIONS only; results invalid): 1 no weight loads, 2 no halo LDS-DMA, 4 no global stores,
 // 8 no workgroup barrier in the K loop, 16 halo staged once in the prologue (real data) and never again,
 // 32 weights always from the same four (L1-hot) units, 64 halo-row fragments read from LDS in the first A step only, 128 halo re-staged every step but always from the same (cache-hot) addresses
@@ -77,6 +81,9 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
 
     const svr_conv_geom& g = a.conv;
     const int tid = threadIdx.x;
+#ifdef SVR_ABLATIONS
+    if constexpr ((DBG & 256) != 0) { if (tid == 0 && blockIdx.x < 4096) g_conv_tl[blockIdx.x][0] = __builtin_amdgcn_s_memtime(); }
+#endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;                            // (TY = 16) the two waves of a SIMD are in different groups
@@ -103,6 +110,19 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
     const int nA = g.kt * cpk;                            // A steps
     const int P = nA * 9;                                 // intervals
     const int64_t frame_bytes = (int64_t)g.H * g.W * g.Cin * 2;
+    // Phase stagger (two workgroups per CU).  All tiles of a launch take the same time, so without it every workgroup
+    // of the chip stays in lockstep with the first dispatch wave: the two workgroups of a CU reach their epilogues
+    // together (nothing overlaps them) and all 512 resident tiles store at the same instant (s_memtime: 24 k cycles per
+    // epilogue, 820 cycles per store iteration).  The workgroups of the first dispatch wave therefore start 0..7 eighths
+    // of a K loop late -- the two slots of a CU half a tile apart, neighbouring CUs 3/8 apart -- and later workgroups
+    // inherit the phase of the slot they take over.  (a.ps.F = 1 with the pixel shuffle disabled: measurement knob, off.)
+    if constexpr (MODE != 0) {
+        if (blockIdx.x < 512 && a.ps.F == 0) {
+            const int units = (((int)blockIdx.x >> 3) * 3 + ((int)blockIdx.x >> 8) * 4) & 7;
+            const int naps = (units * (THIN ? 16 : P)) / 43;          // one nap = s_sleep 100 = 6400 cycles; K loop = P * 1200
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(100);
+        }
+    }
 
     // ---- staging roles: one 16-byte chunk per thread and piece / unit (row = id >> 2, position = id & 3)
     const int srow = tid >> 2, spos = tid & 3;
@@ -378,6 +398,9 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef SVR_ABLATIONS
+        if constexpr ((DBG & 256) != 0) { if (tid == 0 && blockIdx.x < 4096) g_conv_tl[blockIdx.x][1] = __builtin_amdgcn_s_memtime(); }
+#endif
         for (int s = 0; s < nA; ++s) {
             const char* fnext = frame_ptr((DBG & 128) ? 0 : min(s + 1, nA - 1));     // (128: always the same, cache-hot halo)
             interval3(std::integral_constant<int, 0>{}, s, fnext, w0, w2);
@@ -466,6 +489,9 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
 
     }
 
+#ifdef SVR_ABLATIONS
+    if constexpr ((DBG & 256) != 0) { if (tid == 0 && blockIdx.x < 4096) g_conv_tl[blockIdx.x][2] = __builtin_amdgcn_s_memtime(); }
+#endif
     // ---- epilogue through LDS, two passes of EP_ROWS patch rows (TY = 16: rows 0-7 are the waves with wm < 2, rows 8-15
     // wm >= 2; TY = 8: one wave row per pass): the fp32 tile (+ bias) is parked in LDS [voxels][132 floats] and written back row-contiguous
     // (16 lanes cover one voxel's 128 couts; every global access is a full 16-byte lane / 256-byte row).
@@ -479,75 +505,107 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             const int n = n0 + wn * 64 + nt * 32 + 8 * gq + hi4;
             bv[nt][gq] = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#ifdef SVR_ABLATIONS
+#define SVR_EP_STAMP(i) if constexpr ((DBG & 256) != 0) { if (tid == 0 && blockIdx.x < 4096) g_conv_ep[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define SVR_EP_STAMP(i)
+#endif
+    SVR_EP_STAMP(0)
     const bool resid_gate = a.epilogue == SVR_EPI_RESID_GATE;
     // fused GroupNorm statistics of the stored (bf16-rounded) output: this thread always stores the same
     // 8-cout chunk (tid & 15), so it keeps two quad sums over its 16 voxels
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
     constexpr int EP_ROWS = G::EP_ROWS, EP_WM = EP_ROWS / MTW;      // patch rows / wave rows per pass
     static_assert(TY / EP_ROWS == 2 && EP_ROWS * 32 * 16 == 8 * NT, "two passes, eight store iterations each");
+    // The body is instantiated once per option set of the production calls (bf16 output, no SiLU, no gate; residual and
+    // fused statistics on / off) so that the loops carry no per-element option branches -- a taken scalar branch costs a
+    // wave ~40 cycles of instruction refetch, and with one per LDS write / five per store iteration they made up a third
+    // of the epilogue (s_memtime).  F < 0: every option decided at run time (fp32 output, SiLU, gate: tests, DiT-style use).
+    auto ep_body = [&](auto fc) {
+        constexpr int F = decltype(fc)::value;
+        constexpr bool RT = F < 0, F_RESID = !RT && (F & 1), F_GN = !RT && (F & 2);
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if (wm / EP_WM == pass) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if (wm / EP_WM == pass) {
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-                char* row = smem + (((wm % EP_WM) * MTW + mt) * 32 + l31) * EP_PITCH;
+                for (int mt = 0; mt < MTW; ++mt) {
+                    char* row = smem + (((wm % EP_WM) * MTW + mt) * 32 + l31) * EP_PITCH;
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    const f32x16_t v = acc[mt][nt];
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const f32x16_t v = acc[mt][nt];
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        f32x4 o = {v[4 * gq] + bv[nt][gq][0], v[4 * gq + 1] + bv[nt][gq][1],
-                                   v[4 * gq + 2] + bv[nt][gq][2], v[4 * gq + 3] + bv[nt][gq][3]};
-                        if (a.epilogue == SVR_EPI_BIAS_SILU) { o[0] = silu(o[0]); o[1] = silu(o[1]); o[2] = silu(o[2]); o[3] = silu(o[3]); }
-                        *(f32x4*)(row + (wn * 64 + nt * 32 + 8 * gq + hi4) * 4) = o;
+                        for (int gq = 0; gq < 4; ++gq) {
+                            f32x4 o = {v[4 * gq] + bv[nt][gq][0], v[4 * gq + 1] + bv[nt][gq][1],
+                                       v[4 * gq + 2] + bv[nt][gq][2], v[4 * gq + 3] + bv[nt][gq][3]};
+                            if constexpr (RT) {
+                                if (a.epilogue == SVR_EPI_BIAS_SILU) { o[0] = silu(o[0]); o[1] = silu(o[1]); o[2] = silu(o[2]); o[3] = silu(o[3]); }
+                            }
+                            *(f32x4*)(row + (wn * 64 + nt * 32 + 8 * gq + hi4) * 4) = o;
+                        }
                     }
                 }
             }
-        }
-        __syncthreads();
+            SVR_EP_STAMP(1 + 3 * pass)                     // LDS writes issued
+            __syncthreads();
+            SVR_EP_STAMP(2 + 3 * pass)                     // barrier passed
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int id = it * NT + tid;
-            const int vox = id >> 4, ch = id & 15;        // voxel of the half patch, 8-cout chunk
-            const int y = y0 + pass * EP_ROWS + (vox >> 5), x = x0 + (vox & 31);
-            if (y >= g.H || x >= g.W) continue;
-            if constexpr ((DBG & 4) != 0) continue;
-            const int64_t m = ((int64_t)to * g.H + y) * g.W + x;
-            const int n = n0 + ch * 8;
-            const f32x4 lo = *(const f32x4*)(smem + vox * EP_PITCH + ch * 32);
-            const f32x4 hi_ = *(const f32x4*)(smem + vox * EP_PITCH + ch * 32 + 16);
-            float f[8] = {lo[0], lo[1], lo[2], lo[3], hi_[0], hi_[1], hi_[2], hi_[3]};
-            if (resid_gate) {
-                if (a.gate) {
+            for (int it = 0; it < 8; ++it) {
+                const int id = it * NT + tid;
+                const int vox = id >> 4, ch = id & 15;    // voxel of the half patch, 8-cout chunk
+                const int y = y0 + pass * EP_ROWS + (vox >> 5), x = x0 + (vox & 31);
+                if (y >= g.H || x >= g.W) continue;
+                if constexpr ((DBG & 4) != 0) continue;
+                const int64_t m = ((int64_t)to * g.H + y) * g.W + x;
+                const int n = n0 + ch * 8;
+                const f32x4 lo = *(const f32x4*)(smem + vox * EP_PITCH + ch * 32);
+                const f32x4 hi_ = *(const f32x4*)(smem + vox * EP_PITCH + ch * 32 + 16);
+                float f[8] = {lo[0], lo[1], lo[2], lo[3], hi_[0], hi_[1], hi_[2], hi_[3]};
+                bool add_resid = F_RESID;
+                if constexpr (RT) {
+                    if (resid_gate) {
+                        if (a.gate) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] *= a.gate[n + e];
+                            for (int e = 0; e < 8; ++e) f[e] *= a.gate[n + e];
+                        }
+                        add_resid = a.resid != nullptr;
+                    }
                 }
-                if (a.resid) {
+                if (add_resid) {
                     const uint4 rr8 = *(const uint4*)((const bf16_t*)a.resid + m * a.ldr + n);
                     float r8[8];
                     unpack8(rr8, r8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] += r8[e];
                 }
-            }
-            if (a.out_f32) {
-                float* cp = (float*)a.C + m * a.ldc + n;
-                *(float4*)cp = make_float4(f[0], f[1], f[2], f[3]);
-                *(float4*)(cp + 4) = make_float4(f[4], f[5], f[6], f[7]);
-            } else {
-                const uint4 pk = pack8(f);
-                *(uint4*)((bf16_t*)a.C + m * a.ldc + n) = pk;
-                if (a.gn_partial) {
-                    float r[8];
-                    unpack8(pk, r);
-                    gs0 += r[0] + r[1] + r[2] + r[3];
-                    gq0 += r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
-                    gs1 += r[4] + r[5] + r[6] + r[7];
-                    gq1 += r[4] * r[4] + r[5] * r[5] + r[6] * r[6] + r[7] * r[7];
+                if (RT && a.out_f32) {
+                    float* cp = (float*)a.C + m * a.ldc + n;
+                    *(float4*)cp = make_float4(f[0], f[1], f[2], f[3]);
+                    *(float4*)(cp + 4) = make_float4(f[4], f[5], f[6], f[7]);
+                } else {
+                    const uint4 pk = pack8(f);
+                    *(uint4*)((bf16_t*)a.C + m * a.ldc + n) = pk;
+                    if (RT ? a.gn_partial != nullptr : F_GN) {
+                        float r[8];
+                        unpack8(pk, r);
+                        gs0 += r[0] + r[1] + r[2] + r[3];
+                        gq0 += r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+                        gs1 += r[4] + r[5] + r[6] + r[7];
+                        gq1 += r[4] * r[4] + r[5] * r[5] + r[6] * r[6] + r[7] * r[7];
+                    }
                 }
             }
+            SVR_EP_STAMP(3 + 3 * pass)                     // stores issued
+            if (pass == 0) __syncthreads();
         }
-        if (pass == 0) __syncthreads();
+    };
+    if (a.epilogue != SVR_EPI_BIAS_SILU && !a.out_f32 && a.gate == nullptr) {
+        const int F = ((resid_gate && a.resid != nullptr) ? 1 : 0) | (a.gn_partial != nullptr ? 2 : 0);
+        if (F == 0) ep_body(std::integral_constant<int, 0>{});
+        else if (F == 1) ep_body(std::integral_constant<int, 1>{});
+        else if (F == 2) ep_body(std::integral_constant<int, 2>{});
+        else ep_body(std::integral_constant<int, 3>{});
+    } else {
+        ep_body(std::integral_constant<int, -1>{});
     }
     if (a.gn_partial) {                                   // fixed-order reduction: thread -> quad -> group
         __syncthreads();
@@ -574,8 +632,14 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             ((double2*)a.gn_partial)[((int64_t)to * nblk + blk) * a.gn_groups + (n0 >> 2) / qpg + tid] = make_double2(s, q);
         }
     }
+#ifdef SVR_ABLATIONS
+    if constexpr ((DBG & 256) != 0) {     // (no wait for the stores: when the last store has been ISSUED)
+        if (tid == 0 && blockIdx.x < 4096) g_conv_tl[blockIdx.x][3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
+int g_conv_no_stagger = [] { const char* e = getenv("SVR_CONV_NO_STAGGER"); return e ? atoi(e) : 0; }();
 int g_conv_lds_dbg = 0;    // measurement knob: dynamic LDS bytes to request (forces one workgroup per CU when > 80 KiB)
 static bool conv_halo2_wreg(const svr_gemm_args& a) { return a.W_frag != nullptr && g_conv_impl == 0; }
 
@@ -589,7 +653,9 @@ template <int TY, int MODE, int DBG = 0> static int launch_conv_halo2_t(const sv
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_halo2_kernel<TY, MODE, DBG>), dim3(tiles), dim3(G::NT), g_conv_lds_dbg > G::LDS ? g_conv_lds_dbg : G::LDS, s, a);
+    svr_gemm_args b = a;
+    b.ps.F = g_conv_no_stagger;                           // (ps is disabled for every geometry this kernel serves)
+    hipLaunchKernelGGL((conv_halo2_kernel<TY, MODE, DBG>), dim3(tiles), dim3(G::NT), g_conv_lds_dbg > G::LDS ? g_conv_lds_dbg : G::LDS, s, b);
     return (int)hipGetLastError();
 }
 
@@ -607,6 +673,7 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
         case 48: return launch_conv_halo2_t<8, 1, 48>(a, s);
         case 112: return launch_conv_halo2_t<8, 1, 112>(a, s);
         case 128: return launch_conv_halo2_t<8, 1, 128>(a, s);
+        case 256: return launch_conv_halo2_t<8, 1, 256>(a, s);
         default: break;
     }
 #endif
