@@ -492,19 +492,18 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
 #ifdef SVR_ABLATIONS
     if constexpr ((DBG & 256) != 0) { if (tid == 0 && blockIdx.x < 4096) g_conv_tl[blockIdx.x][2] = __builtin_amdgcn_s_memtime(); }
 #endif
-    // ---- epilogue through LDS, two passes of EP_ROWS patch rows (TY = 16: rows 0-7 are the waves with wm < 2, rows 8-15
-    // wm >= 2; TY = 8: one wave row per pass): the fp32 tile (+ bias) is parked in LDS [voxels][132 floats] and written back row-contiguous
+    // ---- epilogue through LDS, two passes of TY / 2 patch rows (every wave parks two of its four rows per pass): the fp32
+    // tile is parked in LDS [voxels][132 floats] and written back row-contiguous, bias / residual added on the way out
     // (16 lanes cover one voxel's 128 couts; every global access is a full 16-byte lane / 256-byte row).
     constexpr int EP_PITCH = 528;                         // 128 floats + 16 B pad: conflict-free b128 writes
     const int hi4 = hi * 4;
-    f32x4 bv[NTW][4];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int n = n0 + wn * 64 + nt * 32 + 8 * gq + hi4;
-            bv[nt][gq] = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    // bias of the 8 couts this thread stores (every store iteration has the same chunk tid & 15): loaded now, used after
+    // the first barrier -- the latency hides under the LDS write phase
+    f32x4 bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+        bias_lo = *(const f32x4*)(a.bias + n0 + (tid & 15) * 8);
+        bias_hi = *(const f32x4*)(a.bias + n0 + (tid & 15) * 8 + 4);
+    }
 #ifdef SVR_ABLATIONS
 #define SVR_EP_STAMP(i) if constexpr ((DBG & 256) != 0) { if (tid == 0 && blockIdx.x < 4096) g_conv_ep[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); }
 #else
@@ -515,8 +514,8 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
     // fused GroupNorm statistics of the stored (bf16-rounded) output: this thread always stores the same
     // 8-cout chunk (tid & 15), so it keeps two quad sums over its 16 voxels
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
-    constexpr int EP_ROWS = G::EP_ROWS, EP_WM = EP_ROWS / MTW;      // patch rows / wave rows per pass
-    static_assert(TY / EP_ROWS == 2 && EP_ROWS * 32 * 16 == 8 * NT, "two passes, eight store iterations each");
+    constexpr int EP_ROWS = G::EP_ROWS;                             // patch rows per pass
+    static_assert(TY / EP_ROWS == 2 && EP_ROWS * 32 * 16 == 8 * NT && MTW == 4, "two passes, eight store iterations each");
     // The body is instantiated once per option set of the production calls (bf16 output, no SiLU, no gate; residual and
     // fused statistics on / off) so that the loops carry no per-element option branches -- a taken scalar branch costs a
     // wave ~40 cycles of instruction refetch, and with one per LDS write / five per store iteration they made up a third
@@ -524,67 +523,81 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
     auto ep_body = [&](auto fc) {
         constexpr int F = decltype(fc)::value;
         constexpr bool RT = F < 0, F_RESID = !RT && (F & 1), F_GN = !RT && (F & 2);
+        const bool with_resid = RT ? (resid_gate && a.resid != nullptr) : F_RESID;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
-            if (wm / EP_WM == pass) {
+            // every wave parks two of its four rows per pass (all waves write in both passes): LDS slot row wm * 2 + j
+            // holds patch row wm * 4 + 2 * pass + j
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) {
-                    char* row = smem + (((wm % EP_WM) * MTW + mt) * 32 + l31) * EP_PITCH;
+            for (int j = 0; j < 2; ++j) {
+                char* row = smem + ((wm * 2 + j) * 32 + l31) * EP_PITCH;
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) {
-                        const f32x16_t v = acc[mt][nt];
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const f32x16_t v = acc[2 * pass + j][nt];
 #pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            f32x4 o = {v[4 * gq] + bv[nt][gq][0], v[4 * gq + 1] + bv[nt][gq][1],
-                                       v[4 * gq + 2] + bv[nt][gq][2], v[4 * gq + 3] + bv[nt][gq][3]};
-                            if constexpr (RT) {
-                                if (a.epilogue == SVR_EPI_BIAS_SILU) { o[0] = silu(o[0]); o[1] = silu(o[1]); o[2] = silu(o[2]); o[3] = silu(o[3]); }
-                            }
-                            *(f32x4*)(row + (wn * 64 + nt * 32 + 8 * gq + hi4) * 4) = o;
-                        }
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const f32x4 o = {v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
+                        *(f32x4*)(row + (wn * 64 + nt * 32 + 8 * gq + hi4) * 4) = o;
                     }
                 }
             }
             SVR_EP_STAMP(1 + 3 * pass)                     // LDS writes issued
             __syncthreads();
             SVR_EP_STAMP(2 + 3 * pass)                     // barrier passed
+            // store side, branch-free sweeps of four iterations so their LDS reads and residual loads are in flight
+            // together (out-of-image voxels read a clamped address and are masked at the store)
+            const int n = n0 + (tid & 15) * 8;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int id = it * NT + tid;
-                const int vox = id >> 4, ch = id & 15;    // voxel of the half patch, 8-cout chunk
-                const int y = y0 + pass * EP_ROWS + (vox >> 5), x = x0 + (vox & 31);
-                if (y >= g.H || x >= g.W) continue;
-                if constexpr ((DBG & 4) != 0) continue;
-                const int64_t m = ((int64_t)to * g.H + y) * g.W + x;
-                const int n = n0 + ch * 8;
-                const f32x4 lo = *(const f32x4*)(smem + vox * EP_PITCH + ch * 32);
-                const f32x4 hi_ = *(const f32x4*)(smem + vox * EP_PITCH + ch * 32 + 16);
-                float f[8] = {lo[0], lo[1], lo[2], lo[3], hi_[0], hi_[1], hi_[2], hi_[3]};
-                bool add_resid = F_RESID;
+            for (int half = 0; half < 2; ++half) {
+            f32x4 lo[4], hi_[4];
+            uint4 rr8[4];
+            int64_t mrow[4];
+            bool ok[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int vox = ((half * 4 + it) * NT + tid) >> 4;      // voxel slot of this pass
+                const int r = vox >> 5;
+                const int y = y0 + (r >> 1) * 4 + 2 * pass + (r & 1), x = x0 + (vox & 31);
+                ok[it] = y < g.H && x < g.W;
+                if constexpr ((DBG & 4) != 0) ok[it] = false;
+                mrow[it] = ((int64_t)to * g.H + min(y, g.H - 1)) * g.W + min(x, g.W - 1);
+                lo[it] = *(const f32x4*)(smem + vox * EP_PITCH + (tid & 15) * 32);
+                hi_[it] = *(const f32x4*)(smem + vox * EP_PITCH + (tid & 15) * 32 + 16);
+            }
+            if (with_resid) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) rr8[it] = *(const uint4*)((const bf16_t*)a.resid + mrow[it] * a.ldr + n);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                float f[8] = {lo[it][0] + bias_lo[0], lo[it][1] + bias_lo[1], lo[it][2] + bias_lo[2], lo[it][3] + bias_lo[3],
+                              hi_[it][0] + bias_hi[0], hi_[it][1] + bias_hi[1], hi_[it][2] + bias_hi[2], hi_[it][3] + bias_hi[3]};
                 if constexpr (RT) {
-                    if (resid_gate) {
-                        if (a.gate) {
+                    if (a.epilogue == SVR_EPI_BIAS_SILU) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] *= a.gate[n + e];
-                        }
-                        add_resid = a.resid != nullptr;
+                        for (int e = 0; e < 8; ++e) f[e] = silu(f[e]);
+                    }
+                    if (resid_gate && a.gate) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] *= a.gate[n + e];
                     }
                 }
-                if (add_resid) {
-                    const uint4 rr8 = *(const uint4*)((const bf16_t*)a.resid + m * a.ldr + n);
+                if (with_resid) {
                     float r8[8];
-                    unpack8(rr8, r8);
+                    unpack8(rr8[it], r8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] += r8[e];
                 }
                 if (RT && a.out_f32) {
-                    float* cp = (float*)a.C + m * a.ldc + n;
-                    *(float4*)cp = make_float4(f[0], f[1], f[2], f[3]);
-                    *(float4*)(cp + 4) = make_float4(f[4], f[5], f[6], f[7]);
+                    if (ok[it]) {
+                        float* cp = (float*)a.C + mrow[it] * a.ldc + n;
+                        *(float4*)cp = make_float4(f[0], f[1], f[2], f[3]);
+                        *(float4*)(cp + 4) = make_float4(f[4], f[5], f[6], f[7]);
+                    }
                 } else {
                     const uint4 pk = pack8(f);
-                    *(uint4*)((bf16_t*)a.C + m * a.ldc + n) = pk;
-                    if (RT ? a.gn_partial != nullptr : F_GN) {
+                    if (ok[it]) *(uint4*)((bf16_t*)a.C + mrow[it] * a.ldc + n) = pk;
+                    if ((RT ? a.gn_partial != nullptr : F_GN) && ok[it]) {
                         float r[8];
                         unpack8(pk, r);
                         gs0 += r[0] + r[1] + r[2] + r[3];
@@ -593,6 +606,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
                         gq1 += r[4] * r[4] + r[5] * r[5] + r[6] * r[6] + r[7] * r[7];
                     }
                 }
+            }
             }
             SVR_EP_STAMP(3 + 3 * pass)                     // stores issued
             if (pass == 0) __syncthreads();
