@@ -110,20 +110,6 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
     const int nA = g.kt * cpk;                            // A steps
     const int P = nA * 9;                                 // intervals
     const int64_t frame_bytes = (int64_t)g.H * g.W * g.Cin * 2;
-    // Phase stagger (two workgroups per CU).  All tiles of a launch take the same time, so without it every workgroup
-    // of the chip stays in lockstep with the first dispatch wave: the two workgroups of a CU reach their epilogues
-    // together (nothing overlaps them) and all 512 resident tiles store at the same instant (s_memtime: 24 k cycles per
-    // epilogue, 820 cycles per store iteration).  The workgroups of the first dispatch wave therefore start 0..7 eighths
-    // of a K loop late -- the two slots of a CU half a tile apart, neighbouring CUs 3/8 apart -- and later workgroups
-    // inherit the phase of the slot they take over.  (a.ps.F = 1 with the pixel shuffle disabled: measurement knob, off.)
-    if constexpr (MODE != 0) {
-        if (blockIdx.x < 512 && a.ps.F == 0) {
-            const int units = (((int)blockIdx.x >> 3) * 3 + ((int)blockIdx.x >> 8) * 4) & 7;
-            const int naps = (units * (THIN ? 16 : P)) / 43;          // one nap = s_sleep 100 = 6400 cycles; K loop = P * 1200
-            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(100);
-        }
-    }
-
     // ---- staging roles: one 16-byte chunk per thread and piece / unit (row = id >> 2, position = id & 3)
     const int srow = tid >> 2, spos = tid & 3;
     const char* wbase = (const char*)a.W + (int64_t)(n0 + srow) * a.K * 2 + ((spos ^ ((srow >> 2) & 3)) * 16);
@@ -653,7 +639,6 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
 #endif
 }
 
-int g_conv_no_stagger = [] { const char* e = getenv("SVR_CONV_NO_STAGGER"); return e ? atoi(e) : 0; }();
 int g_conv_lds_dbg = 0;    // measurement knob: dynamic LDS bytes to request (forces one workgroup per CU when > 80 KiB)
 static bool conv_halo2_wreg(const svr_gemm_args& a) { return a.W_frag != nullptr && g_conv_impl == 0; }
 
@@ -667,9 +652,7 @@ template <int TY, int MODE, int DBG = 0> static int launch_conv_halo2_t(const sv
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    svr_gemm_args b = a;
-    b.ps.F = g_conv_no_stagger;                           // (ps is disabled for every geometry this kernel serves)
-    hipLaunchKernelGGL((conv_halo2_kernel<TY, MODE, DBG>), dim3(tiles), dim3(G::NT), g_conv_lds_dbg > G::LDS ? g_conv_lds_dbg : G::LDS, s, b);
+    hipLaunchKernelGGL((conv_halo2_kernel<TY, MODE, DBG>), dim3(tiles), dim3(G::NT), g_conv_lds_dbg > G::LDS ? g_conv_lds_dbg : G::LDS, s, a);
     return (int)hipGetLastError();
 }
 
