@@ -282,8 +282,15 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
         // (vmcnt retires in issue order)
         auto wload = [&](bf16x8 (&w)[NTW][2], int k) {
             if constexpr ((DBG & 32) != 0) k &= 3;                  // measurement: weights always from the same 4 L1-hot units
-            const char* p0 = wp0 + (int64_t)min(k, P - 1) * 2048;     // (the last two intervals re-load the final unit)
-            const char* p1 = wp1 + (int64_t)min(k, P - 1) * 2048;
+            // (the last two intervals re-load the final unit; readfirstlane pins the wave-uniform addresses in SGPRs for
+            // the "s" constraints below -- it folds away wherever hipcc already proves them uniform)
+            auto uniform_ptr = [](const char* p) {
+                const uint64_t u = (uint64_t)p;
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+                return (const char*)(((uint64_t)hi << 32) | lo);
+            };
+            const char* p0 = uniform_ptr(wp0 + (int64_t)min(k, P - 1) * 2048);
+            const char* p1 = uniform_ptr(wp1 + (int64_t)min(k, P - 1) * 2048);
             if constexpr (DBG & 1) {
                 const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                 w[0][0] = z; w[0][1] = z; w[1][0] = z; w[1][1] = z;
