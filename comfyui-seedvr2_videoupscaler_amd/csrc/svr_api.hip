@@ -67,8 +67,8 @@ int32_t svr_gemm_gn_blocks(const svr_gemm_args* args) {
 
 int svr_groupnorm_reduce(const void* partial, double* stats, int32_t T, int32_t nblk, int32_t groups, void* stream) {
     if (T <= 0 || nblk <= 0) return 0;
-    if (groups <= 0 || groups > 32) return fail("svr_groupnorm_reduce: 1..32 groups");
-    hipLaunchKernelGGL(groupnorm_reduce_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream,
+    if (groups <= 0 || groups > 65535) return fail("svr_groupnorm_reduce: 1..65535 groups");
+    hipLaunchKernelGGL(groupnorm_reduce_kernel, dim3(T, groups), dim3(256), 0, (hipStream_t)stream,
                        (const double2*)partial, stats, (int)nblk, groups);
     return check(hipGetLastError(), "svr_groupnorm_reduce");
 }
@@ -186,7 +186,7 @@ int svr_groupnorm_stats(const void* x, double* stats, void* workspace, int32_t T
     const unsigned nblk = blocks_for(HW, GN_ROWS_PER_BLOCK);
     hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x, (double2*)workspace, HW, C, groups);
-    hipLaunchKernelGGL(groupnorm_reduce_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(groupnorm_reduce_kernel, dim3(T, groups), dim3(256), 0, (hipStream_t)stream,
                        (const double2*)workspace, stats, (int)nblk, groups);
     return check(hipGetLastError(), "svr_groupnorm_stats");
 }

@@ -251,26 +251,29 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
     }
 }
 
-// stats[t][g] = fixed-order sum of the nblk block partials.  One block per frame, 8 lanes per group.
+// stats[t][g] = fixed-order sum of the nblk block partials.  One 256-thread block per (frame, group): thread i adds the
+// partials i, i + 256, ... in order, then a fixed binary tree over the 256 threads in LDS -- the order depends only on
+// nblk, never on timing.  (This kernel sits between every fused conv and its GroupNorm apply with the rest of the GPU idle,
+// so it is built for latency: the 8-lanes-per-group version took 50 us at nblk = 4096.)
 __global__ __launch_bounds__(256) void groupnorm_reduce_kernel(const double2* __restrict__ partial, double* __restrict__ stats,
                                                                int nblk, int groups) {
-    const int t = blockIdx.x;
-    const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
+    __shared__ double2 red[256];
+    const int t = blockIdx.x, g = blockIdx.y, i = threadIdx.x;
     double s = 0.0, q = 0.0;
-    if (g < groups) {
-        for (int b = l; b < nblk; b += 8) {
-            const double2 v = partial[((int64_t)t * nblk + b) * groups + g];
-            s += v.x; q += v.y;
-        }
+    for (int b = i; b < nblk; b += 256) {
+        const double2 v = partial[((int64_t)t * nblk + b) * groups + g];
+        s += v.x; q += v.y;
     }
+    red[i] = make_double2(s, q);
+    __syncthreads();
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1) {               // fixed tree over the 8 lanes of a group
-        s += __shfl_down(s, o, 8);
-        q += __shfl_down(q, o, 8);
+    for (int o = 128; o > 0; o >>= 1) {
+        if (i < o) { red[i].x += red[i + o].x; red[i].y += red[i + o].y; }
+        __syncthreads();
     }
-    if (g < groups && l == 0) {
-        stats[((int64_t)t * groups + g) * 2] = s;
-        stats[((int64_t)t * groups + g) * 2 + 1] = q;
+    if (i == 0) {
+        stats[((int64_t)t * groups + g) * 2] = red[0].x;
+        stats[((int64_t)t * groups + g) * 2 + 1] = red[0].y;
     }
 }
 
