@@ -48,3 +48,37 @@ def test_vae_oracle_equals_reference_sliced():
     with torch.no_grad():
         assert rel_err(vae_oracle.encode(x, sd, cfg), ref.encode(x).latent) < 2e-5
         assert rel_err(vae_oracle.decode(z, sd, cfg), ref.decode(z).sample) < 2e-5
+
+
+def test_window_boxes_equal_reference_fuzz():
+    """Randomised sweep of the window planner against the reference's window.py (both families, several window counts)."""
+    import random
+    windows = sub("windows")
+    ref = rl.reference_window_module()
+    rnd = random.Random(1234)
+    for _ in range(150):
+        size = (rnd.randint(1, 40), rnd.randint(1, 140), rnd.randint(1, 250))
+        num = rnd.choice([(4, 3, 3), (1, 3, 3), (2, 2, 2), (4, 4, 4)])
+        for method, fn in ((windows.REGULAR, ref.make_720Pwindows_bysize),
+                           (windows.SHIFTED, ref.make_shifted_720Pwindows_bysize)):
+            want = [(a.start, a.stop, b.start, b.stop, c.start, c.stop) for a, b, c in fn(size, num)]
+            assert windows.window_boxes(size, num, method) == want, (size, num, method)
+
+
+def test_temporal_padding_and_blend_equal_reference_fuzz():
+    """pad_video_temporal / blend_overlapping_frames against the reference's function text over random lengths."""
+    import random
+    tr = sub("transforms")
+    ns = rl.reference_glue()
+    rnd = random.Random(7)
+    for _ in range(120):
+        t = rnd.randint(1, 23)
+        x = torch.randn(t, 2, 3, 3)
+        count = rnd.choice([0, 0, rnd.randint(1, 30)])
+        prepend = count > 0 and rnd.random() < 0.4
+        got = tr.pad_video_temporal(x, count=count, temporal_dim=0, prepend=prepend)
+        want = ns["pad_video_temporal"](x.clone(), count=count, temporal_dim=0, prepend=prepend)
+        assert got.shape == want.shape and torch.equal(got, want), (t, count, prepend)
+    for ov in range(1, 9):
+        a, b = torch.randn(ov, 4, 5, 3), torch.randn(ov, 4, 5, 3)
+        assert torch.equal(tr.blend_overlapping_frames(a, b, ov), ns["blend_overlapping_frames"](a.clone(), b.clone(), ov))
