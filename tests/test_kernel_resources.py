@@ -57,3 +57,18 @@ def test_no_kernel_uses_scratch(device_asm):
     """None of the library's kernels may spill: every one of them is bandwidth- or MFMA-bound by design."""
     bad = {k: v for k, v in _kernels(device_asm).items() if k.startswith("_ZN3svr") and v["private_segment_fixed_size"]}
     assert not bad, bad
+
+
+def test_measurement_build_compiles(tmp_path):
+    """The -DSVR_ABLATIONS build (measurement-only kernel variants behind svr_set_option("pipe_abl"), tools/conv_timeline.py)
+    must keep compiling: its variants instantiate the hand-written inline asm with different surrounding code."""
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    hip_lib = sub("hip_lib")
+    out = tmp_path / "libseedvr2_hip_abl.so"
+    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc"] + list(hip_lib.HIPCC_FLAGS) + \
+          ["-DSVR_ABLATIONS", os.path.join(hip_lib.CSRC, "svr_api.hip"), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    syms = subprocess.run(["nm", "-D", str(out)], capture_output=True, text=True).stdout
+    assert "svr_debug_conv_timeline" in syms and "svr_gemm_bf16" in syms
