@@ -206,23 +206,20 @@ class VideoVAEEngine:
         K = cw.w.shape[1]
         epi = EPI_RESID_GATE if resid is not None else EPI_BIAS
         stats = None
-        if cw.thin and cw.cin == 4 and tuple(cw.k[1:]) == (3, 3) and tuple(cw.stride) == (1, 1, 1) and K == 128 \
-                and cw.cout % 128 == 0 and (cw.pad_lo, cw.pad_hi) == (1, 1):
-            # RGB input (encoder conv_in): the fused thin-input kernel builds the im2col image of each patch in LDS
-            r = ops.gemm(x, cw.w, out, N=cw.cout, K=K, bias=cw.b, epilogue=epi, resid=resid, conv=geom,
-                         ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups if gn else 0)
-            stats = r[1] if gn else None
-        elif cw.thin:
+        fused_thin = (cw.thin and cw.cin == 4 and tuple(cw.k[1:]) == (3, 3) and tuple(cw.stride) == (1, 1, 1) and K == 128
+                      and cw.cout % 128 == 0 and (cw.pad_lo, cw.pad_hi) == (1, 1))
+        if cw.thin and not fused_thin:                      # decoder conv_in (Cin 16, latent resolution): im2col + plain GEMM
             cols = ops.empty(To * Ho * Wo, K)
             ops.im2col_causal(x, cols, geom)
             ops.gemm(cols, cw.w, out, N=cw.cout, K=K, M=To * Ho * Wo, bias=cw.b, epilogue=epi, resid=resid,
                      lda=K, ldc=cw.cout, ldr=cw.cout)
-        elif gn:
-            _, stats = ops.gemm(x, cw.w, out, N=cw.cout, K=K, bias=cw.b, epilogue=epi, resid=resid, conv=geom,
-                                ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups, W_frag=cw.w_frag)
         else:
-            ops.gemm(x, cw.w, out, N=cw.cout, K=K, bias=cw.b, epilogue=epi, resid=resid, conv=geom,
-                     ldc=cw.cout, ldr=cw.cout, W_frag=cw.w_frag)
+            # implicit-GEMM conv; RGB input (encoder conv_in, Cin 3 -> 4) is served by the thin-input variant of the
+            # LDS-halo kernel, which builds the im2col image of each patch in LDS
+            r = ops.gemm(x, cw.w, out, N=cw.cout, K=K, bias=cw.b, epilogue=epi, resid=resid, conv=geom,
+                         ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups if gn else 0,
+                         W_frag=None if cw.thin else cw.w_frag)
+            stats = r[1] if gn else None
         if carry > 0:                                       # per-conv memory for the next slice
             if T >= carry:
                 st[cw.name] = x[T - carry:].clone()
