@@ -9,6 +9,7 @@
 #include "svr_gemm_pipe.hip"
 #include "svr_conv_halo.hip"
 #include "svr_conv_halo2.hip"
+#include "svr_attn_win.hip"
 #include "svr_attn.hip"
 #include "svr_elementwise.hip"
 
@@ -38,6 +39,7 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "pipe_abl")) { g_pipe_abl = value; return 0; }
     if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
     if (!strcmp(key, "conv_lds")) { g_conv_lds_dbg = value; return 0; }
+    if (!strcmp(key, "attn_impl")) { g_attn_impl = value; return 0; }
     return fail("svr_set_option: unknown key");
 }
 

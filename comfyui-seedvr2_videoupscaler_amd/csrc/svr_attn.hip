@@ -18,6 +18,7 @@
 // transposing stores).
 #include "svr_common.h"
 #include "../../include/seedvr2_hip.h"
+#include <cstdlib>
 
 namespace svr {
 
@@ -239,12 +240,18 @@ static int launch_attn(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_ou
     return (int)hipGetLastError();
 }
 
+// svr_set_option("attn_impl", v): 0 auto (second-generation window kernel, svr_attn_win.hip, wherever it applies),
+// 1 = this file's kernel everywhere.  Used by A/B measurements and the kernel tests.
+int g_attn_impl = [] { const char* e = getenv("SVR_ATTN_IMPL"); return e ? atoi(e) : 0; }();
+
 int attn_dispatch(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,
                   const int32_t* out_rows, const int32_t* cu, int n_seq, int max_len, int heads, int head_dim,
                   float scale, hipStream_t s, const char** why) {
     *why = nullptr;
     if (n_seq <= 0 || max_len <= 0) return 0;
     if (n_seq > 65535 || heads > 65535) { *why = "svr_attn_varlen: grid too large"; return -1; }
+    if (head_dim == 128 && max_len <= AW_MAXL && g_attn_impl != 1)
+        return launch_attn_win(qkv, ld_qkv, out, ld_out, seq_rows, out_rows, cu, n_seq, max_len, heads, scale, s);
     if (head_dim == 128)
         return launch_attn<128, 2, 64>(qkv, ld_qkv, out, ld_out, seq_rows, out_rows, cu, n_seq, max_len, heads, scale, s);
     if (head_dim == 512)

@@ -1,0 +1,324 @@
+// Window attention of the NaDiT for gfx950, second generation (head_dim 128, windows of <= AW_MAXL rows).
+//
+// Replaces pytorch_varlen_attention (src/models/dit_3b/attention.py:27-64) + the window gather / text concat /
+// scatter around it (mmattn.py:199,245-264), like svr_attn.hip; that first kernel stays for head_dim 512 (VAE)
+// and for longer sequences.  What round 1's profile said about it (profiles/r1_cfg3_pmc_traffic.json): 18 % of the
+// MFMA peak, K/V fetched 5.5x from HBM, because (a) every 64-key tile was staged synchronously behind TWO dependent
+// global loads (row index, then the row) with two barriers per tile and nothing in flight meanwhile, (b) V went
+// through registers and 8-byte transposing LDS stores, (c) the q-tiles of one (window, head) were consecutive block
+// ids, i.e. round-robin over the 8 XCDs, so each private L2 fetched the window's K/V again.  Here:
+//
+//   * block = 4 waves x 32 queries (128-query tile), two workgroups per CU (72 KiB LDS, <= 256 registers);
+//   * the window's row indices are read ONCE into an LDS table, so the tile loop has no dependent global load;
+//   * K and V tiles (64 keys x 128 d, 16 KiB each) are double-buffered and BOTH filled by 16-byte LDS-DMA
+//     (global_load_lds) for tile t+1 while tile t is computed -- one barrier per tile, no VGPR staging;
+//   * v_mfma_f32_32x32x16_bf16 throughout, everything transposed so that softmax is lane-local:
+//       S^T[key, q] = K Q^T    A = K rows (ds_read_b128, chunk index XOR key&15 on the DMA source side: conflict-free),
+//                              B = Q held in registers; lane (q = lane&31, hi = lane>>5) gets keys (r&3)+8(r>>2)+4hi
+//       O^T[d,   q] = V^T P^T  B = P^T straight from the S^T accumulators (registers 8u..8u+7 of a 32-key block are
+//                              the 8 key slots of k-step u), A = V^T built by ds_read_b64_tr_b16 from the row-major V
+//                              tile: two transposing reads fetch exactly the two 4-key runs a lane's slots stand for
+//                              (keys 16u+4hi+{0..3} and +8), so P never crosses lanes and V is never transposed in
+//                              software.  V chunk index is XORed with (key&3)<<2 (source side) so that the 32 lanes of
+//                              a tr-read group (2 d-halves x 4 keys x 4 column quads) cover all 64 banks once;
+//   * the two halves of a query (lane, lane+32) exchange the running max with one v_permlane32_swap per tile and
+//     the row sum once; the bf16 output rows are widened to 16-byte stores with the same instruction;
+//   * block ids are remapped so that all q-tiles of a (window, head) pair -- and consecutive pairs -- run on ONE XCD:
+//     K/V of a pair is fetched from HBM once and re-read from that XCD's L2 by its other q-tiles.
+#include "svr_common.h"
+#include "../../include/seedvr2_hip.h"
+
+namespace svr {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int AW_D = 128;                        // head dim
+constexpr int AW_QB = 128;                       // queries per workgroup (4 waves x 32)
+constexpr int AW_KT = 64;                        // keys per tile
+constexpr int AW_MAXL = 2048;                    // longest window (rows incl. text) the LDS row table holds
+constexpr int AW_TILE = AW_KT * AW_D * 2;        // bytes of one K (or V) tile
+constexpr int AW_LDS = 4 * AW_TILE + AW_MAXL * 4;
+
+SVR_DEVICE float aw_other_half_max(float v) {    // max(v, value held by lane ^ 32)
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+SVR_DEVICE float aw_other_half_sum(float v) {
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
+// Eight transposing reads = the V^T fragments (A operands) of the four 32-d blocks for ONE 16-key k-step: rows OFF/256
+// .. + 3 and + 8 .. + 11 of the V tile.  Issued from inline asm so that (a) hipcc does not serialise them behind the
+// LDS-DMA of the next tile (it puts s_waitcnt vmcnt(0) in front of the ds_read_tr builtin, not in front of plain LDS
+// loads) and (b) the reads of k-step g+1 are in flight under the MFMAs of k-step g (the compiler's own schedule was
+// read -> wait -> MFMA, one read at a time).  hipcc does not count asm loads: aw_wait_lgkm<N> is the counted wait, it
+// names the destinations "+v" so no consumer can be scheduled above it (cdna_hip_programming.md 5.7 form (ii)).
+template <int OFF>
+SVR_DEVICE void aw_tr8(bf16x4 (&v)[8], unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %2, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %4, %10 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %6, %11 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %7, %11 offset:%13"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(OFF), "n"(OFF + 2048)
+        : "memory");
+}
+// Four K fragments (A operands of S^T = K Q^T) by ds_read_b128, same discipline.
+template <int OFF>
+SVR_DEVICE void aw_k4(bf16x8 (&k)[4], unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+    asm volatile(
+        "ds_read_b128 %0, %4 offset:%8\n\t"
+        "ds_read_b128 %1, %5 offset:%8\n\t"
+        "ds_read_b128 %2, %6 offset:%8\n\t"
+        "ds_read_b128 %3, %7 offset:%8"
+        : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3])
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(OFF)
+        : "memory");
+}
+template <int N>
+SVR_DEVICE void aw_wait_k(bf16x8 (&k)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]) : "n"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+SVR_DEVICE void aw_wait_lgkm(bf16x4 (&v)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 : "n"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_win_kernel(
+    const bf16_t* __restrict__ qkv, int64_t ld_qkv, bf16_t* __restrict__ out, int64_t ld_out,
+    const int32_t* __restrict__ seq_rows, const int32_t* __restrict__ out_rows, const int32_t* __restrict__ cu,
+    int heads, int n_pairs, int qt_per_pair, float scale_log2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* srow = (int*)(smem + 4 * AW_TILE);
+
+    // ---- work item: XCD x owns pairs x, x + 8, ...; the q-tiles of a pair are consecutive in its dispatch order
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int pair = (j / qt_per_pair) * 8 + xcd;
+    if (pair >= n_pairs) return;
+    const int seq = pair / heads, head = pair - seq * heads;
+    const int beg = cu[seq];
+    const int L = cu[seq + 1] - beg;
+    const int q0 = (j % qt_per_pair) * AW_QB;
+    if (q0 >= L) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nk = (L + AW_KT - 1) / AW_KT;
+
+    for (int i = tid; i < nk * AW_KT; i += 256) srow[i] = seq_rows[beg + min(i, L - 1)];
+    __syncthreads();
+
+    const int64_t ld_bytes = ld_qkv * 2;
+    const char* qbase = (const char*)qkv + (int64_t)head * (AW_D * 2);
+    const int64_t k_off = (int64_t)heads * (AW_D * 2), v_off = 2 * k_off;
+
+    // ---- LDS-DMA roles: wave instruction (it, wave) fills chunk positions (it*4 + wave)*64 + lane = 4 keys x 16 slots
+    const int st_key = wave * 4 + (lane >> 4);                       // key within the 16-key group of piece `it`
+    const int st_k = (((lane & 15) ^ st_key) << 4);                  // source chunk of K: slot ^ (key & 15)
+    const int st_v = (((lane & 15) ^ ((lane >> 4) << 2)) << 4);      // source chunk of V: slot ^ ((key & 3) << 2)
+    const char* nsrc[4];                                             // source rows of the NEXT tile to stage (this lane's 4 keys)
+    auto next_rows = [&](int t) {                                    // (plain LDS reads + 64-bit mads, waited for by hipcc right here)
+        const int tt = min(t, nk - 1);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) nsrc[it] = qbase + (int64_t)srow[tt * AW_KT + it * 16 + st_key] * ld_bytes;
+    };
+    auto stage_piece = [&](int it, int buf) {                        // 1 KiB of K and 1 KiB of V per wave instruction
+        glds16(nsrc[it] + k_off + st_k, smem + buf * AW_TILE + wave * 1024 + it * 4096);
+        glds16(nsrc[it] + v_off + st_v, smem + (2 + buf) * AW_TILE + wave * 1024 + it * 4096);
+    };
+    next_rows(0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) stage_piece(it, 0);
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = q0 + 32 wave + l31][16 ds + 8 hi .. + 8]
+    const int qpos = q0 + wave * 32 + l31;
+    bf16x8 qf[8];
+    {
+        const char* qp = qbase + (int64_t)srow[min(qpos, L - 1)] * ld_bytes + hi * 16;
+#pragma unroll
+        for (int ds = 0; ds < 8; ++ds) qf[ds] = *(const bf16x8*)(qp + ds * 32);
+    }
+    next_rows(1);
+
+    // ---- per-lane LDS byte addresses (buffer 0; the tile loop adds +-AW_TILE)
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    // K: row = key (32 kb + l31), 16-byte slot = (2 ds + hi) ^ (key & 15); kb = 1 is the +8192 immediate
+    unsigned ka_[8];
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) ka_[ds] = lds_base + l31 * 256 + (((2 * ds + hi) ^ (l31 & 15)) << 4);
+    // V (ds_read_b64_tr_b16): this lane supplies the address of key row jr (of its group's 4 keys), columns 4 c4 .. + 3 of
+    // the 16-d half G of 32-d block m; the instruction hands lane (G, i) the 4 keys of column i.  hi selects keys + 4.
+    const int i16 = lane & 15, G = (lane >> 4) & 1, jr = i16 >> 2, c4 = i16 & 3;
+    unsigned va_[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        va_[m] = lds_base + 2 * AW_TILE + hi * 1024 + jr * 256 + (((((m ^ jr) << 2) | (2 * G + (c4 >> 1))) << 4)) + (c4 & 1) * 8;
+
+    f32x16 o[4];
+    float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[m][r] = 0.f;
+
+    __syncthreads();                                   // tile 0 landed (vmcnt(0) + barrier)
+
+    for (int t = 0; t < nk; ++t) {
+        const int nxt = (t & 1) ^ 1;
+        const bool more = t + 1 < nk;                  // wave-uniform
+
+        // ---- S^T = K Q^T : 2 key blocks x 8 d-steps.  Fragment reads (asm, counted waits) run 4 k-steps ahead of the
+        //      MFMAs; the 8 LDS-DMA pieces of tile t+1 are issued between the MFMA groups, not as a burst.
+        f32x16 sacc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[0][r] = 0.f; sacc[1][r] = 0.f; }
+        bf16x8 kA[4], kB[4];
+        bf16x4 vA[8], vB[8];
+        aw_k4<0>(kA, ka_[0], ka_[1], ka_[2], ka_[3]);
+        aw_k4<0>(kB, ka_[4], ka_[5], ka_[6], ka_[7]);
+        aw_wait_k<4>(kA);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[e], qf[e], sacc[0], 0, 0, 0);
+        if (more) stage_piece(0, nxt);
+        aw_k4<8192>(kA, ka_[0], ka_[1], ka_[2], ka_[3]);
+        aw_wait_k<4>(kB);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kB[e], qf[4 + e], sacc[0], 0, 0, 0);
+        if (more) stage_piece(1, nxt);
+        aw_k4<8192>(kB, ka_[4], ka_[5], ka_[6], ka_[7]);
+        aw_wait_k<4>(kA);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[e], qf[e], sacc[1], 0, 0, 0);
+        if (more) stage_piece(2, nxt);
+        aw_tr8<0>(vA, va_[0], va_[1], va_[2], va_[3]);         // V^T fragments of the first k-step fly under the softmax
+        aw_wait_k<8>(kB);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kB[e], qf[4 + e], sacc[1], 0, 0, 0);
+        if (more) stage_piece(3, nxt);
+
+        // ---- online softmax, lane-local over this lane's 32 keys; the other 32 keys of the tile live in lane ^ 32
+        if ((t + 1) * AW_KT > L) {                     // ragged last tile (wave-uniform): mask keys >= L
+            const int kbase = t * AW_KT + 4 * hi;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= L) sacc[kb][r] = -INFINITY;
+        }
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+        mx = aw_other_half_max(mx);
+        const float m_new = fmaxf(m_run, mx);          // finite: every tile holds at least one valid key
+        const float mc = m_new * scale_log2;
+        const float alpha = fast_exp2(m_run * scale_log2 - mc);
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float p[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    p[e] = fast_exp2(fmaf(sacc[kb][8 * u + e], scale_log2, -mc));
+                    psum += p[e];
+                }
+                const uint4 pk = pack8(p);
+                pf[kb][u] = __builtin_bit_cast(bf16x8, pk);
+            }
+        l_run = l_run * alpha + psum;
+        if (!__all(alpha == 1.0f)) {                   // wave-uniform: no running max moved -> nothing to rescale (exact)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
+        }
+
+        // ---- O^T += V^T P^T : 4 k-steps (16 keys each) x 4 d blocks; the reads of k-step g+1 fly under the MFMAs of g
+#define AW_PV(V, KB, U)                                                                                            \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                              \
+            const bf16x8 vf = __builtin_shufflevector(V[2 * m], V[2 * m + 1], 0, 1, 2, 3, 4, 5, 6, 7);               \
+            o[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[KB][U], o[m], 0, 0, 0);                            \
+        }
+        aw_tr8<4096>(vB, va_[0], va_[1], va_[2], va_[3]);
+        aw_wait_lgkm<8>(vA);
+        AW_PV(vA, 0, 0)
+        aw_tr8<8192>(vA, va_[0], va_[1], va_[2], va_[3]);
+        aw_wait_lgkm<8>(vB);
+        AW_PV(vB, 0, 1)
+        aw_tr8<12288>(vB, va_[0], va_[1], va_[2], va_[3]);
+        aw_wait_lgkm<8>(vA);
+        AW_PV(vA, 1, 0)
+        aw_wait_lgkm<0>(vB);
+        AW_PV(vB, 1, 1)
+#undef AW_PV
+        next_rows(t + 2);                              // (after the last counted wait: hipcc's own lgkmcnt(0) here is harmless)
+        const int flip = (t & 1) ? -AW_TILE : AW_TILE;   // the other buffer of the K pair / V pair
+#pragma unroll
+        for (int ds = 0; ds < 8; ++ds) ka_[ds] += flip;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) va_[m] += flip;
+        __syncthreads();                               // tile t+1 landed (vmcnt(0)); everyone is done reading this tile's buffers
+    }
+
+    // ---- normalise and scatter.  Lane (q, hi) holds O[q][32 m + 8 rq + 4 hi + 0..3] in o[m][4 rq .. 4 rq + 3]
+    const float l = aw_other_half_sum(l_run);
+    const float inv = 1.0f / l;
+    const bool valid = qpos < L;
+    const int orow = valid ? out_rows[beg + qpos] : 0;
+    char* op = (char*)out + ((int64_t)orow * ld_out + (int64_t)head * AW_D) * 2 + hi * 16;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rq = 0; rq < 4; rq += 2) {
+            uint32_t ax = pack2bf(o[m][4 * rq + 0] * inv, o[m][4 * rq + 1] * inv);
+            uint32_t ay = pack2bf(o[m][4 * rq + 2] * inv, o[m][4 * rq + 3] * inv);
+            uint32_t bx = pack2bf(o[m][4 * rq + 4] * inv, o[m][4 * rq + 5] * inv);
+            uint32_t by = pack2bf(o[m][4 * rq + 6] * inv, o[m][4 * rq + 7] * inv);
+            // half exchange: lower lanes end up with d = 32 m + 8 rq + 0..7, upper lanes with 32 m + 8 (rq + 1) + 0..7
+            const u32x2 sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const u32x2 sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            if (valid) *(uint4*)(op + (32 * m + 8 * rq) * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+}
+
+static int launch_attn_win(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,
+                           const int32_t* out_rows, const int32_t* cu, int n_seq, int max_len, int heads, float scale,
+                           hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_win_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AW_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int qt = (max_len + AW_QB - 1) / AW_QB;
+    const int64_t n_pairs = (int64_t)n_seq * heads;
+    const int64_t blocks = 8 * ((n_pairs + 7) / 8) * qt;
+    if (blocks > 0x7fffffff) return -2;
+    hipLaunchKernelGGL(attn_win_kernel, dim3((unsigned)blocks), dim3(256), AW_LDS, s, (const bf16_t*)qkv, ld_qkv,
+                       (bf16_t*)out, ld_out, seq_rows, out_rows, cu, heads, (int)n_pairs, qt,
+                       scale * 1.4426950408889634f);
+    return (int)hipGetLastError();
+}
+
+}  // namespace svr

@@ -11,6 +11,15 @@ Fixtures (all tensors small; weights are NOT stored -- they are regenerated from
   dit7b_tiny.pt       DIT_7B_TINY forward (the dit_7b model code), latent 3x24x40
   dit3b_cfg1.pt       full SeedVR2-3B forward, latent 1x32x32    (BASELINE config 1 shape)
   vae_small.pt        full VAE encode/decode of a 5x64x96 clip, untiled and tiled (32x48 / 16)
+Round-2 fixtures at production width / headline geometry (``--only r2`` regenerates just these; the inputs are NOT
+stored -- tests rebuild them with the seeded helpers below, which use only exact elementwise arithmetic):
+  dit3b_w4l_crop.pt   SeedVR2-3B WIDTH (2560, 20 heads), 4 layers (2 MM + 2 shared, last vid-only) on a cropped
+                      BASELINE config-3 grid: latent 9x60x108 -> 9x30x54 tokens; windows 3x15x27 = the config-3
+                      window, 12 regular + 36 shifted windows with ragged edges (77 .. 1215 video rows)
+  vae_tiled17.pt      full VAE, 17 frames 96x160, tiled 64/32 px: 2x4 tiles + the skipped-tile rule on both axes,
+                      5 temporal slices through the reference's causal memory (split 4)
+  vae_tile1024.pt     full VAE at the REAL tile size: 5 frames 1024x1152 (latent 2x128x144), tiled 1024/128 ->
+                      a 2-tile strip with the 128-px cosine blend; encode stored whole, decode as 8 crops
 """
 import argparse
 import importlib
@@ -38,6 +47,29 @@ def dit_inputs(T, H, W, seed):
     return _bf16_values(torch.cat([noise, cond], dim=-1))
 
 
+def dit_r2_config(config):
+    """3B width, 4 layers: blocks 0-1 separate vid/txt weights, 2-3 shared, block 3 video-only MLP."""
+    return config.DiTConfig(num_layers=4, mm_layers=2)
+
+
+def blocky_frames(T, H, W, seed, cell=16):
+    """Frames in [-1, 1] with large-scale structure (nearest-upsampled low-res noise) plus fine noise; only exact
+    elementwise ops, so the bf16 values are identical on every machine."""
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.rand(3, T, (H + cell - 1) // cell, (W + cell - 1) // cell, generator=g) * 1.6 - 0.8
+    x = lo.repeat_interleave(cell, dim=2).repeat_interleave(cell, dim=3)[:, :, :H, :W]
+    x = x + (torch.rand(3, T, H, W, generator=g) - 0.5) * 0.25
+    return _bf16_values(x.clamp(-1, 1))[None]                       # [1, 3, T, H, W]
+
+
+def latent_input(T, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    return _bf16_values(torch.randn(1, 16, T, H, W, generator=g))
+
+
+CROPS_1024 = [(0, 0), (0, 1056), (928, 0), (464, 832), (464, 960), (100, 896), (928, 1056), (512, 300)]   # (y, x) of 96x96 crops; x 896..1024 is the blend seam
+
+
 def run_reference_dit(rl, cfg, sd, vid, txt):
     ref = rl.build_reference_dit(cfg.as_dict(), {k: v.float() for k, v in sd.items()})
     T, H, W, C = vid.shape
@@ -51,7 +83,10 @@ def run_reference_dit(rl, cfg, sd, vid, txt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-3b", action="store_true")
+    ap.add_argument("--only", default="", help="'r2': only the round-2 fixtures; 'r2-dit' / 'r2-vae17' / 'r2-vae1024': one of them")
     args = ap.parse_args()
+    if args.only:
+        return main_r2(args.only)
     from oracle import reference_loader as rl
     assert rl.available(), "needs /root/reference"
     config = importlib.import_module(PKG + ".config")
@@ -114,6 +149,58 @@ def main():
                 "tile_size": (32, 48), "tile_overlap": (16, 16), "seed_weights": weights.SEED_WEIGHTS + 1},
                os.path.join(GOLD, "vae_small.pt"))
     print("vae_small enc", tuple(enc.shape), "dec", tuple(dec.shape))
+
+
+def main_r2(which):
+    from oracle import reference_loader as rl
+    assert rl.available(), "needs /root/reference"
+    config = importlib.import_module(PKG + ".config")
+    weights = importlib.import_module(PKG + ".weights")
+    txt = torch.load(os.path.join(GOLD, "text_pos_emb.pt"), weights_only=True)
+    if which in ("r2", "r2-dit"):
+        cfg = dit_r2_config(config)
+        sd = weights.synth_dit_state_dict(cfg)
+        vid = dit_inputs(9, 60, 108, seed=44)
+        t0 = time.time()
+        out = run_reference_dit(rl, cfg, sd, vid, txt)
+        print("dit3b_w4l_crop reference fp32 forward %.0fs" % (time.time() - t0), tuple(out.shape), float(out.std()))
+        torch.save({"out": out, "latent": (9, 60, 108), "seed_input": 44, "seed_weights": weights.SEED_WEIGHTS},
+                   os.path.join(GOLD, "dit3b_w4l_crop.pt"))
+        del sd
+    if which in ("r2", "r2-vae17", "r2-vae1024"):
+        vcfg = config.VAE_V3
+        sd = weights.synth_vae_state_dict(vcfg)
+        ref = rl.build_reference_vae({k: v.float() for k, v in sd.items()})
+    if which in ("r2", "r2-vae17"):
+        x = blocky_frames(17, 96, 160, seed=45, cell=8)
+        z = latent_input(5, 12, 20, seed=46)
+        tile = dict(tiled=True, tile_size=(64, 64), tile_overlap=(32, 32))
+        t0 = time.time()
+        with torch.no_grad():
+            enc = ref.encode(x.float(), **tile).latent
+            dec = ref.decode(z.float(), **tile).sample
+        print("vae_tiled17 %.0fs" % (time.time() - t0), tuple(enc.shape), tuple(dec.shape))
+        torch.save({"enc_tiled": enc.clone(), "dec_tiled": dec.clone(), "frames": (17, 96, 160), "latent": (5, 12, 20), "seed_x": 45,
+                    "seed_z": 46, "cell": 8, "tile_size": (64, 64), "tile_overlap": (32, 32),
+                    "seed_weights": weights.SEED_WEIGHTS + 1}, os.path.join(GOLD, "vae_tiled17.pt"))
+    if which in ("r2", "r2-vae1024"):
+        x = blocky_frames(5, 1024, 1152, seed=47, cell=32)
+        z = latent_input(2, 128, 144, seed=48)
+        tile = dict(tiled=True, tile_size=(1024, 1024), tile_overlap=(128, 128))
+        t0 = time.time()
+        with torch.no_grad():
+            enc = ref.encode(x.float(), **tile).latent
+        print("vae_tile1024 encode %.0fs" % (time.time() - t0), tuple(enc.shape))
+        t0 = time.time()
+        with torch.no_grad():
+            dec = ref.decode(z.float(), **tile).sample
+        print("vae_tile1024 decode %.0fs" % (time.time() - t0), tuple(dec.shape))
+        crops = torch.stack([dec[0, :, :, y:y + 96, xx:xx + 96] for (y, xx) in CROPS_1024])
+        torch.save({"enc_tiled": enc.clone(), "dec_crops": crops, "crops": CROPS_1024, "dec_mean": float(dec.mean()),
+                    "dec_std": float(dec.std()), "dec_min": float(dec.min()), "dec_max": float(dec.max()),
+                    "frames": (5, 1024, 1152), "latent": (2, 128, 144), "seed_x": 47, "seed_z": 48, "cell": 32,
+                    "tile_size": (1024, 1024), "tile_overlap": (128, 128), "seed_weights": weights.SEED_WEIGHTS + 1},
+                   os.path.join(GOLD, "vae_tile1024.pt"))
 
 
 if __name__ == "__main__":

@@ -108,6 +108,12 @@ def test_gemm_epilogues(hip, ref):
         hip.gemm(A, W, out, N=N, K=K, bias=bias, epilogue=epi, **kw)
         want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias, epilogue=epi, **kw)
         assert rel_err(out.float(), want) < TOL_BF16, epi
+    # fp32-store test epilogue: the north star's 1e-3 bound, per fused epilogue (same inputs, no output rounding)
+    for epi, kw in ((EPI_BIAS_SILU, {}), (EPI_BIAS_GELU, {}), (EPI_RESID_GATE, dict(gate=gate, resid=resid))):
+        out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+        hip.gemm(A, W, out, N=N, K=K, bias=bias, epilogue=epi, out_f32=True, **kw)
+        want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias, epilogue=epi, **kw)
+        assert rel_err(out, want) < TOL_F32, epi
     # in-place residual (C aliases resid), row-sliced views as the DiT uses them
     buf = rnd(M + 58, N, seed=6)
     want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE,
@@ -128,6 +134,9 @@ def test_gemm_swiglu(hip, ref):
     hip.gemm(A, W, out, N=2 * Hd, K=K, epilogue=EPI_SWIGLU)
     want = torch.nn.functional.silu(A.float() @ wg.float().t()) * (A.float() @ wi.float().t())
     assert rel_err(out.float(), want) < TOL_BF16
+    out32 = torch.empty(M, Hd, device="cuda", dtype=torch.float32)                 # fp32-store test epilogue: 1e-3
+    hip.gemm(A, W, out32, N=2 * Hd, K=K, epilogue=EPI_SWIGLU, out_f32=True)
+    assert rel_err(out32, want) < TOL_F32
     # and the reference double agrees with the closed form (keeps the two test backends honest)
     w2 = ref.gemm(A, W, torch.empty(M, Hd, device="cuda"), N=2 * Hd, K=K, epilogue=EPI_SWIGLU)
     assert rel_err(w2, want) < 1e-5
@@ -169,7 +178,16 @@ def test_conv3d_implicit_gemm(hip, ref, case, conv_impl):
         hip.set_option("conv_impl", 0)
 
 
-def _conv_case(hip, ref, case, frag=False):
+@pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[9], CONV_CASES[10], CONV_CASES[3], CONV_CASES[7]],
+                         ids=["halo_small", "halo_carried_head", "halo_ragged_patches", "halo_256_128", "generic_stride2", "thin_out"])
+@pytest.mark.parametrize("frag", [False, True], ids=["lds_weights", "wreg"])
+def test_conv3d_fp32_store_1e3(hip, ref, case, frag):
+    """The 1e-3 contract (fp32-store test epilogue, bias + residual fused) for the conv kernels that carry the VAE:
+    LDS-halo kernel with LDS-staged and with register-streamed weights, the generic strided kernel, the thin-output one."""
+    _conv_case(hip, ref, case, frag=frag, out_f32=True)
+
+
+def _conv_case(hip, ref, case, frag=False, out_f32=False):
     packing, opsmod = sub("packing"), sub("ops")
     Cin, Cout, k, stride, (plo, phi), T, H, W, hf = case
     kt, kh, kw = k
@@ -184,10 +202,10 @@ def _conv_case(hip, ref, case, frag=False):
     Wo = (W + plo + phi - kw) // stride[2] + 1
     geom = opsmod.Conv3dGeom(T, H, W, Cin, To, Ho, Wo, k, stride, (pt, plo, plo), halo)
     resid = rnd(To, Ho, Wo, Cout, seed=11)
-    out = torch.empty(To, Ho, Wo, Cout, device="cuda", dtype=BF16)
+    out = torch.empty(To, Ho, Wo, Cout, device="cuda", dtype=torch.float32 if out_f32 else BF16)
     Wf = hip.pack_conv_frag(Wp, kt, Cin, Cout) if frag and (kh, kw) == (3, 3) else None
     hip.gemm(x, Wp, out, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, epilogue=EPI_RESID_GATE, resid=resid,
-             ldc=Cout, ldr=Cout, W_frag=Wf)
+             ldc=Cout, ldr=Cout, W_frag=Wf, out_f32=out_f32)
     want = ref.gemm(x, Wp, torch.empty(To, Ho, Wo, Cout, device="cuda"), N=Cout, K=Wp.shape[1], bias=bias,
                     conv=geom, epilogue=EPI_RESID_GATE, resid=resid)
     # independent check of the reference double itself against F.conv3d semantics of the causal conv
@@ -196,7 +214,7 @@ def _conv_case(hip, ref, case, frag=False):
     xin = torch.nn.functional.pad(xin, (plo, phi, plo, phi))
     y = torch.nn.functional.conv3d(xin, w5.float(), bias, stride=stride)[0].permute(1, 2, 3, 0) + resid.float()
     assert rel_err(want, y) < 1e-5
-    assert rel_err(out.float(), want) < TOL_BF16
+    assert rel_err(out.float(), want) < (TOL_F32 if out_f32 else TOL_BF16)
 
 
 def test_conv3d_halo_kernel_race_screen_and_generic_agreement(hip):
@@ -382,22 +400,65 @@ def _attn_case(lens, heads, D, n_rows, seed=0):
     return to(seq_rows), to(out_rows), torch.tensor(cu, dtype=torch.int32).cuda(), o
 
 
+@pytest.fixture(params=[0, 1], ids=["attn_win", "attn_gen1"])
+def attn_impl(request, hip):
+    """Both window-attention kernels stay parity-green: 0 = second-generation kernel (svr_attn_win.hip) wherever it
+    applies (head_dim 128, windows <= 2048 rows), 1 = the first kernel everywhere."""
+    hip.set_option("attn_impl", request.param)
+    yield request.param
+    hip.set_option("attn_impl", 0)
+
+
 @pytest.mark.parametrize("lens,heads,D", [([135, 64, 1, 200, 129, 1273], 3, 128), ([314], 20, 128),
-                                          ([100, 33, 257], 1, 512)])
-def test_attn_varlen(hip, ref, lens, heads, D):
+                                          ([100, 33, 257], 1, 512),
+                                          # tile-boundary lengths (64-key tiles, 128-query tiles), 1- and 2-row windows
+                                          ([64, 128, 192, 63, 65, 127, 129, 2, 1, 256], 2, 128),
+                                          # (window, head) pairs not a multiple of the 8 XCDs; longest window the LDS row table holds
+                                          ([2048, 77, 1215, 640], 5, 128),
+                                          # one row more than the table: served by the first kernel whatever attn_impl says
+                                          ([2049, 300], 1, 128)])
+def test_attn_varlen(hip, ref, attn_impl, lens, heads, D):
     n_rows = 1500
     qkv = rnd(n_rows, 3 * heads * D)
     seq_rows, out_rows, cu, total = _attn_case(lens, heads, D, n_rows)
     scale = 1.0 / math.sqrt(D)
-    out = torch.zeros(total, heads * D, device="cuda", dtype=BF16)
+    out = torch.full((total, heads * D), float("nan"), device="cuda", dtype=BF16)     # every row must be written
     hip.attn_varlen(qkv, out, seq_rows, out_rows, cu, max(lens), heads, D, scale)
     want = ref.attn_varlen(qkv, torch.zeros(total, heads * D, device="cuda"), seq_rows, out_rows, cu, max(lens),
                            heads, D, scale)
     assert rel_err(out.float(), want) < 4e-3       # P is rounded to bf16 before PV (as flash kernels do)
+    # race screen: the double-buffered LDS pipeline must be deterministic
+    for _ in range(3):
+        again = torch.zeros_like(out)
+        hip.attn_varlen(qkv, again, seq_rows, out_rows, cu, max(lens), heads, D, scale)
+        assert torch.equal(again, out)
 
 
-def test_attn_varlen_spiky_scores(hip, ref):
-    """Forces the online-softmax rescale: one key dominates late in the sequence."""
+def test_attn_varlen_scattered_output_rows(hip, ref, attn_impl):
+    """Window-ordered gather AND scatter through distinct index vectors (text rows go to a scratch tail), output rows
+    that no window owns stay untouched."""
+    heads, D, n_rows = 4, 128, 3000
+    lens = [700, 411, 1273, 90]
+    qkv = rnd(n_rows, 3 * heads * D, seed=3)
+    g = torch.Generator().manual_seed(11)
+    perm = torch.randperm(n_rows, generator=g)
+    total = sum(lens)
+    seq_rows = perm[:total].to(torch.int32).cuda()
+    out_rows = torch.randperm(total + 500, generator=g)[:total].to(torch.int32).cuda()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32).cuda()
+    out = torch.full((total + 500, heads * D), 7.0, device="cuda", dtype=BF16)
+    hip.attn_varlen(qkv, out, seq_rows, out_rows, cu, max(lens), heads, D, 1.0 / math.sqrt(D))
+    want = ref.attn_varlen(qkv, torch.full((total + 500, heads * D), 7.0, device="cuda"), seq_rows, out_rows, cu,
+                           max(lens), heads, D, 1.0 / math.sqrt(D))
+    assert rel_err(out.float(), want) < 4e-3
+    untouched = torch.ones(total + 500, dtype=torch.bool, device="cuda")
+    untouched[out_rows.long()] = False
+    assert bool((out[untouched] == 7.0).all())
+
+
+def test_attn_varlen_spiky_scores(hip, ref, attn_impl):
+    """Forces the online-softmax rescale: one key dominates late in the sequence (and, for the second-generation kernel,
+    the wave-uniform skip of the rescale when no running max moved is exercised by the tiles after it)."""
     heads, D, L = 2, 128, 400
     qkv = rnd(L, 3 * heads * D, scale=0.5)
     qkv[300, heads * D:2 * heads * D] = qkv[5, :heads * D] * 8          # k[300] aligned with q[5]
@@ -406,6 +467,22 @@ def test_attn_varlen_spiky_scores(hip, ref):
     out = torch.zeros(L, heads * D, device="cuda", dtype=BF16)
     hip.attn_varlen(qkv, out, rows, rows, cu, L, heads, D, 1.0 / math.sqrt(D))
     want = ref.attn_varlen(qkv, torch.zeros(L, heads * D, device="cuda"), rows, rows, cu, L, heads, D, 1.0 / math.sqrt(D))
+    assert rel_err(out.float(), want) < 4e-3
+    assert rel_err(out[5].float(), want[5]) < 4e-3                      # the row whose max jumps at key 300
+
+
+def test_attn_varlen_constant_scores_skip_rescale(hip, ref, attn_impl):
+    """All keys identical -> every score of a row is equal, the running max never moves after the first tile, so the
+    second-generation kernel takes its no-rescale branch on every later tile; the output must equal v (uniform
+    attention over identical values would hide an error, so V differs per key: out = mean(v))."""
+    heads, D, L = 1, 128, 640
+    qkv = rnd(L, 3 * heads * D, seed=5)
+    qkv[:, D:2 * D] = qkv[0, D:2 * D]
+    rows = torch.arange(L, dtype=torch.int32, device="cuda")
+    cu = torch.tensor([0, L], dtype=torch.int32, device="cuda")
+    out = torch.zeros(L, D, device="cuda", dtype=BF16)
+    hip.attn_varlen(qkv, out, rows, rows, cu, L, heads, D, 1.0 / math.sqrt(D))
+    want = qkv[:, 2 * D:].float().mean(0, keepdim=True).expand(L, D)
     assert rel_err(out.float(), want) < 4e-3
 
 

@@ -6,7 +6,9 @@ Tolerances (stated contract): the reference's own bf16 pa
 fp32 self by rel-err 1.66e-2 (DiT-3B) and 1.6e-2 / 2.3e-2 (VAE encode / decode), so "1e-3 end to end"
 is below the storage-format noise floor.  We require, against the fp32 reference outputs:
   * DiT: rel-err <= 2.0e-2 and PSNR >= 50 dB;   * VAE: rel-err <= 2.5e-2 and PSNR >= 50 dB
-with PSNR measured against the reference output's own range (max - min).
+with PSNR measured against the reference output's own range (max - min) for latents / DiT predictions, and
+against the NOMINAL range 2.0 of clamped [-1, 1] frames for decoded pixels (``psnr_nominal``).
+Round-2 tests (production width, multi-window, multi-tile, real tile size) assert measured x 1.5.
 """
 import math
 import os
@@ -24,6 +26,13 @@ def psnr(a, b):
     rng = float(b.max() - b.min())
     mse = float((a.double() - b.double()).pow(2).mean())
     return 10 * math.log10(rng * rng / max(mse, 1e-30))
+
+
+def psnr_nominal(a, b, peak=2.0):
+    """PSNR of decoded frames against the nominal range of clamped [-1, 1] output (peak 2.0), SURVEY.md 7(ii).  With
+    random-initialised weights the decoder's output spans about [-3.5, 3] (std 0.58), so this is the stricter measure."""
+    mse = float((a.double() - b.double()).pow(2).mean())
+    return 10 * math.log10(peak * peak / max(mse, 1e-30))
 
 
 @pytest.fixture(scope="module")
@@ -69,6 +78,31 @@ def test_dit_3b_cfg1_vs_reference_golden(hip):
     assert e < 2.0e-2 and p > 50
 
 
+def test_dit_3b_width_multiwindow_vs_reference_golden(hip):
+    """Production WIDTH (2560, 20 heads x 128) on a cropped BASELINE config-3 token grid 9x30x54: the config-3 window
+    (3x15x27 = 1215 video rows + 58 text rows), 12 regular + 36 shifted windows with ragged edges (77 .. 1215 rows),
+    2 MM + 2 shared blocks, last block video-only; golden from the imported reference (fp32).  Both window-attention
+    kernels.  Measured on MI355X: see the printed values; bound = measured x 1.5."""
+    from oracle import make_golden as mg
+    config, weights, dit = sub("config"), sub("weights"), sub("dit")
+    g, txt = _golden("dit3b_w4l_crop.pt"), _golden("text_pos_emb.pt")
+    cfg = mg.dit_r2_config(config)
+    eng = dit.NaDiTEngine(cfg, weights.synth_dit_state_dict(cfg, seed=g["seed_weights"]), hip)
+    vid = mg.dit_inputs(*g["latent"], seed=g["seed_input"]).cuda()
+    outs = {}
+    for impl in (0, 1):
+        hip.set_option("attn_impl", impl)
+        try:
+            out = eng.forward(vid, txt.cuda(), 1000.0).float().cpu()
+        finally:
+            hip.set_option("attn_impl", 0)
+        e, p = rel_err(out, g["out"]), psnr(out, g["out"])
+        print(f"DiT 3B-width 4 layers, 48 windows, attn_impl={impl}: rel-err {e:.3e}, PSNR {p:.1f} dB")
+        assert e < 6e-3 and p > 60, (impl, e, p)      # 4 layers: well under the 32-layer budget of 2e-2
+        outs[impl] = out
+    assert rel_err(outs[0], outs[1]) < 4e-3
+
+
 def test_dit_runner_euler_endpoint(hip):
     """runner.inference == x_t - dit(x_t || cond) (one-step Euler endpoint fused into un-patchify)."""
     config, weights, dit, runner = sub("config"), sub("weights"), sub("dit"), sub("runner")
@@ -102,6 +136,59 @@ def test_vae_vs_reference_golden(hip, tiled):
     e, p = rel_err(y, want), psnr(y, want)
     print(f"VAE decode tiled={tiled}: rel-err {e:.3e}, PSNR {p:.1f} dB")
     assert e < 2.5e-2 and p > 50
+
+
+def test_vae_17_frames_multitile_vs_reference_golden(hip):
+    """17 frames (5 temporal slices in the reference's split-4 scheme; here one slice AND forced 4-frame slices),
+    2x4 spatial tiles with the skipped-tile rule exercised on both axes; golden from the imported reference."""
+    from oracle import make_golden as mg
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    g = _golden("vae_tiled17.pt")
+    cfg = config.VAE_V3
+    eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg, seed=g["seed_weights"]), hip)
+    kw = dict(tiled=True, tile_size=tuple(g["tile_size"]), tile_overlap=tuple(g["tile_overlap"]))
+    x = mg.blocky_frames(*g["frames"], seed=g["seed_x"], cell=g["cell"])[0].cuda()
+    want = g["enc_tiled"][0].permute(1, 2, 3, 0) * cfg.scaling_factor
+    lat = eng.encode(x, **kw)
+    assert torch.equal(lat, eng.encode(x, frames_per_slice=4, **kw))                 # slicing is bit-invisible
+    e, p = rel_err(lat.float().cpu(), want), psnr(lat.float().cpu(), want)
+    print(f"VAE encode 17 frames, 2x4 tiles: rel-err {e:.3e}, PSNR {p:.1f} dB")
+    assert e < 2.5e-2 and p > 50
+    z = (mg.latent_input(*g["latent"], seed=g["seed_z"])[0].permute(1, 2, 3, 0).float() * cfg.scaling_factor).to(BF16).cuda()
+    y = eng.decode(z, **kw)
+    assert torch.equal(y, eng.decode(z, latents_per_slice=1, **kw))
+    y = y.float().cpu()
+    e, p, pn = rel_err(y, g["dec_tiled"][0]), psnr(y, g["dec_tiled"][0]), psnr_nominal(y, g["dec_tiled"][0])
+    print(f"VAE decode 17 frames, 2x4 tiles: rel-err {e:.3e}, PSNR {p:.1f} dB (own range), {pn:.1f} dB (nominal peak 2.0)")
+    assert e < 2.5e-2 and p > 50 and pn > 44
+
+
+def test_vae_real_tile_size_strip_vs_reference_golden(hip):
+    """The headline tile geometry: 5 frames 1024x1152 = a 2-tile strip at tile 1024 / overlap 128 (what BASELINE config 3
+    runs 15 times per batch), golden from the imported reference (fp32, 9 min of CPU): encode compared whole, decode on 8
+    96x96 crops incl. the blend seam (x 896..1024), corners and tile interiors."""
+    from oracle import make_golden as mg
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    g = _golden("vae_tile1024.pt")
+    cfg = config.VAE_V3
+    eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg, seed=g["seed_weights"]), hip)
+    kw = dict(tiled=True, tile_size=tuple(g["tile_size"]), tile_overlap=tuple(g["tile_overlap"]))
+    x = mg.blocky_frames(*g["frames"], seed=g["seed_x"], cell=g["cell"])[0].cuda()
+    lat = eng.encode(x, **kw).float().cpu()
+    want = g["enc_tiled"][0].permute(1, 2, 3, 0) * cfg.scaling_factor
+    e, p = rel_err(lat, want), psnr(lat, want)
+    print(f"VAE encode 1024-px tiles (2-tile strip): rel-err {e:.3e}, PSNR {p:.1f} dB")
+    assert e < 2.5e-2 and p > 50
+    del x
+    z = (mg.latent_input(*g["latent"], seed=g["seed_z"])[0].permute(1, 2, 3, 0).float() * cfg.scaling_factor).to(BF16).cuda()
+    y = eng.decode(z, **kw).float().cpu()                                            # [3, 5, 1024, 1152]
+    assert y.shape == (3, 5, 1024, 1152)
+    got = torch.stack([y[:, :, yy:yy + 96, xx:xx + 96] for (yy, xx) in g["crops"]])
+    e, p, pn = rel_err(got, g["dec_crops"]), psnr(got, g["dec_crops"]), psnr_nominal(got, g["dec_crops"])
+    print(f"VAE decode 1024-px tiles (2-tile strip, 8 crops): rel-err {e:.3e}, PSNR {p:.1f} dB (own range), "
+          f"{pn:.1f} dB (nominal peak 2.0)")
+    assert e < 2.5e-2 and p > 50 and pn > 44
+    assert abs(float(y.mean()) - g["dec_mean"]) < 5e-3 and abs(float(y.std()) - g["dec_std"]) < 5e-3
 
 
 def test_vae_temporal_slicing_invariance(hip):

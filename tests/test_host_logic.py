@@ -73,6 +73,21 @@ def test_vae_engine_encode_decode_slicing_tiling(vae_setup):
     assert rel_err(eng.decode(z, latents_per_slice=1, **tile), g["dec_tiled"][0]) < 2e-5
 
 
+def test_vae_engine_17_frames_tiled_golden(vae_setup):
+    """Round-2 fixture: 17 frames, 2x4 tiles + skipped tiles, the engine slicing at 4 frames / 1 latent like the reference
+    and at its own budget-derived slice length."""
+    from oracle import make_golden as mg
+    cfg, sd, eng = vae_setup
+    g = torch.load(os.path.join(GOLDEN, "vae_tiled17.pt"), weights_only=True)
+    tile = dict(tiled=True, tile_size=tuple(g["tile_size"]), tile_overlap=tuple(g["tile_overlap"]))
+    x = mg.blocky_frames(*g["frames"], seed=g["seed_x"], cell=g["cell"])[0].float()
+    z = mg.latent_input(*g["latent"], seed=g["seed_z"])[0].permute(1, 2, 3, 0).float() * cfg.scaling_factor
+    want_e = g["enc_tiled"][0].permute(1, 2, 3, 0) * cfg.scaling_factor
+    assert rel_err(eng.encode(x, frames_per_slice=4, **tile), want_e) < 2e-5
+    assert rel_err(eng.encode(x, **tile), want_e) < 2e-5
+    assert rel_err(eng.decode(z, latents_per_slice=1, **tile), g["dec_tiled"][0]) < 2e-5
+
+
 def test_vae_engine_multi_slice_equals_oracle(vae_setup):
     cfg, sd, eng = vae_setup
     torch.manual_seed(0)

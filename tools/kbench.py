@@ -112,10 +112,13 @@ def main():
             qkv = rnd(N + Lt, 3 * heads * 128)
             att = ops.empty(N + Lt + plan.n_win * Lt, heads * 128)
             t_seq, t_out, t_cu = (torch.from_numpy(v).to(dev) for v in (seq, outr, cu))
-            sec = timeit(lambda: ops.attn_varlen(qkv, att, t_seq, t_out, t_cu, int(lens.max()) + Lt, heads, 128,
-                                                 1 / math.sqrt(128)), args.reps)
             fl = sum(4.0 * heads * 128 * float(l + Lt) ** 2 for l in lens)
-            report(f"attn window {method} ({plan.n_win} windows)", sec, flops=fl)
+            for impl, tag in ((0, "gen2 svr_attn_win"), (1, "gen1 svr_attn")):
+                ops.set_option("attn_impl", impl)
+                sec = timeit(lambda: ops.attn_varlen(qkv, att, t_seq, t_out, t_cu, int(lens.max()) + Lt, heads, 128,
+                                                     1 / math.sqrt(128)), args.reps)
+                report(f"attn window {method} ({plan.n_win} windows) [{tag}]", sec, flops=fl)
+            ops.set_option("attn_impl", 0)
             del qkv, att
         # VAE mid-block attention on one 1024-px tile: 9 frames x (128*128) tokens, 1 head of 512
         T, n, Cc = 9, 128 * 128, 512
