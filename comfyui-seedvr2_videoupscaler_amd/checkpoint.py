@@ -14,7 +14,8 @@ and the dtype handling around them for the formats the hot path supports:
     causal_inflation_lib.py:440-457): "tail" puts the 2D kernel in the last temporal tap, "replicate"
     spreads it / depth;
   * RoPE ``freqs`` buffers missing from a checkpoint are zero-filled like the reference's meta-buffer
-    initialisation (model_loader.py:777-815), with a warning.
+    initialisation (model_loader.py:777-815), with a warning;
+  * both model families: SeedVR2-3B and -7B (dit_7b) checkpoints are told apart by their tensors.
 
 GGUF (llama.cpp block-quantised) checkpoints are a small-VRAM format and out of scope.
 The engines then pre-tile for the MFMA kernels (packing.py).  Registry names: model_registry.py:34-57.
@@ -25,7 +26,7 @@ from typing import Dict, Iterable, Optional, Tuple
 
 import torch
 
-from .config import DIT_3B, VAE_V3, DiTConfig, VAEConfig
+from .config import DIT_3B, DIT_7B, VAE_V3, DiTConfig, VAEConfig
 
 DEFAULT_DIT = "seedvr2_ema_3b_fp8_e4m3fn.safetensors"      # model_registry.py:56
 DEFAULT_VAE = "ema_vae_fp16.safetensors"
@@ -112,6 +113,20 @@ def dit_expected_keys(cfg: DiTConfig = DIT_3B) -> Iterable[str]:
     return weights.synth_dit_state_dict(DiTConfig(**{**cfg.as_dict(), "vid_dim": 128, "heads": 1, "txt_in_dim": 64})).keys()
 
 
+def detect_dit_config(sd: Dict[str, torch.Tensor], name: str = "") -> DiTConfig:
+    """SeedVR2-3B or -7B from the tensors themselves (model_registry.py:34-57 keys the choice on the file name; the
+    shapes are the safer witness): the 7B family has biased GELU MLPs (``mlp.*.proj_in.bias``) and width 3072."""
+    w = sd.get("vid_in.proj.weight", sd.get("model.diffusion_model.vid_in.proj.weight"))
+    has_mlp_bias = any(k.endswith("mlp.vid.proj_in.bias") for k in sd)
+    if (w is not None and w.shape[0] == DIT_7B.vid_dim) or has_mlp_bias:
+        return DIT_7B
+    if w is not None and w.shape[0] == DIT_3B.vid_dim:
+        return DIT_3B
+    if w is None and "7b" in name.lower():
+        return DIT_7B
+    return DIT_3B
+
+
 def prepare_dit_state_dict(sd: Dict[str, torch.Tensor], cfg: DiTConfig = DIT_3B) -> Dict[str, torch.Tensor]:
     sd = to_compute_dtype(sd)
     # ComfyUI-style exports may carry a "model.diffusion_model." prefix (model_loader.py:156-160 handles it for GGUF)
@@ -122,34 +137,39 @@ def prepare_dit_state_dict(sd: Dict[str, torch.Tensor], cfg: DiTConfig = DIT_3B)
     for k in list(missing):
         if k.endswith("rope.rope.freqs"):
             warnings.warn(f"{k} missing from the checkpoint: zero-filled (reference behaviour for meta buffers)")
-            n_freq = (cfg.head_dim // 3) // 2
-            sd[k] = torch.zeros(n_freq, dtype=torch.float32)
+            sd[k] = torch.zeros(cfg.rope_freqs, dtype=torch.float32)      # 3B: 21 per axis, 7B: 10 (config.DiTConfig.rope_freqs)
             missing.remove(k)
     if missing:
         raise KeyError(f"DiT checkpoint is missing {len(missing)} tensors, e.g. {missing[:5]}")
     return sd
 
 
-def prepare_vae_state_dict(sd: Dict[str, torch.Tensor], cfg: VAEConfig = VAE_V3, inflation_mode: str = "tail") -> Dict[str, torch.Tensor]:
+def vae_expected_keys(cfg: VAEConfig = VAE_V3) -> Iterable[str]:
+    """Key set of the real architecture (incl. the 1x1x1 ``conv_shortcut`` of every resnet whose width changes), built
+    on the meta device: shapes only, no memory."""
     from . import weights
+    return weights.synth_vae_state_dict(cfg, device="meta").keys()
+
+
+def prepare_vae_state_dict(sd: Dict[str, torch.Tensor], cfg: VAEConfig = VAE_V3, inflation_mode: str = "tail") -> Dict[str, torch.Tensor]:
     sd = inflate_vae_state_dict(to_compute_dtype(sd), cfg, inflation_mode)
-    expected = weights.synth_vae_state_dict(VAEConfig(**{**cfg.__dict__, "block_out_channels": (32, 32, 32, 32)})).keys()
-    missing = [k for k in expected if k not in sd]
+    missing = [k for k in vae_expected_keys(cfg) if k not in sd]
     if missing:
         raise KeyError(f"VAE checkpoint is missing {len(missing)} tensors, e.g. {missing[:5]}")
     return sd
 
 
 def build_engines(ops, dit_path: Optional[str] = None, vae_path: Optional[str] = None,
-                  dit_cfg: DiTConfig = DIT_3B, vae_cfg: VAEConfig = VAE_V3) -> Tuple[object, object]:
-    """(NaDiTEngine | None, VideoVAEEngine | None) from checkpoint files, weights resident in HBM."""
+                  dit_cfg: Optional[DiTConfig] = None, vae_cfg: VAEConfig = VAE_V3) -> Tuple[object, object]:
+    """(NaDiTEngine | None, VideoVAEEngine | None) from checkpoint files, weights resident in HBM.  ``dit_cfg`` None:
+    SeedVR2-3B or -7B is detected from the checkpoint's tensors (detect_dit_config)."""
     from .dit import NaDiTEngine
     from .vae import VideoVAEEngine
     dit = vae = None
     if dit_path:
-        if "7b" in os.path.basename(dit_path).lower():
-            raise NotImplementedError("the 7B NaDiT variant is a later row (DESIGN.md section 7)")
-        dit = NaDiTEngine(dit_cfg, prepare_dit_state_dict(load_state_dict(dit_path), dit_cfg), ops)
+        sd = load_state_dict(dit_path)
+        cfg = dit_cfg or detect_dit_config(sd, os.path.basename(dit_path))
+        dit = NaDiTEngine(cfg, prepare_dit_state_dict(sd, cfg), ops)
     if vae_path:
         vae = VideoVAEEngine(vae_cfg, prepare_vae_state_dict(load_state_dict(vae_path), vae_cfg), ops)
     return dit, vae

@@ -2,7 +2,7 @@
 (omegaconf is not available here; values cited per key).
 
   configs_3b/main.yaml:11-36            -> DIT_3B
-  configs_7b/main.yaml:11-33            -> DIT_7B (shape constants only; 7B path is a later row)
+  configs_7b/main.yaml:11-33            -> DIT_7B
   video_vae_v3/s8_c16_t4_inflation_sd3.yaml, configs_3b/main.yaml:45-63 -> VAE_V3
 """
 from dataclasses import dataclass, field, asdict

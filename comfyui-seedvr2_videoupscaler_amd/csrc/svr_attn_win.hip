@@ -27,6 +27,7 @@
 //     K/V of a pair is fetched from HBM once and re-read from that XCD's L2 by its other q-tiles.
 #include "svr_common.h"
 #include "../../include/seedvr2_hip.h"
+#include <cstdlib>
 
 namespace svr {
 
@@ -35,21 +36,32 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 constexpr int AW_D = 128;                        // head dim
-constexpr int AW_QB = 128;                       // queries per workgroup (4 waves x 32)
 constexpr int AW_KT = 64;                        // keys per tile
 constexpr int AW_MAXL = 2048;                    // longest window (rows incl. text) the LDS row table holds
 constexpr int AW_TILE = AW_KT * AW_D * 2;        // bytes of one K (or V) tile
 constexpr int AW_LDS = 4 * AW_TILE + AW_MAXL * 4;
 
+// v_permlane32_swap_b32 vdst, src exchanges lanes 32-63 of vdst with lanes 0-31 of src.  Fed the same value in both
+// operands, one of the two results is this lane's own value and the other the value of lane ^ 32 -- in BOTH halves.
+// NOTE: the two results are copied into scalars before any __builtin_bit_cast: bit-casting the vector-element lvalue
+// r[1] directly reads element 0 (clang 22 / ROCm 7.2: found on the GPU as a 17 % error, each half of a query
+// normalising with its own max and sum; the -O0 IR shows both loads at offset 0).
+SVR_DEVICE void aw_swap_halves(float v, float& own_or_other, float& other_or_own) {
+    const unsigned a = __builtin_bit_cast(unsigned, v);
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    const unsigned r0 = r.x, r1 = r.y;
+    own_or_other = __builtin_bit_cast(float, r0);
+    other_or_own = __builtin_bit_cast(float, r1);
+}
 SVR_DEVICE float aw_other_half_max(float v) {    // max(v, value held by lane ^ 32)
-    const unsigned b = __builtin_bit_cast(unsigned, v);
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    float a, b;
+    aw_swap_halves(v, a, b);
+    return fmaxf(a, b);
 }
 SVR_DEVICE float aw_other_half_sum(float v) {
-    const unsigned b = __builtin_bit_cast(unsigned, v);
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    float a, b;
+    aw_swap_halves(v, a, b);
+    return a + b;
 }
 
 // Eight transposing reads = the V^T fragments (A operands) of the four 32-d blocks for ONE 16-key k-step: rows OFF/256
@@ -98,7 +110,10 @@ SVR_DEVICE void aw_wait_lgkm(bf16x4 (&v)[8]) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ __launch_bounds__(256, 2) void attn_win_kernel(
+// NW: waves per workgroup (4: 128-query tiles, two workgroups per CU; 8: 256-query tiles, one workgroup per CU -- half the
+// LDS-DMA instructions and L2->LDS bytes per MFMA, coarser tiles for ragged windows).  PRIO: s_setprio 1 around MFMA groups.
+template <int NW, bool PRIO>
+__global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld_qkv, bf16_t* __restrict__ out, int64_t ld_out,
     const int32_t* __restrict__ seq_rows, const int32_t* __restrict__ out_rows, const int32_t* __restrict__ cu,
     int heads, int n_pairs, int qt_per_pair, float scale_log2) {
@@ -113,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void attn_win_kernel(
     const int seq = pair / heads, head = pair - seq * heads;
     const int beg = cu[seq];
     const int L = cu[seq + 1] - beg;
+    constexpr int AW_QB = NW * 32, NP = 16 / NW;      // queries per workgroup; LDS-DMA pieces (1 KiB of K + 1 KiB of V) per wave per tile
     const int q0 = (j % qt_per_pair) * AW_QB;
     if (q0 >= L) return;
 
@@ -121,30 +137,30 @@ __global__ __launch_bounds__(256, 2) void attn_win_kernel(
     const int l31 = lane & 31, hi = lane >> 5;
     const int nk = (L + AW_KT - 1) / AW_KT;
 
-    for (int i = tid; i < nk * AW_KT; i += 256) srow[i] = seq_rows[beg + min(i, L - 1)];
+    for (int i = tid; i < nk * AW_KT; i += NW * 64) srow[i] = seq_rows[beg + min(i, L - 1)];
     __syncthreads();
 
     const int64_t ld_bytes = ld_qkv * 2;
     const char* qbase = (const char*)qkv + (int64_t)head * (AW_D * 2);
     const int64_t k_off = (int64_t)heads * (AW_D * 2), v_off = 2 * k_off;
 
-    // ---- LDS-DMA roles: wave instruction (it, wave) fills chunk positions (it*4 + wave)*64 + lane = 4 keys x 16 slots
-    const int st_key = wave * 4 + (lane >> 4);                       // key within the 16-key group of piece `it`
-    const int st_k = (((lane & 15) ^ st_key) << 4);                  // source chunk of K: slot ^ (key & 15)
+    // ---- LDS-DMA roles: wave instruction (it, wave) fills chunk positions (it*NW + wave)*64 + lane = 4 keys x 16 slots
+    const int st_key = wave * 4 + (lane >> 4);                       // key within the (4 NW)-key group of piece `it`
+    const int st_k = (((lane & 15) ^ (st_key & 15)) << 4);           // source chunk of K: slot ^ (key & 15)
     const int st_v = (((lane & 15) ^ ((lane >> 4) << 2)) << 4);      // source chunk of V: slot ^ ((key & 3) << 2)
-    const char* nsrc[4];                                             // source rows of the NEXT tile to stage (this lane's 4 keys)
+    const char* nsrc[NP];                                            // source rows of the NEXT tile to stage (this lane's NP keys)
     auto next_rows = [&](int t) {                                    // (plain LDS reads + 64-bit mads, waited for by hipcc right here)
         const int tt = min(t, nk - 1);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) nsrc[it] = qbase + (int64_t)srow[tt * AW_KT + it * 16 + st_key] * ld_bytes;
+        for (int it = 0; it < NP; ++it) nsrc[it] = qbase + (int64_t)srow[tt * AW_KT + it * (4 * NW) + st_key] * ld_bytes;
     };
     auto stage_piece = [&](int it, int buf) {                        // 1 KiB of K and 1 KiB of V per wave instruction
-        glds16(nsrc[it] + k_off + st_k, smem + buf * AW_TILE + wave * 1024 + it * 4096);
-        glds16(nsrc[it] + v_off + st_v, smem + (2 + buf) * AW_TILE + wave * 1024 + it * 4096);
+        glds16(nsrc[it] + k_off + st_k, smem + buf * AW_TILE + wave * 1024 + it * (NW * 1024));
+        glds16(nsrc[it] + v_off + st_v, smem + (2 + buf) * AW_TILE + wave * 1024 + it * (NW * 1024));
     };
     next_rows(0);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) stage_piece(it, 0);
+    for (int it = 0; it < NP; ++it) stage_piece(it, 0);
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = q0 + 32 wave + l31][16 ds + 8 hi .. + 8]
     const int qpos = q0 + wave * 32 + l31;
@@ -192,25 +208,27 @@ __global__ __launch_bounds__(256, 2) void attn_win_kernel(
         bf16x4 vA[8], vB[8];
         aw_k4<0>(kA, ka_[0], ka_[1], ka_[2], ka_[3]);
         aw_k4<0>(kB, ka_[4], ka_[5], ka_[6], ka_[7]);
+#define AW_QK(K, Q0, S)                                                                                               \
+        if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                 \
+            sacc[S] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(K[e], qf[Q0 + e], sacc[S], 0, 0, 0);                    \
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         aw_wait_k<4>(kA);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[e], qf[e], sacc[0], 0, 0, 0);
+        AW_QK(kA, 0, 0)
         if (more) stage_piece(0, nxt);
         aw_k4<8192>(kA, ka_[0], ka_[1], ka_[2], ka_[3]);
         aw_wait_k<4>(kB);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kB[e], qf[4 + e], sacc[0], 0, 0, 0);
-        if (more) stage_piece(1, nxt);
+        AW_QK(kB, 4, 0)
+        if (more && NP == 4) stage_piece(1, nxt);
         aw_k4<8192>(kB, ka_[4], ka_[5], ka_[6], ka_[7]);
         aw_wait_k<4>(kA);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kA[e], qf[e], sacc[1], 0, 0, 0);
-        if (more) stage_piece(2, nxt);
+        AW_QK(kA, 0, 1)
+        if (more) stage_piece(NP == 4 ? 2 : 1, nxt);
         aw_tr8<0>(vA, va_[0], va_[1], va_[2], va_[3]);         // V^T fragments of the first k-step fly under the softmax
         aw_wait_k<8>(kB);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kB[e], qf[4 + e], sacc[1], 0, 0, 0);
-        if (more) stage_piece(3, nxt);
+        AW_QK(kB, 4, 1)
+        if (more && NP == 4) stage_piece(3, nxt);
+#undef AW_QK
 
         // ---- online softmax, lane-local over this lane's 32 keys; the other 32 keys of the tile live in lane ^ 32
         if ((t + 1) * AW_KT > L) {                     // ragged last tile (wave-uniform): mask keys >= L
@@ -256,10 +274,12 @@ __global__ __launch_bounds__(256, 2) void attn_win_kernel(
 
         // ---- O^T += V^T P^T : 4 k-steps (16 keys each) x 4 d blocks; the reads of k-step g+1 fly under the MFMAs of g
 #define AW_PV(V, KB, U)                                                                                            \
+        if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                     \
         _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                              \
             const bf16x8 vf = __builtin_shufflevector(V[2 * m], V[2 * m + 1], 0, 1, 2, 3, 4, 5, 6, 7);               \
             o[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[KB][U], o[m], 0, 0, 0);                            \
-        }
+        }                                                                                                            \
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         aw_tr8<4096>(vB, va_[0], va_[1], va_[2], va_[3]);
         aw_wait_lgkm<8>(vA);
         AW_PV(vA, 0, 0)
@@ -302,23 +322,42 @@ __global__ __launch_bounds__(256, 2) void attn_win_kernel(
         }
 }
 
-static int launch_attn_win(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,
-                           const int32_t* out_rows, const int32_t* cu, int n_seq, int max_len, int heads, float scale,
-                           hipStream_t s) {
+// svr_set_option("attn_variant", v): 0 = 4 waves, 1 = 4 waves + s_setprio, 2 = 8 waves, 3 = 8 waves + s_setprio (A/B knob)
+int g_attn_variant = [] { const char* e = getenv("SVR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
+
+template <int NW, bool PRIO>
+static int launch_attn_win_t(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,
+                             const int32_t* out_rows, const int32_t* cu, int n_seq, int max_len, int heads, float scale,
+                             hipStream_t s) {
+    auto kern = attn_win_kernel<NW, PRIO>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_win_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AW_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AW_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int qt = (max_len + AW_QB - 1) / AW_QB;
+    constexpr int QB = NW * 32;
+    const int qt = (max_len + QB - 1) / QB;
     const int64_t n_pairs = (int64_t)n_seq * heads;
     const int64_t blocks = 8 * ((n_pairs + 7) / 8) * qt;
     if (blocks > 0x7fffffff) return -2;
-    hipLaunchKernelGGL(attn_win_kernel, dim3((unsigned)blocks), dim3(256), AW_LDS, s, (const bf16_t*)qkv, ld_qkv,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), AW_LDS, s, (const bf16_t*)qkv, ld_qkv,
                        (bf16_t*)out, ld_out, seq_rows, out_rows, cu, heads, (int)n_pairs, qt,
                        scale * 1.4426950408889634f);
     return (int)hipGetLastError();
+}
+
+static int launch_attn_win(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,
+                           const int32_t* out_rows, const int32_t* cu, int n_seq, int max_len, int heads, float scale,
+                           hipStream_t s) {
+#define AW_ARGS qkv, ld_qkv, out, ld_out, seq_rows, out_rows, cu, n_seq, max_len, heads, scale, s
+    switch (g_attn_variant) {
+        case 1: return launch_attn_win_t<4, true>(AW_ARGS);
+        case 2: return launch_attn_win_t<8, false>(AW_ARGS);
+        case 3: return launch_attn_win_t<8, true>(AW_ARGS);
+        default: return launch_attn_win_t<4, false>(AW_ARGS);
+    }
+#undef AW_ARGS
 }
 
 }  // namespace svr

@@ -49,15 +49,33 @@ def plan_batches(total_frames: int, batch_size: int, temporal_overlap: int = 0,
     return plans, temporal_overlap
 
 
-def prepare_batch(images_thwc: torch.Tensor, plan: BatchPlan, resolution: int, max_resolution: int = 0) -> torch.Tensor:
-    """frames [start, end) -> uniform padding -> 4n+1 padding -> input transform: [3, T', H', W'] in [-1, 1]."""
+def prepare_batch(images_thwc: torch.Tensor, plan: BatchPlan, resolution: int, max_resolution: int = 0,
+                  dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """frames [start, end) -> uniform padding -> 4n+1 padding -> input transform: [3, T', H', W'] in [-1, 1].
+    ``dtype``: cast the frames BEFORE padding / resizing, as phase 1 of the reference does (the batch goes to the
+    compute dtype at generation_phases.py:377-385, so its resize result, clamp, pad and normalise are rounded to bf16
+    step by step); phase 4 re-transforms the input in its own dtype (generation_phases.py:127-168) -> ``None``."""
     video = images_thwc[plan.start:plan.end]
+    if dtype is not None:
+        video = video.to(dtype)
     if plan.uniform_pad > 0:
         video = transforms.pad_video_temporal(video, count=plan.uniform_pad, temporal_dim=0, prepend=False)
     video = video.permute(0, 3, 1, 2)                                    # T C H W
     if video.size(0) % 4 != 1:
         video = transforms.pad_video_temporal(video, temporal_dim=0, prepend=False)
     return transforms.video_transform(video[:, :3], resolution, max_resolution)
+
+
+def transformed_shape(images_thwc: torch.Tensor, plan: BatchPlan, resolution: int, max_resolution: int = 0) -> Tuple[int, ...]:
+    """Shape of prepare_batch()'s result without computing it: [3, T', H', W']."""
+    t = plan.end - plan.start + plan.uniform_pad
+    if t % 4 != 1:
+        t = ((t - 1) // 4 + 1) * 4 + 1
+    h, w = transforms.resized_output_size(images_thwc.shape[1], images_thwc.shape[2], resolution)
+    if max_resolution > 0 and max(h, w) > max_resolution:
+        scale = max_resolution / max(h, w)
+        h, w = round(h * scale), round(w * scale)
+    return (3, t, (h + 15) // 16 * 16, (w + 15) // 16 * 16)
 
 
 @torch.no_grad()
@@ -86,17 +104,30 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
     plans, overlap = plan_batches(total, batch_size, temporal_overlap, uniform_batch_size)
     mine = [i for i in range(len(plans)) if batch_filter is None or batch_filter(i)]
 
-    # ---- phase 1: encode
+    # ---- phase 1: encode.  The input noise comes from ONE generator stream seeded with seed + 1e6 before the first
+    # batch (set_seed(seed_vae), generation_phases.py:327-330) and consumed batch after batch; a rank that skips batches
+    # (batch_filter) draws and discards their noise, so every batch sees the noise of the single-rank run.
     latents = {}
-    for n, i in enumerate(mine):
-        x = prepare_batch(images, plans[i], resolution, max_resolution).to(dt)
+    if input_noise_scale > 0:
+        torch.manual_seed(seed + 1_000_000)
+        if dev.type == "cuda":
+            torch.cuda.manual_seed(seed + 1_000_000)
+    owned = set(mine)
+    done = 0
+    for i, plan in enumerate(plans):
+        if i not in owned:
+            if input_noise_scale > 0 and i < max(mine, default=-1):
+                torch.randn(transformed_shape(images, plan, resolution, max_resolution), dtype=dt, device=dev)
+            continue
+        x = prepare_batch(images, plan, resolution, max_resolution, dtype=dt)
         if input_noise_scale > 0:
             noise = torch.randn_like(x) * 0.05
             blend = input_noise_scale * 0.5
             x = x * (1 - blend) + (x + noise) * blend
         latents[i] = runner.vae_encode([x])[0]
+        done += 1
         if progress:
-            progress("encode", n + 1, len(mine))
+            progress("encode", done, len(mine))
 
     # ---- phase 2: one-step DiT
     upscaled = {}

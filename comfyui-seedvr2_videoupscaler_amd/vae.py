@@ -137,8 +137,11 @@ class VideoVAEEngine:
 
         def resnet(name):
             sc = conv(name + ".conv_shortcut", pad=(0, 0)) if (name + ".conv_shortcut.weight") in sd else None
-            return _Resnet(norm(name + ".norm1"), conv(name + ".conv1"), norm(name + ".norm2"),
-                           conv(name + ".conv2"), sc)
+            rb = _Resnet(norm(name + ".norm1"), conv(name + ".conv1"), norm(name + ".norm2"), conv(name + ".conv2"), sc)
+            if sc is None and rb.conv1.cin != rb.conv2.cout:
+                raise KeyError(f"{name}: width changes {rb.conv1.cin} -> {rb.conv2.cout} but {name}.conv_shortcut is missing "
+                               "from the state dict (ResnetBlock3D, attn_video_vae.py:292-305)")
+            return rb
 
         def attn(name):
             c = sd[name + ".to_q.weight"].shape[0]
@@ -202,6 +205,8 @@ class VideoVAEEngine:
         Ho = (H + cw.pad_lo + cw.pad_hi - kh) // sH + 1
         Wo = (W + cw.pad_lo + cw.pad_hi - kw) // sW + 1
         geom = Conv3dGeom(T, H, W, Cin, To, Ho, Wo, cw.k, cw.stride, (pt, cw.pad_lo, cw.pad_lo), halo)
+        if resid is not None and tuple(resid.shape) != (To, Ho, Wo, cw.cout):
+            raise ValueError(f"{cw.name}: residual {tuple(resid.shape)} does not match the output {(To, Ho, Wo, cw.cout)}")
         out = ops.empty(To, Ho, Wo, cw.cout)
         K = cw.w.shape[1]
         epi = EPI_RESID_GATE if resid is not None else EPI_BIAS

@@ -42,7 +42,7 @@ def tr16_b64(lds, addr):
     return out
 
 
-def run_wave(q, k, v, L, q0, wave, scale):
+def run_wave(q, k, v, L, q0, wave, scale, NW=4):
     """q,k,v: [L, 128] float (bf16-representable not required).  Returns {qpos: out row} for this wave's valid queries."""
     nk = (L + KT - 1) // KT
     lds = np.zeros(4 * TILE // 2)                        # element (2-byte) addressed
@@ -59,16 +59,16 @@ def run_wave(q, k, v, L, q0, wave, scale):
     m_run = np.full(64, -np.inf); l_run = np.zeros(64)
     c = scale * 1.4426950408889634
 
-    def stage(t, buf):                                   # all 4 waves' pieces
-        for w in range(4):
-            for it in range(4):
+    def stage(t, buf):                                   # all NW waves' pieces
+        for w in range(NW):
+            for it in range(16 // NW):
                 for lane in range(64):
                     st_key = w * 4 + (lane >> 4)
-                    key = min(t * KT + it * 16 + st_key, L - 1)
-                    st_k = ((lane & 15) ^ st_key)
+                    key = min(t * KT + it * 4 * NW + st_key, L - 1)
+                    st_k = ((lane & 15) ^ (st_key & 15))
                     st_v = ((lane & 15) ^ ((lane >> 4) << 2))
-                    dk = (buf * TILE + w * 1024 + it * 4096 + lane * 16) // 2
-                    dv = ((2 + buf) * TILE + w * 1024 + it * 4096 + lane * 16) // 2
+                    dk = (buf * TILE + w * 1024 + it * NW * 1024 + lane * 16) // 2
+                    dv = ((2 + buf) * TILE + w * 1024 + it * NW * 1024 + lane * 16) // 2
                     lds[dk:dk + 8] = k[key, st_k * 8:st_k * 8 + 8]
                     lds[dv:dv + 8] = v[key, st_v * 8:st_v * 8 + 8]
 
@@ -127,7 +127,11 @@ def run_wave(q, k, v, L, q0, wave, scale):
     return rows
 
 
-def test_attn_win_index_algebra():
+import pytest
+
+
+@pytest.mark.parametrize("NW", [4, 8])
+def test_attn_win_index_algebra(NW):
     rng = np.random.default_rng(0)
     L = 150                                              # 3 key tiles, ragged tail (150 = 2*64 + 22), 2 query tiles
     q, k, v = (rng.standard_normal((L, D)) for _ in range(3))
@@ -136,8 +140,8 @@ def test_attn_win_index_algebra():
     p = np.exp(s - s.max(1, keepdims=True))
     want = (p / p.sum(1, keepdims=True)) @ v
     got = {}
-    for q0, wave in ((0, 0), (0, 3), (128, 0)):
-        got.update(run_wave(q, k, v, L, q0, wave, scale))
+    for q0, wave in (((0, 0), (0, 3), (128, 0)) if NW == 4 else ((0, 0), (0, 3), (0, 4))):
+        got.update(run_wave(q, k, v, L, q0, wave, scale, NW))
     assert set(got) == set(range(0, 32)) | set(range(96, 128)) | set(range(128, 150))
     for r, row in got.items():
         assert not np.isnan(row).any()

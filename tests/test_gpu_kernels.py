@@ -432,6 +432,15 @@ def test_attn_varlen(hip, ref, attn_impl, lens, heads, D):
         again = torch.zeros_like(out)
         hip.attn_varlen(qkv, again, seq_rows, out_rows, cu, max(lens), heads, D, scale)
         assert torch.equal(again, out)
+    if attn_impl == 0 and D == 128:                 # the build variants of the second-generation kernel (A/B knob)
+        for variant in (1, 2, 3):                   # 4 waves + s_setprio, 8 waves, 8 waves + s_setprio
+            hip.set_option("attn_variant", variant)
+            try:
+                other = torch.full_like(out, float("nan"))
+                hip.attn_varlen(qkv, other, seq_rows, out_rows, cu, max(lens), heads, D, scale)
+            finally:
+                hip.set_option("attn_variant", 0)
+            assert torch.equal(other, out), variant     # same MFMAs in the same order per query row -> same bits
 
 
 def test_attn_varlen_scattered_output_rows(hip, ref, attn_impl):

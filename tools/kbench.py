@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="conv,gemm,attn,side")
     ap.add_argument("--match", default="", help="conv: only shapes whose name contains this substring")
+    ap.add_argument("--attn-default-only", action="store_true", help="attn: skip the A/B build variants of the window kernel")
+    ap.add_argument("--no-vae-attn", action="store_true", help="attn: only the DiT window attention")
     ap.add_argument("--no-frag", action="store_true", help="conv: do not supply the fragment-ordered weight copy")
     args = ap.parse_args()
     only = set(args.only.split(","))
@@ -113,13 +115,19 @@ def main():
             att = ops.empty(N + Lt + plan.n_win * Lt, heads * 128)
             t_seq, t_out, t_cu = (torch.from_numpy(v).to(dev) for v in (seq, outr, cu))
             fl = sum(4.0 * heads * 128 * float(l + Lt) ** 2 for l in lens)
-            for impl, tag in ((0, "gen2 svr_attn_win"), (1, "gen1 svr_attn")):
+            for impl, variant, tag in ((0, 0, "gen2 4 waves"), (0, 1, "gen2 4 waves + setprio"), (0, 2, "gen2 8 waves"),
+                                       (0, 3, "gen2 8 waves + setprio"), (1, 0, "gen1 svr_attn")):
+                if variant and args.attn_default_only:
+                    continue
                 ops.set_option("attn_impl", impl)
+                ops.set_option("attn_variant", variant)
                 sec = timeit(lambda: ops.attn_varlen(qkv, att, t_seq, t_out, t_cu, int(lens.max()) + Lt, heads, 128,
                                                      1 / math.sqrt(128)), args.reps)
                 report(f"attn window {method} ({plan.n_win} windows) [{tag}]", sec, flops=fl)
             ops.set_option("attn_impl", 0)
+            ops.set_option("attn_variant", 0)
             del qkv, att
+    if "attn" in only and not args.no_vae_attn:
         # VAE mid-block attention on one 1024-px tile: 9 frames x (128*128) tokens, 1 head of 512
         T, n, Cc = 9, 128 * 128, 512
         qkv = rnd(T * n, 3 * Cc)
