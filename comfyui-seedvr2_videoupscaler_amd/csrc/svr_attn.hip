@@ -250,7 +250,7 @@ int attn_dispatch(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, co
     *why = nullptr;
     if (n_seq <= 0 || max_len <= 0) return 0;
     if (n_seq > 65535 || heads > 65535) { *why = "svr_attn_varlen: grid too large"; return -1; }
-    if (head_dim == 128 && max_len <= AW_MAXL && g_attn_impl != 1)
+    if (head_dim == 128 && max_len <= AW_MAXL && (ld_qkv % 8) == 0 && g_attn_impl != 1)
         return launch_attn_win(qkv, ld_qkv, out, ld_out, seq_rows, out_rows, cu, n_seq, max_len, heads, scale, s);
     if (head_dim == 128)
         return launch_attn<128, 2, 64>(qkv, ld_qkv, out, ld_out, seq_rows, out_rows, cu, n_seq, max_len, heads, scale, s);

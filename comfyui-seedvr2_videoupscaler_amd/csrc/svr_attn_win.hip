@@ -8,8 +8,10 @@
 // through registers and 8-byte transposing LDS stores, (c) the q-tiles of one (window, head) were consecutive block
 // ids, i.e. round-robin over the 8 XCDs, so each private L2 fetched the window's K/V again.  Here:
 //
-//   * block = 4 waves x 32 queries (128-query tile), two workgroups per CU (72 KiB LDS, <= 256 registers);
-//   * the window's row indices are read ONCE into an LDS table, so the tile loop has no dependent global load;
+//   * block = 8 waves x 32 queries (256-query tile, one workgroup per CU; a 4-wave / two-workgroup build is kept behind
+//     svr_set_option("attn_variant") -- 72 KiB LDS, <= 256 registers either way);
+//   * the window's rows are resolved ONCE into an LDS table of qkv byte offsets (16-byte units, 32 bits: qkv < 64 GiB),
+//     so the tile loop has no dependent global load and no 64-bit multiply;
 //   * K and V tiles (64 keys x 128 d, 16 KiB each) are double-buffered and BOTH filled by 16-byte LDS-DMA
 //     (global_load_lds) for tile t+1 while tile t is computed -- one barrier per tile, no VGPR staging;
 //   * v_mfma_f32_32x32x16_bf16 throughout, everything transposed so that softmax is lane-local:
@@ -34,12 +36,14 @@ namespace svr {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int AW_D = 128;                        // head dim
 constexpr int AW_KT = 64;                        // keys per tile
 constexpr int AW_MAXL = 2048;                    // longest window (rows incl. text) the LDS row table holds
 constexpr int AW_TILE = AW_KT * AW_D * 2;        // bytes of one K (or V) tile
 constexpr int AW_LDS = 4 * AW_TILE + AW_MAXL * 4;
+constexpr float AW_DEFER = 6.0f;                 // log2 units: P <= 64 between rescales
 
 // v_permlane32_swap_b32 vdst, src exchanges lanes 32-63 of vdst with lanes 0-31 of src.  Fed the same value in both
 // operands, one of the two results is this lane's own value and the other the value of lane ^ 32 -- in BOTH halves.
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
     const int32_t* __restrict__ seq_rows, const int32_t* __restrict__ out_rows, const int32_t* __restrict__ cu,
     int heads, int n_pairs, int qt_per_pair, float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* srow = (int*)(smem + 4 * AW_TILE);
+    unsigned* srow = (unsigned*)(smem + 4 * AW_TILE);     // row table: byte offset of every window row in qkv, in 16-byte units
 
     // ---- work item: XCD x owns pairs x, x + 8, ...; the q-tiles of a pair are consecutive in its dispatch order
     const int bid = blockIdx.x;
@@ -137,10 +141,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
     const int l31 = lane & 31, hi = lane >> 5;
     const int nk = (L + AW_KT - 1) / AW_KT;
 
-    for (int i = tid; i < nk * AW_KT; i += NW * 64) srow[i] = seq_rows[beg + min(i, L - 1)];
+    const int64_t ld_bytes = ld_qkv * 2;                  // (multiple of 16: checked by the launcher)
+    for (int i = tid; i < nk * AW_KT; i += NW * 64)
+        srow[i] = (unsigned)(((int64_t)seq_rows[beg + min(i, L - 1)] * ld_bytes) >> 4);
     __syncthreads();
 
-    const int64_t ld_bytes = ld_qkv * 2;
     const char* qbase = (const char*)qkv + (int64_t)head * (AW_D * 2);
     const int64_t k_off = (int64_t)heads * (AW_D * 2), v_off = 2 * k_off;
 
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
     auto next_rows = [&](int t) {                                    // (plain LDS reads + 64-bit mads, waited for by hipcc right here)
         const int tt = min(t, nk - 1);
 #pragma unroll
-        for (int it = 0; it < NP; ++it) nsrc[it] = qbase + (int64_t)srow[tt * AW_KT + it * (4 * NW) + st_key] * ld_bytes;
+        for (int it = 0; it < NP; ++it) nsrc[it] = qbase + ((uint64_t)srow[tt * AW_KT + it * (4 * NW) + st_key] << 4);
     };
     auto stage_piece = [&](int it, int buf) {                        // 1 KiB of K and 1 KiB of V per wave instruction
         glds16(nsrc[it] + k_off + st_k, smem + buf * AW_TILE + wave * 1024 + it * (NW * 1024));
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
     const int qpos = q0 + wave * 32 + l31;
     bf16x8 qf[8];
     {
-        const char* qp = qbase + (int64_t)srow[min(qpos, L - 1)] * ld_bytes + hi * 16;
+        const char* qp = qbase + ((uint64_t)srow[min(qpos, L - 1)] << 4) + hi * 16;
 #pragma unroll
         for (int ds = 0; ds < 8; ++ds) qf[ds] = *(const bf16x8*)(qp + ds * 32);
     }
@@ -245,11 +250,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
         mx = aw_other_half_max(mx);
-        const float m_new = fmaxf(m_run, mx);          // finite: every tile holds at least one valid key
-        const float mc = m_new * scale_log2;
-        const float alpha = fast_exp2(m_run * scale_log2 - mc);
-        m_run = m_new;
-        float psum = 0.f;
+        // Deferred rescale (cdna_hip_programming.md T13): while no row's maximum grew by more than 2^AW_DEFER over the
+        // reference value m_run, keep m_run -- P is then bounded by 2^AW_DEFER instead of 1 (same RELATIVE bf16 precision,
+        // fp32 accumulators) and the O / l rescale is skipped for the whole wave.  Everything exponentiated in this tile
+        // uses the m_run decided HERE, and O, l are rescaled in the same place, so nothing is ever at a stale scale.
+        if (!__all((mx - m_run) * scale_log2 <= AW_DEFER)) {          // also true for the first tile (m_run = -inf)
+            const float m_new = fmaxf(m_run, mx);                     // finite: every tile holds at least one valid key
+            const float alpha = fast_exp2((m_run - m_new) * scale_log2);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
+        }
+        const float mc = m_run * scale_log2;
+        f32x2 ps = {0.f, 0.f};
+        const f32x2 c2 = {scale_log2, scale_log2}, mc2 = {-mc, -mc};
         bf16x8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -257,20 +274,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
             for (int u = 0; u < 2; ++u) {
                 float p[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    p[e] = fast_exp2(fmaf(sacc[kb][8 * u + e], scale_log2, -mc));
-                    psum += p[e];
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 sv = {sacc[kb][8 * u + e], sacc[kb][8 * u + e + 1]};
+                    const f32x2 a = __builtin_elementwise_fma(sv, c2, mc2);            // v_pk_fma_f32
+                    p[e] = fast_exp2(a[0]);
+                    p[e + 1] = fast_exp2(a[1]);
+                    const f32x2 pv = {p[e], p[e + 1]};
+                    ps += pv;                                                           // v_pk_add_f32
                 }
                 const uint4 pk = pack8(p);
                 pf[kb][u] = __builtin_bit_cast(bf16x8, pk);
             }
-        l_run = l_run * alpha + psum;
-        if (!__all(alpha == 1.0f)) {                   // wave-uniform: no running max moved -> nothing to rescale (exact)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
-        }
+        l_run += ps[0] + ps[1];
 
         // ---- O^T += V^T P^T : 4 k-steps (16 keys each) x 4 d blocks; the reads of k-step g+1 fly under the MFMAs of g
 #define AW_PV(V, KB, U)                                                                                            \
@@ -322,7 +337,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
         }
 }
 
-// svr_set_option("attn_variant", v): 0 = 4 waves, 1 = 4 waves + s_setprio, 2 = 8 waves, 3 = 8 waves + s_setprio (A/B knob)
+// svr_set_option("attn_variant", v): A/B knob over the build variants -- 0 = default (8 waves; measured best on both window
+// families, profiles/r2_attn_kbench.jsonl), 1 = 4 waves + s_setprio, 2 = 8 waves, 3 = 8 waves + s_setprio, 4 = 4 waves
 int g_attn_variant = [] { const char* e = getenv("SVR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
 
 template <int NW, bool PRIO>
@@ -337,6 +353,7 @@ static int launch_attn_win_t(const void* qkv, int64_t ld_qkv, void* out, int64_t
         attr_set = true;
     }
     constexpr int QB = NW * 32;
+    if ((ld_qkv * 2) % 16 != 0) return -3;            // (attn_dispatch only sends 16-byte aligned row pitches here)
     const int qt = (max_len + QB - 1) / QB;
     const int64_t n_pairs = (int64_t)n_seq * heads;
     const int64_t blocks = 8 * ((n_pairs + 7) / 8) * qt;
@@ -353,9 +370,9 @@ static int launch_attn_win(const void* qkv, int64_t ld_qkv, void* out, int64_t l
 #define AW_ARGS qkv, ld_qkv, out, ld_out, seq_rows, out_rows, cu, n_seq, max_len, heads, scale, s
     switch (g_attn_variant) {
         case 1: return launch_attn_win_t<4, true>(AW_ARGS);
-        case 2: return launch_attn_win_t<8, false>(AW_ARGS);
         case 3: return launch_attn_win_t<8, true>(AW_ARGS);
-        default: return launch_attn_win_t<4, false>(AW_ARGS);
+        case 4: return launch_attn_win_t<4, false>(AW_ARGS);
+        default: return launch_attn_win_t<8, false>(AW_ARGS);
     }
 #undef AW_ARGS
 }

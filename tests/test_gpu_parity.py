@@ -98,7 +98,7 @@ def test_dit_3b_width_multiwindow_vs_reference_golden(hip):
             hip.set_option("attn_impl", 0)
         e, p = rel_err(out, g["out"]), psnr(out, g["out"])
         print(f"DiT 3B-width 4 layers, 48 windows, attn_impl={impl}: rel-err {e:.3e}, PSNR {p:.1f} dB")
-        assert e < 6e-3 and p > 60, (impl, e, p)      # 4 layers: well under the 32-layer budget of 2e-2
+        assert e < 9e-3 and p > 60, (impl, e, p)      # measured 5.7e-3 / 64.3 dB (4 layers; 32-layer budget: 2e-2)
         outs[impl] = out
     assert rel_err(outs[0], outs[1]) < 4e-3
 
