@@ -10,14 +10,23 @@ calls the reference pipeline makes per batch (src/core/infer.py:117,315,203).  W
     cfg3  33 frames 2160x3840 (720p->4K clip of 32 frames, 4n+1 padded), VAE tiled 1024/128   [metric config]
     cfg2   9 frames 2048x2048 (8-frame 512^2->2K clip), VAE untiled
     cfg1   1 frame  256x256
-N > 1: one process per GPU (torchrun), every rank upscales its own temporal batch (weak scaling, no
-data-path collective) and the upscaled bf16 frames are all-gathered over RCCL/xGMI inside the step.
-Rank 0 prints ONE JSON line.  `value` = frames all ranks produced / max-over-ranks wall time.
+    cfg4  128 frames 720x1280 -> 2160x3840 through the whole four-phase pipeline (input transform, 8 temporal batches
+          of 17 with a 1-frame overlap blend, LAB colour fix), batches dealt to the ranks (dist.upscale_sharded):
+          BASELINE config 4, STRONG scaling (the clip is fixed, N ranks share its 8 batches)
+N > 1: one process per GPU.  Launched under torchrun (RANK / WORLD_SIZE set) it joins that group; launched bare with
+--gpus N it re-executes itself under torch.distributed.run with N ranks on 127.0.0.1 (and fails loudly when fewer
+GPUs are visible).  cfg3/cfg2/cfg1/cfg5: every rank upscales its own temporal batch (weak scaling, no data-path
+collective) and the upscaled bf16 frames are all-gathered over RCCL/xGMI inside the step.
+Rank 0 prints ONE JSON line.  `value` = frames all ranks produced / max-over-ranks wall time; `n_gpus` is the
+all-reduced count of ranks that ran.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -35,7 +44,12 @@ WORKLOADS = {
     # BASELINE config 5's model and clip on ONE GPU, bf16 weights (the reference does no fp8 arithmetic either:
     # fp8 checkpoints are up-cast per op); not the metric config, run with --workload cfg5
     "cfg5": (65, 2160, 3840, True, "SeedVR2-7B 65-frame (64+1 pad) 1080p->4K clip, VAE tiled 1024/128"),
+    # BASELINE config 4: the whole pipeline over a 128-frame clip, temporal batches sharded over the ranks (strong scaling)
+    "cfg4": (128, 2160, 3840, True, "SeedVR2-3B 128-frame 720p->4K clip, 8 temporal batches of 17 (overlap 1) sharded "
+                                    "over the ranks, full pipeline (transform, encode, DiT, decode, blend, LAB colour fix)"),
 }
+CFG4 = dict(in_hw=(720, 1280), resolution=2160, batch_size=17, temporal_overlap=1, uniform_batch_size=True,
+            color_correction="lab")
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16 peak, MI355X_MICROARCH.md
 
 
@@ -91,35 +105,64 @@ def make_profiled_ops(device):
 
 
 def cpu_baseline(flops_per_frame: float) -> dict:
-    """The CPU oracle (oracle/, a port of the reference's PyTorch path) timed on this host's cores on a
-    bounded sample of the same pipeline; converted to the metric's unit through the algorithmic FLOP
-    ratio (labelled extrapolation).  Test infrastructure used only as a reported baseline."""
+    """The CPU oracle (oracle/, a port of the reference's PyTorch path) timed on this host's cores on a bounded
+    sample of the same pipeline: 1 warm-up + median of 3 per leg, converted to the metric's
+    unit through the algorithmic FLOP ratio (labelled extrapolation).  Test infrastructure used only as a reported
+    baseline.  profiles/r2_cpu_reference_vs_port.json holds the calibration of this port against the reference
+    implementation itself on the same sample (build container, where /root/reference is mounted)."""
     from oracle import dit_oracle, vae_oracle
     config, weights, windows, flops = sub("config"), sub("weights"), sub("windows"), sub("flops")
     cores = torch.get_num_threads()
     vcfg = config.VAE_V3
     vsd = {k: v.float() for k, v in weights.synth_vae_state_dict(vcfg).items()}
     g = torch.Generator().manual_seed(0)
-    x = torch.rand(3, 9, 160, 160, generator=g) * 2 - 1
-    t0 = time.perf_counter()
-    lat = vae_oracle.runner_vae_encode(x, vsd, vcfg)
-    vae_oracle.runner_vae_decode(lat, vsd, vcfg)
-    t_vae = time.perf_counter() - t0
-    f_vae = sum(flops.vae_flops_tiled(vcfg, 9, 160, 160, False).values())
-    # 6-layer slice of the 3B-width DiT on a 3x48x48 latent
-    dcfg = config.DiTConfig(num_layers=6, mm_layers=3)
+    x = torch.rand(3, 5, 96, 96, generator=g) * 2 - 1
+
+    def median3(fn):
+        fn()                                            # warm-up
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    def vae_leg():
+        lat = vae_oracle.runner_vae_encode(x, vsd, vcfg)
+        vae_oracle.runner_vae_decode(lat, vsd, vcfg)
+
+    t_vae = median3(vae_leg)
+    f_vae = sum(flops.vae_flops_tiled(vcfg, 5, 96, 96, False).values())
+    # 2-layer slice (one regular + one shifted window layer) of the 3B-width DiT on a 3x48x48 latent
+    dcfg = config.DiTConfig(num_layers=2, mm_layers=1)
     dsd = weights.synth_dit_state_dict(dcfg)
     vid = torch.randn(3, 48, 48, 33, generator=g)
     txt = weights.synth_text_embedding().float()
-    t0 = time.perf_counter()
-    dit_oracle.dit_forward(dsd, dcfg, vid, txt, 1000.0, windows_mod=windows)
-    t_dit = time.perf_counter() - t0
+    t_dit = median3(lambda: dit_oracle.dit_forward(dsd, dcfg, vid, txt, 1000.0, windows_mod=windows))
     f_dit = flops.dit_flops(dcfg, (3, 24, 24))["total"]
     tflops = (f_vae + f_dit) / (t_vae + t_dit) / 1e12
     return {"value": tflops * 1e12 / flops_per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
-            "cpu_tflops": tflops,
-            "sample": f"oracle fp32: full VAE enc+dec of a 9x160x160 clip ({t_vae:.1f}s) + 6-layer 3B-width DiT on a "
-                      f"3x48x48 latent ({t_dit:.1f}s); extrapolated to the workload by algorithmic FLOPs"}
+            "cpu_tflops": tflops, "timing": "1 warm-up + median of 3 per leg",
+            "sample": f"oracle fp32: full VAE enc+dec of a 5x96x96 clip ({t_vae:.2f}s) + 2-layer (regular + shifted windows) "
+                      f"3B-width DiT on a 3x48x48 latent ({t_dit:.2f}s); extrapolated to the workload by algorithmic FLOPs"}
+
+
+def respawn_under_torchrun(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script on this node (one per GPU, RCCL)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < n:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        print(f"[bench] --gpus {n} requested but only {have} GPU(s) are visible: refusing to report a {n}-GPU number",
+              file=sys.stderr)
+        return 2
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (the host driver supports nothing else)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -132,12 +175,17 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print per-phase timings to stderr")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(respawn_under_torchrun(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:       # (checked before the rendezvous, which would wait for peers)
+        print(f"[bench] launched with WORLD_SIZE={os.environ.get('WORLD_SIZE')} but --gpus {args.gpus}: the two must agree",
+              file=sys.stderr)
+        sys.exit(2)
     dist_mod = sub("dist")
     rank, world, local = dist_mod.init_from_env()
-    if world != args.gpus:
-        if rank == 0 and world > 1:
-            print(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}", file=sys.stderr)
-        args.gpus = world
+    if local >= torch.cuda.device_count():
+        print(f"[bench] rank {rank}: LOCAL_RANK {local} has no GPU ({torch.cuda.device_count()} visible)", file=sys.stderr)
+        sys.exit(2)
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
 
@@ -155,27 +203,38 @@ def main():
     runner.dit, runner.vae = dit, vae
     runner.configure_diffusion(device=device, dtype=torch.bfloat16)
 
-    g = torch.Generator(device=device).manual_seed(42 + rank)
-    x = (torch.rand(3, frames, H, W, generator=g, device=device) * 2 - 1).to(torch.bfloat16)
+    sharded = args.workload == "cfg4"
+    g = torch.Generator(device=device).manual_seed(42 + (0 if sharded else rank))
     Tl, hl, wl = (frames - 1) // 4 + 1, H // 8, W // 8
-    noise = torch.randn(Tl, hl, wl, 16, generator=g, device=device).to(torch.bfloat16)
     txt = weights.synth_text_embedding(device=device)
     phase = {"encode": 0.0, "dit": 0.0, "decode": 0.0, "gather": 0.0}
+    if sharded:
+        # the same synthetic clip on every rank (each rank reads the frames of the batches it owns)
+        images = torch.rand(frames, CFG4["in_hw"][0], CFG4["in_hw"][1], 3, generator=g, device=device)
+        pipe_kw = {k: v for k, v in CFG4.items() if k != "in_hw"}
+        plans, _ = sub("pipeline").plan_batches(frames, CFG4["batch_size"], CFG4["temporal_overlap"], CFG4["uniform_batch_size"])
 
-    def step(timed: bool):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
-        if timed: ev[0].record()
-        lat = runner.vae_encode([x])[0]
-        if timed: ev[1].record()
-        cond = runner.get_condition(noise, latent_blur=lat, task="sr")
-        x0 = runner.inference([noise], [cond], [txt], [txt])[0]
-        if timed: ev[2].record()
-        out = runner.vae_decode([x0])[0]                       # [3, T, H, W] view of THWC
-        if timed: ev[3].record()
-        thwc = out.permute(1, 2, 3, 0) if out.dim() == 4 else out.permute(1, 2, 0)[None]
-        gathered = dist_mod.all_gather_frames(thwc.contiguous())
-        if timed: ev[4].record()
-        return gathered, ev
+        def step(timed: bool):
+            out = dist_mod.upscale_sharded(images, runner, txt, **pipe_kw)      # [128, 2160, 3840, 3] on every rank
+            return out, None
+    else:
+        x = (torch.rand(3, frames, H, W, generator=g, device=device) * 2 - 1).to(torch.bfloat16)
+        noise = torch.randn(Tl, hl, wl, 16, generator=g, device=device).to(torch.bfloat16)
+
+        def step(timed: bool):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
+            if timed: ev[0].record()
+            lat = runner.vae_encode([x])[0]
+            if timed: ev[1].record()
+            cond = runner.get_condition(noise, latent_blur=lat, task="sr")
+            x0 = runner.inference([noise], [cond], [txt], [txt])[0]
+            if timed: ev[2].record()
+            out = runner.vae_decode([x0])[0]                       # [3, T, H, W] view of THWC
+            if timed: ev[3].record()
+            thwc = out.permute(1, 2, 3, 0) if out.dim() == 4 else out.permute(1, 2, 0)[None]
+            gathered = dist_mod.all_gather_frames(thwc.contiguous())
+            if timed: ev[4].record()
+            return gathered, ev
 
     for _ in range(args.warmup):
         step(False)
@@ -193,31 +252,52 @@ def main():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     ops.recording = False
+    n_ranks = 1
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax)
-    for ev in evs:
-        for i, k in enumerate(("encode", "dit", "decode", "gather")):
-            phase[k] += ev[i].elapsed_time(ev[i + 1])
-    phase = {k: v / args.steps for k, v in phase.items()}
+        cnt = torch.ones(1, device=device, dtype=torch.int64)
+        torch.distributed.all_reduce(cnt)                       # ranks that actually ran the timed region
+        n_ranks = int(cnt)
+    if not sharded:
+        for ev in evs:
+            for i, k in enumerate(("encode", "dit", "decode", "gather")):
+                phase[k] += ev[i].elapsed_time(ev[i + 1])
+        phase = {k: v / args.steps for k, v in phase.items()}
 
     if rank == 0:
-        f_dit = flops.dit_flops(dcfg, (Tl, hl // 2, wl // 2))
-        f_vae = flops.vae_flops_tiled(vcfg, frames, H, W, tiled)
-        f_step = f_dit["total"] + f_vae["encode"] + f_vae["decode"]
+        if sharded:        # 8 temporal batches of 17 frames (latent 5 x 270 x 480), tiled VAE
+            bf = CFG4["batch_size"]
+            f_dit = flops.dit_flops(dcfg, ((bf - 1) // 4 + 1, hl // 2, wl // 2))
+            f_vae = flops.vae_flops_tiled(vcfg, bf, H, W, tiled)
+            f_step = len(plans) * (f_dit["total"] + f_vae["encode"] + f_vae["decode"])
+            frames_per_step, useful_per_step = frames, frames
+        else:
+            f_dit = flops.dit_flops(dcfg, (Tl, hl // 2, wl // 2))
+            f_vae = flops.vae_flops_tiled(vcfg, frames, H, W, tiled)
+            f_step = f_dit["total"] + f_vae["encode"] + f_vae["decode"]
+            frames_per_step = world * frames
+            # the 4n+1 rule pads a 32-frame clip with one reversed frame (generation_phases.py:398-404): it is computed but
+            # trimmed from the output, so the useful rate is (frames - 1) / frames of `value` for the padded workloads
+            useful_per_step = world * (frames - 1 if frames > 1 and frames % 4 == 1 else frames)
         kern = ops.summary()
-        # dominant kernel: the LDS-halo implicit-GEMM conv (67 % of the step, profiles/r1_cfg3_kernel_stats.csv)
+        # dominant kernel: the LDS-halo implicit-GEMM conv (70 % of the step, profiles/r1_cfg3_kernel_stats.csv)
         dom = kern.get("conv_halo") or kern.get("conv_generic") or kern["gemm"]
         c_flops, c_sec, c_n = dom["flops"], dom["seconds"], dom["launches"]
         traffic, traffic_note = None, None
-        try:     # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload (never measured live)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_cfg3_pmc_traffic.json")))
-            if pmc.get("workload") == args.workload and "conv_halo" in kern:
-                traffic = pmc["kernels"][pmc.get("dominant", "svr::conv_halo2_kernel")]["hbm_bytes_per_launch"]
-                traffic_note = "bytes/launch, FETCH_SIZE*2 + WRITE_SIZE from profiles/r1_cfg3_pmc_traffic.json"
-        except (OSError, KeyError, ValueError):
-            pass
+        for name in ("r2_cfg3_pmc_traffic.json", "r1_cfg3_pmc_traffic.json"):
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes of this workload (counters cannot be collected
+            # inside the timed run); the file names the commit it was measured on
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if pmc.get("workload") == "cfg3" and args.workload == "cfg3" and "conv_halo" in kern:
+                    traffic = pmc["kernels"][pmc.get("dominant", "svr::conv_halo2_kernel")]["hbm_bytes_per_launch"]
+                    traffic_note = f"bytes/launch, FETCH_SIZE*2 + WRITE_SIZE from profiles/{name}" + \
+                                   (f" (kernels as of {pmc['measured_at']})" if pmc.get("measured_at") else "")
+                    break
+            except (OSError, KeyError, ValueError):
+                continue
         roof = {"bound": "mfma", "kernel": "svr::conv_halo2_kernel<8, register-streamed weights> (LDS-halo implicit-GEMM causal Conv3d, 8x32-voxel patches x 128 couts, 3x3 spatial taps)",
                 "achieved": c_flops / max(c_sec, 1e-12) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": c_flops / max(c_sec, 1e-12) / 1e12 / PEAK_BF16_TFLOPS, "traffic": traffic,
@@ -227,24 +307,31 @@ def main():
                 "share_of_step_time": c_sec / max(dt, 1e-12),
                 "per_kernel": {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2), "tflops": round(v["tflops"], 1)}
                                for k, v in kern.items()}}
+        family = "7B" if args.workload == "cfg5" else "3B"
         res = {
-            "metric": "upscaled frames/sec (720p->4K, SeedVR2-3B)" if args.workload == "cfg3"
-                      else f"upscaled frames/sec ({args.workload}, SeedVR2-{'7B' if args.workload == 'cfg5' else '3B'})",
-            "value": world * frames * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": "upscaled frames/sec (720p->4K, SeedVR2-3B)" if args.workload in ("cfg3", "cfg4")
+                      else f"upscaled frames/sec ({args.workload}, SeedVR2-{family})",
+            "value": frames_per_step * args.steps / dt, "unit": "frames/s", "n_gpus": n_ranks, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "frames_per_step_per_gpu": frames,
+            "config": {"workload": f"{args.workload}: {desc}",
+                       "frames_per_step_per_gpu": frames if not sharded else f"{frames} per clip, 8 batches of 17 shared by the ranks",
                        "pixels": [H, W], "latent": [Tl, hl, wl], "vae_tiled": tiled, "parallelism": f"dp{world}",
-                       "weights": f"random-init SeedVR2-{'7B' if args.workload == 'cfg5' else '3B'} + video_vae_v3 architecture (seeded)"},
-            "dit_ms_per_step": phase["dit"], "vae_encode_ms": phase["encode"], "vae_decode_ms": phase["decode"],
-            "allgather_ms": phase["gather"],
+                       "weights": f"random-init SeedVR2-{family} + video_vae_v3 architecture (seeded)"},
+            "useful_frames_per_s": useful_per_step * args.steps / dt,
             "algorithmic_tflop_per_step": f_step / 1e12,
-            "achieved_tflops_per_gpu": f_step * args.steps / dt / 1e12,
-            "dit_tflops": f_dit["total"] / max(phase["dit"], 1e-9) / 1e9,
+            "achieved_tflops_per_gpu": f_step * (1 if sharded else world) * args.steps / dt / 1e12 / world,
             "roofline": roof,
         }
+        if not sharded:
+            dit_tf = f_dit["total"] / max(phase["dit"], 1e-9) / 1e9
+            res.update({"dit_ms_per_step": phase["dit"], "vae_encode_ms": phase["encode"], "vae_decode_ms": phase["decode"],
+                        "allgather_ms": phase["gather"], "dit_tflops": dit_tf,
+                        # whole-DiT-step MFMA fraction: algorithmic FLOPs of the forward / its measured time / dense bf16 peak
+                        "dit_mfma_frac": dit_tf / PEAK_BF16_TFLOPS})
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(f_step / frames)
+            res["cpu_baseline"] = cpu_baseline(f_step / frames_per_step * (world if not sharded else 1))
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()

@@ -4,12 +4,13 @@ The reference's only live multi-GPU mode is process-level data parallelism in th
 per GPU, results returned through mp.Queue as shared-memory CPU tensors (inference_cli.py:1127-1288).
 Temporal batches are independent through encode -> DiT -> decode, so the native form is:
 batch i -> rank i mod world (keeps batch boundaries, hence pixels, identical to the single-GPU run),
-weights replicated, no data-path collective until ONE all-gather of the upscaled bf16 THWC frames.
+weights replicated, no data-path collective until ONE all-gather of the upscaled bf16 THWC frames (plus, with
+temporal overlap, one point-to-point message per batch boundary between the two owners).
 xGMI is fully connected point-to-point, so the all-gather is issued as a single collective per step
 (each peer link carries only that peer's shard).
 """
 import os
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -52,19 +53,38 @@ def all_gather_frames(local: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def gather_batches(owned: Sequence[torch.Tensor], owned_idx: Sequence[int], n_batches: int) -> List[torch.Tensor]:
-    """Reassemble per-batch outputs of equal shape from all ranks in batch order (ranks with fewer
-    batches contribute a zero placeholder that is dropped)."""
+def _agree_on_like(owned: Sequence[torch.Tensor], device) -> tuple:
+    """(shape, dtype) of one batch output, also on ranks that own none: a tiny MAX all-reduce of [dtype code, ndim, dims...]."""
+    codes = [torch.bfloat16, torch.float32, torch.float16, torch.float64]
+    info = torch.zeros(10, dtype=torch.int64, device=device)
+    if owned:
+        like = owned[0]
+        info[0] = codes.index(like.dtype) + 1
+        info[1] = like.dim()
+        info[2:2 + like.dim()] = torch.tensor(like.shape, dtype=torch.int64)
+    dist.all_reduce(info, op=dist.ReduceOp.MAX)
+    vals = info.tolist()
+    if vals[0] == 0:
+        raise ValueError("gather_batches: no rank owns a batch")
+    return tuple(vals[2:2 + vals[1]]), codes[vals[0] - 1]
+
+
+def gather_batches(owned: Sequence[torch.Tensor], owned_idx: Sequence[int], n_batches: int,
+                   device: Optional[torch.device] = None) -> List[torch.Tensor]:
+    """Reassemble per-batch outputs of equal shape from all ranks in batch order.  Ranks with fewer batches -- or none,
+    when n_batches < world -- contribute a zero placeholder that is dropped (``device`` tells such a rank where)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return list(owned)
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world = dist.get_world_size()
     per_rank = (n_batches + world - 1) // world
-    like = owned[0]
+    dev = owned[0].device if owned else torch.device(device if device is not None else
+                                                     ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    shape, dtype = _agree_on_like(owned, dev)
+    F = shape[0]
     result = [None] * n_batches
     for j in range(per_rank):
-        mine = owned[j] if j < len(owned) else torch.zeros_like(like)
+        mine = owned[j] if j < len(owned) else torch.zeros(shape, dtype=dtype, device=dev)
         gathered = all_gather_frames(mine)
-        F = like.shape[0]
         for r in range(world):
             b = j * world + r
             if b < n_batches:
@@ -72,22 +92,43 @@ def gather_batches(owned: Sequence[torch.Tensor], owned_idx: Sequence[int], n_ba
     return result
 
 
+def exchange_heads_p2p(heads: dict, boundaries: Sequence[int], shape: tuple, device, dtype=torch.bfloat16) -> dict:
+    """Overlap heads travel point to point: the owner of batch i (rank i mod world) sends the first ``overlap`` decoded
+    frames of batch i to the owner of batch i-1, which blends them into its tail (pipeline.upscale phase 3).  One
+    bf16 message of overlap x H x W x 3 per batch boundary over the direct xGMI link of that rank pair -- 149 MB per
+    boundary at 4K / overlap 3 -- instead of a dense all-reduce over every batch of the clip (round 1: 2.4 GB at
+    BASELINE config 4, growing with clip length).  Returns {i: head} for the heads THIS rank has to blend."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ops, recv = [], {}
+    for i in boundaries:                               # every rank walks the same boundary list in the same order
+        src, dst = i % world, (i - 1) % world
+        if src == dst:
+            continue
+        if rank == src:
+            ops.append(dist.P2POp(dist.isend, heads[i].to(device=device, dtype=dtype).contiguous().view(torch.int16), dst))
+        elif rank == dst:
+            buf = torch.empty(shape, dtype=dtype, device=device)
+            recv[i] = buf
+            ops.append(dist.P2POp(dist.irecv, buf.view(torch.int16), src))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return recv
+
+
 def upscale_sharded(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, **kw) -> torch.Tensor:
     """pipeline.upscale() with the temporal batches dealt round-robin to the ranks of the default process group;
     every rank returns the complete clip, identical to the single-rank result (same batch boundaries, the overlap
-    blend done by the owner of the blended frames).  Collectives: one small all-reduce of the overlap heads (only
-    with temporal_overlap > 0) and ONE all-gather of the upscaled bf16 frames."""
+    blend done by the owner of the blended frames).  Communication: one point-to-point message per batch boundary
+    (only with temporal_overlap > 0, exchange_heads_p2p) and ONE all-gather of the upscaled bf16 frames."""
     from . import pipeline
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return pipeline.upscale(images_thwc, runner, text_pos, **kw)
     rank, world = dist.get_rank(), dist.get_world_size()
+    dev = runner.dit.device
 
-    def exchange(heads: dict, n_batches: int, shape: tuple) -> dict:
-        dense = torch.zeros((n_batches,) + tuple(shape), dtype=torch.float32, device=images_thwc.device)
-        for i, h in heads.items():
-            dense[i] = h.float()                                   # disjoint owners: the sum is an exact copy
-        dist.all_reduce(dense)
-        return {i: dense[i] for i in range(n_batches)}
+    def exchange(heads: dict, boundaries: list, shape: tuple) -> dict:
+        return exchange_heads_p2p(heads, boundaries, shape, dev)
 
     final, spans = pipeline.upscale(images_thwc, runner, text_pos, batch_filter=lambda i: i % world == rank,
                                     exchange_heads=exchange, return_spans=True, **kw)

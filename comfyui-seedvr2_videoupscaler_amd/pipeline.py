@@ -86,7 +86,7 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
             batch_filter: Optional[Callable[[int], bool]] = None,
             progress: Optional[Callable[[str, int, int], None]] = None,
             noise_provider: Optional[Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None,
-            exchange_heads: Optional[Callable[[dict, int, tuple], dict]] = None,
+            exchange_heads: Optional[Callable[[dict, list, tuple], dict]] = None,
             return_spans: bool = False):
     """images [T, H, W, 3] in [0, 1] (any float dtype, on the runner's device) -> upscaled [T, H', W', 3] in [0, 1].
 
@@ -117,7 +117,10 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
     for i, plan in enumerate(plans):
         if i not in owned:
             if input_noise_scale > 0 and i < max(mine, default=-1):
-                torch.randn(transformed_shape(images, plan, resolution, max_resolution), dtype=dt, device=dev)
+                c, t, h, w = transformed_shape(images, plan, resolution, max_resolution)
+                # same shape AND strides as prepare_batch's result (a [T, C, H, W] buffer viewed c t h w): the CPU generator
+                # consumes its stream differently for contiguous and strided outputs
+                torch.randn_like(torch.empty((t, c, h, w), dtype=dt, device=dev).permute(1, 0, 2, 3))
             continue
         x = prepare_batch(images, plan, resolution, max_resolution, dtype=dt)
         if input_noise_scale > 0:
@@ -179,7 +182,10 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
         write += n_new
 
     if exchange_heads is not None and overlap > 0:
-        for i, head in exchange_heads(heads, len(plans), (overlap, true_h, true_w, 3)).items():
+        # batch boundaries that carry an overlap blend -- a function of the plans alone, so every rank derives the same list
+        # and the point-to-point exchange posts matching sends and receives
+        boundaries = [i for i, plan in enumerate(plans) if i > 0 and 0 < overlap < plan.end - plan.start and starts[i] >= overlap]
+        for i, head in exchange_heads(heads, boundaries, (overlap, true_h, true_w, 3)).items():
             if (i - 1) in spans and i not in spans:
                 w = starts[i]
                 final[w - overlap:w] = transforms.blend_overlapping_frames(final[w - overlap:w], head.to(final), overlap)

@@ -185,6 +185,48 @@ class VideoVAEEngine:
         self.dec_conv_out = conv("decoder.conv_out")
         self._iota = {}
 
+    # ------------------------------------------------------------------ nn.Module-shaped probes
+    # The reference's phase code asks its models where and what they are the nn.Module way -- next(model.parameters()).device
+    # / .dtype (generation_phases.py:298, 620, 708-712), .eval(), .to(device), .requires_grad_(False): answered here so that
+    # code can drive the engines unchanged.  Weights are resident, pre-tiled tensors; moving them is not supported.
+    def parameters(self):
+        seen = set()
+
+        def walk(o):
+            if torch.is_tensor(o):
+                if o.is_floating_point() and id(o) not in seen:
+                    seen.add(id(o))
+                    yield o
+            elif isinstance(o, dict):
+                for v in o.values():
+                    yield from walk(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    yield from walk(v)
+            elif hasattr(o, "__dataclass_fields__"):
+                for f in o.__dataclass_fields__:
+                    yield from walk(getattr(o, f))
+        for name, v in vars(self).items():
+            if name not in ("ops", "cfg") and not name.startswith("_"):
+                yield from walk(v)
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    def to(self, *args, **kwargs):
+        dev = next((a for a in args if isinstance(a, (str, torch.device))), kwargs.get("device"))
+        if dev is not None and torch.device(dev).type != self.device.type:
+            raise NotImplementedError(f"{type(self).__name__} weights are resident on {self.device} (pre-tiled for the MFMA kernels); "
+                                      "build a new engine on the target device instead of moving this one")
+        return self
+
+    @property
+    def dtype(self):
+        return self.ops.act_dtype
+
     # ------------------------------------------------------------------ layer primitives
     def _conv(self, cw: _Conv, x: torch.Tensor, st: dict, first: bool, resid: Optional[torch.Tensor] = None,
               gn: bool = False):

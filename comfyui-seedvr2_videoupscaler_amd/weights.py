@@ -28,12 +28,16 @@ def _gen(device, seed):
 
 
 class _Maker:
+    """device "meta": shapes only (no generator, no memory) -- how checkpoint.py enumerates the expected key set."""
+
     def __init__(self, device, seed, dtype=torch.bfloat16):
         self.device = torch.device(device)
-        self.g = _gen(self.device, seed)
+        self.g = None if self.device.type == "meta" else _gen(self.device, seed)
         self.dtype = dtype
 
     def normal(self, shape, std, mean=0.0):
+        if self.g is None:
+            return torch.empty(shape, device="meta", dtype=self.dtype)
         t = torch.randn(shape, generator=self.g, device=self.device, dtype=torch.float32)
         return (t * std + mean).to(self.dtype)
 

@@ -95,3 +95,44 @@ def test_vae_checkpoint_with_2d_weights_inflates_to_engine_shapes(tmp_path):
         assert out[k].shape == v.shape, k
         if v.dim() == 5 and "resnets.0.conv1" in k and v.shape[2] == 3:
             assert torch.equal(out[k][:, :, -1], v[:, :, -1]) and float(out[k][:, :, :-1].abs().sum()) == 0
+
+
+def test_7b_checkpoint_is_detected_and_builds_the_7b_engine(tmp_path):
+    """A SeedVR2-7B-family state dict (dit_7b: biased GELU MLPs, pixel RoPE, separate weights in every block) written as
+    safetensors goes through build_engines() into the DIT_7B graph: the family is detected from the tensors, the 10 RoPE
+    frequencies per axis (not the 3B's 21) are zero-filled when missing, and the engine equals one built from the dict."""
+    from safetensors.torch import save_file
+    ck, weights, config, dit = sub("checkpoint"), sub("weights"), sub("config"), sub("dit")
+    cfg = config.DIT_7B_TINY
+    sd = weights.synth_dit_state_dict(cfg, seed=5)
+    assert ck.detect_dit_config(sd) is config.DIT_7B                       # by the mlp biases, whatever the width
+    assert ck.detect_dit_config(weights.synth_dit_state_dict(config.DIT_TINY)) is config.DIT_3B
+    assert ck.detect_dit_config({}, "seedvr2_ema_7b_fp16.safetensors") is config.DIT_7B
+    path = str(tmp_path / "seedvr2_ema_7b_sharp_fp16.safetensors")         # round 1 refused any file name containing "7b"
+    save_file({k: v.contiguous() for k, v in sd.items()}, path)
+    ops = TorchOps("cpu", act_dtype=torch.float32)
+    eng, _ = ck.build_engines(ops, dit_path=path, dit_cfg=cfg)
+    g = torch.Generator().manual_seed(0)
+    vid, txt = torch.randn(2, 8, 12, 33, generator=g), torch.randn(58, 5120, generator=g)
+    assert torch.equal(eng.forward(vid, txt, 1000.0), dit.NaDiTEngine(cfg, sd, ops).forward(vid, txt, 1000.0))
+    no_freqs = {k: v for k, v in sd.items() if not k.endswith("rope.rope.freqs")}
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        out = ck.prepare_dit_state_dict(no_freqs, cfg)
+    assert out["blocks.0.attn.rope.rope.freqs"].shape == (cfg.rope_freqs,) == (10,)
+
+
+def test_vae_checkpoint_missing_shortcut_is_reported():
+    """The expected key set comes from the real block widths (meta device), so a checkpoint without the 1x1x1
+    conv_shortcut of a width-changing resnet is refused at ingest (round 1 derived the keys from an equal-width model and
+    the engine then read the residual with the wrong stride); the engine itself refuses too."""
+    ck, weights, config, vae = sub("checkpoint"), sub("weights"), sub("config"), sub("vae")
+    cfg = config.VAE_TINY                                                   # (64, 64, 128, 128): one width change per side
+    sd = weights.synth_vae_state_dict(cfg, seed=2)
+    shortcuts = [k for k in sd if "conv_shortcut" in k]
+    assert shortcuts and set(ck.vae_expected_keys(cfg)) == set(sd)
+    broken = {k: v for k, v in sd.items() if k not in shortcuts[:2]}
+    with pytest.raises(KeyError):
+        ck.prepare_vae_state_dict(broken, cfg)
+    with pytest.raises(KeyError):
+        vae.VideoVAEEngine(cfg, broken, TorchOps("cpu", act_dtype=torch.float32))

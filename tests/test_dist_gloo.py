@@ -63,7 +63,39 @@ def test_split_frames_and_round_robin():
     assert d.batch_indices(8, 3, 8) == [3] and d.batch_indices(5, 1, 2) == [1, 3]
 
 
-def _pipeline_worker(rank, world, port, q):
+def _empty_owner_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from conftest import sub as _sub
+    d = _sub("dist")
+    d.init_from_env(backend="gloo")
+    owned_idx = d.batch_indices(1, rank, world)                       # rank 1 owns nothing
+    owned = [torch.full((2, 3, 4, 3), 5.0, dtype=torch.bfloat16) for _ in owned_idx]
+    full = d.gather_batches(owned, owned_idx, 1, device="cpu")
+    q.put((rank, len(full) == 1 and float(full[0].float().mean()) == 5.0 and full[0].shape == (2, 3, 4, 3)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_batches_with_a_rank_that_owns_nothing():
+    """n_batches < world: the idle rank learns shape and dtype from the group and contributes a placeholder (round 1
+    indexed owned[0] there and deadlocked the others in the all-gather)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_owner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
+def _pipeline_worker(rank, world, port, q, noise=0.0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
@@ -73,25 +105,29 @@ def _pipeline_worker(rank, world, port, q):
     d = _sub("dist")
     d.init_from_env(backend="gloo")
     images = torch.rand(23, 16, 24, 3, generator=torch.Generator().manual_seed(5))
-    kw = dict(resolution=32, batch_size=7, uniform_batch_size=True, temporal_overlap=2, color_correction="wavelet")
+    kw = dict(resolution=32, batch_size=7, uniform_batch_size=True, temporal_overlap=2, color_correction="wavelet",
+              input_noise_scale=noise)
     out = d.upscale_sharded(images, _IdentityRunner(), torch.zeros(58, 8), **kw)
     q.put((rank, out.float()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_pipeline_equals_single_rank_with_overlap_blend():
-    """Sharded four-phase pipeline (batches dealt round-robin, overlap heads exchanged, frames all-gathered)
-    == the single-rank pipeline, bit for bit, on both ranks."""
+@pytest.mark.parametrize("world,noise", [(2, 0.0), (3, 0.0), (2, 0.5)])
+def test_sharded_pipeline_equals_single_rank_with_overlap_blend(world, noise):
+    """Sharded four-phase pipeline (batches dealt round-robin, overlap heads sent point to point to the neighbouring
+    batch's owner, frames all-gathered) == the single-rank pipeline, bit for bit, on every rank; with input noise the
+    ranks draw-and-discard the noise of the batches they skip, so every batch sees the single-rank run's noise."""
     from test_glue import _IdentityRunner
     pipeline = sub("pipeline")
     images = torch.rand(23, 16, 24, 3, generator=torch.Generator().manual_seed(5))
     want = pipeline.upscale(images, _IdentityRunner(), torch.zeros(58, 8), resolution=32, batch_size=7,
-                            uniform_batch_size=True, temporal_overlap=2, color_correction="wavelet").float()
+                            uniform_batch_size=True, temporal_overlap=2, color_correction="wavelet",
+                            input_noise_scale=noise).float()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q, noise)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

@@ -204,3 +204,23 @@ def test_pipeline_batch_filter_partitions_the_output():
     parts = [pl.upscale(images, _IdentityRunner(), torch.zeros(58, 8), batch_filter=lambda i, r=r: i % 2 == r, **kw) for r in (0, 1)]
     assert torch.equal(parts[0] + parts[1], full)
     assert float((parts[0] * parts[1]).abs().max()) == 0.0
+
+
+def test_transformed_shape_and_phase1_noise_stream():
+    """pipeline.transformed_shape predicts prepare_batch's result shape (what a rank draws-and-discards for the batches
+    it skips), and phase 1's input noise is a function of ``seed`` alone (seed + 1e6 before the first batch,
+    generation_phases.py:327-330), not of whatever the global generator held."""
+    pipeline = sub("pipeline")
+    g = torch.Generator().manual_seed(2)
+    images = torch.rand(13, 20, 36, 3, generator=g)
+    plans, _ = pipeline.plan_batches(13, 5, 1, True)
+    for res, mx in ((40, 0), (64, 100), (30, 0)):
+        for plan in plans:
+            assert tuple(pipeline.prepare_batch(images, plan, res, mx).shape) == pipeline.transformed_shape(images, plan, res, mx)
+    kw = dict(resolution=32, batch_size=5, temporal_overlap=1, color_correction="none", input_noise_scale=0.8, seed=7)
+    torch.manual_seed(123)
+    a = pipeline.upscale(images, _IdentityRunner(), torch.zeros(58, 8), **kw)
+    torch.manual_seed(456)
+    b = pipeline.upscale(images, _IdentityRunner(), torch.zeros(58, 8), **kw)
+    c = pipeline.upscale(images, _IdentityRunner(), torch.zeros(58, 8), **{**kw, "seed": 8})
+    assert torch.equal(a, b) and not torch.equal(a, c)

@@ -16,7 +16,7 @@ import os
 import pytest
 import torch
 
-from conftest import sub, rel_err, GOLDEN
+from conftest import sub, rel_err, GOLDEN, ROOT as ROOT_DIR
 
 pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
@@ -294,3 +294,53 @@ def test_vae_full_tile_size_properties(hip):
     z = (torch.randn(5, 64, 64, 16, generator=g, device="cuda")).to(BF16)        # 512-px tile through the decoder
     d = eng.decode(z)
     assert d.shape == (3, 17, 512, 512) and torch.equal(d, eng.decode(z, latents_per_slice=2))
+
+
+def _nccl_worker(rank, world, port, q):
+    import sys as _sys
+    _sys.path.insert(0, ROOT_DIR)
+    _sys.path.insert(0, os.path.join(ROOT_DIR, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from conftest import sub as _sub
+    import torch.distributed as _dist
+    d = _sub("dist")
+    d.init_from_env(backend="nccl")
+    torch.cuda.set_device(rank)
+    config, weights, dit, vae, runner, pipeline = (_sub(n) for n in ("config", "weights", "dit", "vae", "runner", "pipeline"))
+    ops = _sub("ops").HipOps(f"cuda:{rank}")
+    dcfg, vcfg = config.DIT_TINY, config.VAEConfig(block_out_channels=(128, 128, 128, 128))
+    r = runner.VideoDiffusionInfer(runner.default_config(dcfg, vcfg))
+    r.dit = dit.NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, seed=21), ops)
+    r.vae = vae.VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, seed=22), ops)
+    images = torch.rand(23, 24, 40, 3, generator=torch.Generator().manual_seed(4)).cuda(rank)
+    kw = dict(resolution=48, batch_size=5, uniform_batch_size=True, temporal_overlap=2, color_correction="lab")
+    out = d.upscale_sharded(images, r, weights.synth_text_embedding().cuda(rank), **kw)
+    want = pipeline.upscale(images, r, weights.synth_text_embedding().cuda(rank), **kw) if rank == 0 else None
+    q.put((rank, out.float().cpu(), None if want is None else want.float().cpu()))
+    _dist.barrier()
+    _dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs on one node (RCCL over xGMI)")
+def test_two_gpu_rccl_sharded_pipeline_equals_single_gpu():
+    """One process per GPU, torch.distributed backend "nccl" (= RCCL): the sharded pipeline (round-robin temporal batches,
+    point-to-point overlap heads, one all-gather of the upscaled frames) returns on every rank exactly what one GPU
+    computes alone -- every kernel on the path is deterministic, so the comparison is bit-exact."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (o, w) for r, o, w in (q.get(timeout=600) for _ in procs)}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = res[0][1]
+    assert torch.equal(res[0][0], want) and torch.equal(res[1][0], want)
