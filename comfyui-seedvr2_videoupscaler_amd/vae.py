@@ -267,7 +267,7 @@ class VideoVAEEngine:
                          ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups if gn else 0,
                          W_frag=None if cw.thin else cw.w_frag)
             stats = r[1] if gn else None
-        if carry > 0:                                       # per-conv memory for the next slice
+        if carry > 0 and not st.get("__last_slice__", False):   # per-conv memory for the next slice (none follows the last one)
             if T >= carry:
                 st[cw.name] = x[T - carry:].clone()
             else:
@@ -394,7 +394,9 @@ class VideoVAEEngine:
             per_frame = H * W * self.cfg.block_out_channels[0] * 2
             frames_per_slice = max(4, int(self.act_budget_bytes // per_frame) // 4 * 4)
         st, outs = {}, []
-        for i, (a, b) in enumerate(self._slices(T, 4, frames_per_slice)):
+        slices = self._slices(T, 4, frames_per_slice)
+        for i, (a, b) in enumerate(slices):
+            st["__last_slice__"] = i == len(slices) - 1      # its tail frames would never be read: skip the copies
             outs.append(self._encoder_slice(x_thwc[a:b], st, i == 0))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
@@ -406,7 +408,9 @@ class VideoVAEEngine:
             per_latent = (h * s) * (w * s) * 2 * self.cfg.block_out_channels[0] * 2 * self.cfg.temporal_downsample_factor
             latents_per_slice = max(1, int(self.act_budget_bytes // per_latent))
         st, outs = {}, []
-        for i, (a, b) in enumerate(self._slices(Tl, 1, latents_per_slice)):
+        slices = self._slices(Tl, 1, latents_per_slice)
+        for i, (a, b) in enumerate(slices):
+            st["__last_slice__"] = i == len(slices) - 1
             outs.append(self._decoder_slice(z_thwc[a:b], st, i == 0))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
