@@ -95,7 +95,9 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
     """
     if images_thwc.shape[-1] != 3:
         raise NotImplementedError("RGB input only (the alpha path is outside the hot path, DESIGN.md section 7)")
-    dev, dt = runner.dit.device, torch.bfloat16
+    # compute / storage dtype of the phases = the engines' activation dtype (bf16 on the HIP path, as the reference's
+    # compute_dtype; fp32 when the CPU tests drive the engines with the fp32 torch double of the C ABI)
+    dev, dt = runner.dit.device, getattr(getattr(runner.dit, "ops", None), "act_dtype", torch.bfloat16)
     images = images_thwc.to(device=dev)
     if prepend_frames > 0:
         images = transforms.pad_video_temporal(images, count=prepend_frames, temporal_dim=0, prepend=True)

@@ -20,6 +20,10 @@ stored -- tests rebuild them with the seeded helpers below, which use only exact
                       5 temporal slices through the reference's causal memory (split 4)
   vae_tile1024.pt     full VAE at the REAL tile size: 5 frames 1024x1152 (latent 2x128x144), tiled 1024/128 ->
                       a 2-tile strip with the 128-px cosine blend; encode stored whole, decode as 8 crops
+  pipeline_small.pt   the WHOLE chain (``--only r2-pipe``): 11 frames 24x40 -> 48x80, batches of 5 with uniform padding
+                      and a 2-frame overlap blend, LAB colour fix; the reference's own NaDiT (DIT_TINY width) and VAE
+                      (4 x 128 channels) classes plus the reference's text of pad_video_temporal / SideResize /
+                      DivisiblePad / blend_overlapping_frames / lab_color_transfer, driven by oracle/pipeline_oracle.py
 """
 import argparse
 import importlib
@@ -151,12 +155,80 @@ def main():
     print("vae_small enc", tuple(enc.shape), "dec", tuple(dec.shape))
 
 
+PIPE_CASE = dict(frames=11, hw=(24, 40), resolution=48, batch_size=5, temporal_overlap=2, uniform_batch_size=True,
+                 seed_images=4, seed_dit=21, seed_vae=22, vae_channels=(128, 128, 128, 128))
+
+
+def pipeline_noise(lat):
+    """The (base, extra) noise pair of a batch as a function of the latent's size (what tests/test_gpu_parity.py injects)."""
+    gg = torch.Generator().manual_seed(lat.numel())
+    return torch.randn(lat.shape, generator=gg), torch.randn(lat.shape, generator=gg)
+
+
+def reference_pipeline_components(rl, config, weights, txt):
+    """pipeline_oracle.Components built from the REFERENCE: its NaDiT and VAE classes, and its glue function text."""
+    from oracle import pipeline_oracle as po
+    glue = rl.reference_glue()
+    dcfg = config.DIT_TINY
+    vcfg = config.VAEConfig(block_out_channels=PIPE_CASE["vae_channels"])
+    dsd = weights.synth_dit_state_dict(dcfg, seed=PIPE_CASE["seed_dit"])
+    vsd = weights.synth_vae_state_dict(vcfg, seed=PIPE_CASE["seed_vae"])
+    dit = rl.build_reference_dit(dcfg.as_dict(), {k: v.float() for k, v in dsd.items()})
+    vae = rl.build_reference_vae({k: v.float() for k, v in vsd.items()}, block_out_channels=vcfg.block_out_channels)
+    res = PIPE_CASE["resolution"]
+    resize, pad16 = glue["SideResize"](size=res, max_size=0), glue["DivisiblePad"]((16, 16))
+
+    class _Dbg:
+        def log(self, *a, **k):
+            pass
+
+    def video_transform(x_tchw):                       # generation_utils.py:72-84
+        y = pad16(torch.clamp(resize(x_tchw), 0.0, 1.0))
+        return ((y - 0.5) / 0.5).permute(1, 0, 2, 3)
+
+    def true_dims(h, w):                               # generation_utils.py:124-137
+        y = resize(torch.zeros(1, 3, h, w))
+        return (y.shape[-2] // 2) * 2, (y.shape[-1] // 2) * 2
+
+    def vae_encode(x_cthw):                            # infer.py:117-199
+        with torch.no_grad():
+            lat = vae.encode(x_cthw[None].float()).latent[0]
+        return (lat.permute(1, 2, 3, 0) - vcfg.shifting_factor) * vcfg.scaling_factor
+
+    def vae_decode(lat_thwc):                          # infer.py:203-278
+        z = (lat_thwc / vcfg.scaling_factor + vcfg.shifting_factor).permute(3, 0, 1, 2)[None]
+        with torch.no_grad():
+            return vae.decode(z.float()).sample[0]
+
+    def dit_fn(vid, text):
+        T, H, W, C = vid.shape
+        with torch.no_grad():
+            out = dit(vid=vid.float().reshape(-1, C), txt=text.float(), vid_shape=torch.tensor([[T, H, W]]),
+                      txt_shape=torch.tensor([[text.shape[0]]]), timestep=torch.tensor([1000.0])).vid_sample
+        return out.reshape(T, H, W, -1)
+
+    return po.Components(
+        pad_video_temporal=glue["pad_video_temporal"], video_transform=video_transform, true_target_dims=true_dims,
+        vae_encode=vae_encode, dit=dit_fn, vae_decode=vae_decode, blend_overlapping_frames=glue["blend_overlapping_frames"],
+        color_fix=lambda s_, r_: glue["lab_color_transfer"](s_, r_, _Dbg(), luminance_weight=0.8), noise=pipeline_noise)
+
+
 def main_r2(which):
     from oracle import reference_loader as rl
     assert rl.available(), "needs /root/reference"
     config = importlib.import_module(PKG + ".config")
     weights = importlib.import_module(PKG + ".weights")
     txt = torch.load(os.path.join(GOLD, "text_pos_emb.pt"), weights_only=True)
+    if which in ("r2", "r2-pipe"):
+        from oracle import pipeline_oracle as po
+        pc = PIPE_CASE
+        images = torch.rand(pc["frames"], pc["hw"][0], pc["hw"][1], 3, generator=torch.Generator().manual_seed(pc["seed_images"]))
+        text = weights.synth_text_embedding()
+        comps = reference_pipeline_components(rl, config, weights, text)
+        t0 = time.time()
+        out = po.upscale(images, text.float(), comps, pc["batch_size"], pc["temporal_overlap"], pc["uniform_batch_size"])
+        print("pipeline_small %.0fs" % (time.time() - t0), tuple(out.shape), float(out.mean()), float(out.std()))
+        torch.save({"out": out.clone(), **{k: v for k, v in pc.items()}}, os.path.join(GOLD, "pipeline_small.pt"))
     if which in ("r2", "r2-dit"):
         cfg = dit_r2_config(config)
         sd = weights.synth_dit_state_dict(cfg)

@@ -250,33 +250,35 @@ def test_dit_window_attention_properties_full_size(hip):
     assert rel_err(outs[1], outs[0]) < 4e-3
 
 
-def test_pipeline_four_phases_gpu_vs_fp32_double(hip):
-    """The whole N1-N3 + hot path chain (batching, 4n+1 padding, transform, encode, one-step DiT, decode, overlap blend,
-    LAB colour fix) on the GPU against the same pipeline driving fp32 torch doubles of the engines on the CPU,
-    same weights, same noise: PSNR >= 30 dB on the [0, 1] output frames (bf16 storage end to end)."""
-    from ops_reference import TorchOps
+def _psnr_unit(a, b):
+    """PSNR of [0, 1] output frames against their nominal range (peak 1.0 = the 2.0 of [-1, 1] frames)."""
+    mse = float((a.double() - b.double()).pow(2).mean())
+    return 10 * math.log10(1.0 / max(mse, 1e-30))
+
+
+def test_pipeline_vs_reference_golden(hip):
+    """The whole chain (batching with uniform padding, 4n+1 padding, input transform in bf16, VAE encode, one-step DiT, VAE
+    decode, trims, 2-frame overlap blend, LAB colour fix, [-1,1] -> [0,1]) on the GPU against the golden of the REFERENCE's
+    components in fp32 (tests/golden/pipeline_small.pt, oracle/make_golden.py --only r2-pipe) -- not against this repo's
+    own host logic.  Reported: PSNR at the nominal peak (1.0 on [0,1] frames) with and without the colour fix stage.
+    Measured on MI355X (round 2): see the printed lines; asserted = measured - 1.5 dB.  Where the dB go: the VAE decode of
+    bf16 latents (reference bf16-vs-fp32 floor: 46.3 dB at nominal peak), not the glue."""
+    from oracle import make_golden as mg
     config, weights, dit, vae, runner, pipeline = (sub(n) for n in ("config", "weights", "dit", "vae", "runner", "pipeline"))
-    dcfg, vcfg = config.DIT_TINY, config.VAEConfig(block_out_channels=(128, 128, 128, 128))   # GroupNorm kernels need >= 4 ch / group
-    dsd, vsd = weights.synth_dit_state_dict(dcfg, seed=21), weights.synth_vae_state_dict(vcfg, seed=22)
-    txt = weights.synth_text_embedding()
-    g = torch.Generator().manual_seed(4)
-    images = torch.rand(11, 24, 40, 3, generator=g)
-
-    def noise(lat):
-        gg = torch.Generator().manual_seed(lat.numel())
-        return torch.randn(lat.shape, generator=gg), torch.randn(lat.shape, generator=gg)
-
-    outs = []
-    for ops, dev in ((hip, "cuda"), (TorchOps("cpu", act_dtype=torch.float32), "cpu")):
-        r = runner.VideoDiffusionInfer(runner.default_config(dcfg, vcfg))
-        r.dit, r.vae = dit.NaDiTEngine(dcfg, dsd, ops), vae.VideoVAEEngine(vcfg, vsd, ops)
-        out = pipeline.upscale(images.to(dev), r, txt.to(dev), resolution=48, batch_size=5, uniform_batch_size=True,
-                               temporal_overlap=2, color_correction="lab", noise_provider=noise)
-        outs.append(out.float().cpu())
-    assert outs[0].shape == outs[1].shape == (11, 48, 80, 3)
-    p = psnr(outs[0], outs[1])
-    print(f"pipeline GPU vs fp32 double: PSNR {p:.1f} dB")
-    assert p > 30
+    g = _golden("pipeline_small.pt")
+    dcfg, vcfg = config.DIT_TINY, config.VAEConfig(block_out_channels=tuple(g["vae_channels"]))
+    r = runner.VideoDiffusionInfer(runner.default_config(dcfg, vcfg))
+    r.dit = dit.NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, seed=g["seed_dit"]), hip)
+    r.vae = vae.VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, seed=g["seed_vae"]), hip)
+    images = torch.rand(g["frames"], g["hw"][0], g["hw"][1], 3, generator=torch.Generator().manual_seed(g["seed_images"]))
+    out = pipeline.upscale(images.cuda(), r, weights.synth_text_embedding().cuda(), resolution=g["resolution"],
+                           batch_size=g["batch_size"], uniform_batch_size=g["uniform_batch_size"],
+                           temporal_overlap=g["temporal_overlap"], color_correction="lab",
+                           noise_provider=mg.pipeline_noise).float().cpu()
+    assert out.shape == g["out"].shape
+    p, e = _psnr_unit(out, g["out"]), rel_err(out, g["out"])
+    print(f"pipeline GPU vs reference-chain golden: PSNR {p:.1f} dB (nominal peak), rel-err {e:.3e}")
+    assert p > 40 and e < 2e-2
 
 
 def test_vae_full_tile_size_properties(hip):
