@@ -261,8 +261,11 @@ def test_pipeline_vs_reference_golden(hip):
     decode, trims, 2-frame overlap blend, LAB colour fix, [-1,1] -> [0,1]) on the GPU against the golden of the REFERENCE's
     components in fp32 (tests/golden/pipeline_small.pt, oracle/make_golden.py --only r2-pipe) -- not against this repo's
     own host logic.  Reported: PSNR at the nominal peak (1.0 on [0,1] frames) with and without the colour fix stage.
-    Measured on MI355X (round 2): see the printed lines; asserted = measured - 1.5 dB.  Where the dB go: the VAE decode of
-    bf16 latents (reference bf16-vs-fp32 floor: 46.3 dB at nominal peak), not the glue."""
+    Measured on MI355X (round 2): 48.2 dB at the nominal peak, rel-err 6.9e-3; asserted = measured - 1.5 dB.  Where the dB
+    go: the VAE decode in bf16 storage alone measures 49.4 / 50.3 dB at the same peak on exact inputs (the 17-frame and the
+    1024-px-tile tests above; rel-err 1.0e-2), encode + DiT errors arriving in its input cost the rest; the glue is exact
+    (tests/test_pipeline_oracle.py).  The reference's own bf16 path sits at 46.3 dB for the decode alone (BASELINE.md
+    section 2), so 50 dB end to end is below the bf16 storage floor of this architecture with random-initialised weights."""
     from oracle import make_golden as mg
     config, weights, dit, vae, runner, pipeline = (sub(n) for n in ("config", "weights", "dit", "vae", "runner", "pipeline"))
     g = _golden("pipeline_small.pt")
@@ -278,7 +281,7 @@ def test_pipeline_vs_reference_golden(hip):
     assert out.shape == g["out"].shape
     p, e = _psnr_unit(out, g["out"]), rel_err(out, g["out"])
     print(f"pipeline GPU vs reference-chain golden: PSNR {p:.1f} dB (nominal peak), rel-err {e:.3e}")
-    assert p > 40 and e < 2e-2
+    assert p > 46.5 and e < 1.1e-2
 
 
 def test_vae_full_tile_size_properties(hip):
