@@ -317,7 +317,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}",
                        "frames_per_step_per_gpu": frames if not sharded else f"{frames} per clip, 8 batches of 17 shared by the ranks",
-                       "pixels": [H, W], "latent": [Tl, hl, wl], "vae_tiled": tiled, "parallelism": f"dp{world}",
+                       "pixels": [H, W], "latent": [Tl, hl, wl] if not sharded else [(CFG4["batch_size"] - 1) // 4 + 1, hl, wl],
+                       "vae_tiled": tiled, "parallelism": f"dp{world}",
                        "weights": f"random-init SeedVR2-{family} + video_vae_v3 architecture (seeded)"},
             "useful_frames_per_s": useful_per_step * args.steps / dt,
             "algorithmic_tflop_per_step": f_step / 1e12,

@@ -42,9 +42,9 @@ def split_frames(n_frames: int, batch_size: int) -> List[tuple]:
     return [(s, min(s + batch_size, n_frames)) for s in range(0, n_frames, batch_size)]
 
 
-def all_gather_frames(local: torch.Tensor) -> torch.Tensor:
+def all_gather_frames(local: torch.Tensor, force: bool = False) -> torch.Tensor:
     """local [F, H, W, 3] (same F on every rank) -> [world * F, H, W, 3] in rank order."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return local
     world = dist.get_world_size()
     local = local.contiguous()
@@ -122,7 +122,8 @@ def upscale_sharded(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *
     blend done by the owner of the blended frames).  Communication: one point-to-point message per batch boundary
     (only with temporal_overlap > 0, exchange_heads_p2p) and ONE all-gather of the upscaled bf16 frames."""
     from . import pipeline
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    force = kw.pop("force_collectives", False)         # tests: walk the collective code path even in a one-rank group
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return pipeline.upscale(images_thwc, runner, text_pos, **kw)
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = runner.dit.device
@@ -140,7 +141,7 @@ def upscale_sharded(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *
     cap = int(counts.max())
     padded = torch.zeros((cap,) + tuple(final.shape[1:]), dtype=final.dtype, device=final.device)
     padded[:mine.shape[0]] = mine
-    gathered = all_gather_frames(padded).reshape((world, cap) + tuple(final.shape[1:]))
+    gathered = all_gather_frames(padded, force).reshape((world, cap) + tuple(final.shape[1:]))
     table = torch.full((final.shape[0],), -1, dtype=torch.int64, device=final.device)          # frame -> owner rank
     for _, (a, b) in spans.items():
         table[a:b] = rank

@@ -327,6 +327,34 @@ def _nccl_worker(rank, world, port, q):
     _dist.destroy_process_group()
 
 
+def test_sharded_path_through_rccl_with_one_rank(hip):
+    """The collective calls of dist.upscale_sharded (all-reduce of the share sizes and of the frame-owner table, all-gather of
+    the padded bf16 frame shares) issued through RCCL on device tensors -- in a one-rank "nccl" group, which is what a 1-GPU box
+    can run; the world-2 test below needs a multi-GPU node.  Result == the plain single-GPU pipeline, bit for bit."""
+    import socket
+    import torch.distributed as tdist
+    config, weights, dit, vae, runner, pipeline, d = (sub(n) for n in ("config", "weights", "dit", "vae", "runner", "pipeline", "dist"))
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    tdist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        dcfg, vcfg = config.DIT_TINY, config.VAEConfig(block_out_channels=(128, 128, 128, 128))
+        r = runner.VideoDiffusionInfer(runner.default_config(dcfg, vcfg))
+        r.dit = dit.NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, seed=21), hip)
+        r.vae = vae.VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, seed=22), hip)
+        images = torch.rand(13, 24, 40, 3, generator=torch.Generator().manual_seed(4)).cuda()
+        txt = weights.synth_text_embedding().cuda()
+        kw = dict(resolution=48, batch_size=5, uniform_batch_size=True, temporal_overlap=2, color_correction="lab")
+        want = pipeline.upscale(images, r, txt, **kw)
+        got = d.upscale_sharded(images, r, txt, force_collectives=True, **kw)
+        assert torch.equal(got, want)
+    finally:
+        tdist.destroy_process_group()
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs on one node (RCCL over xGMI)")
 def test_two_gpu_rccl_sharded_pipeline_equals_single_gpu():
     """One process per GPU, torch.distributed backend "nccl" (= RCCL): the sharded pipeline (round-robin temporal batches,
