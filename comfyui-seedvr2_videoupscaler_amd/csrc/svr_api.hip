@@ -6,7 +6,6 @@
 
 // single translation unit: the kernel sources are included here so one hipcc call builds the library
 #include "svr_gemm.hip"
-#include "svr_gemm_pipe.hip"
 #include "svr_conv_halo.hip"
 #include "svr_conv_halo2.hip"
 #include "svr_attn_win.hip"
@@ -35,7 +34,6 @@ int svr_abi_version(void) { return SVR_ABI_VERSION; }
 
 int svr_set_option(const char* key, int32_t value) {
     if (!key) return fail("svr_set_option: null key");
-    if (!strcmp(key, "gemm_impl")) { g_gemm_impl = value; return 0; }
     if (!strcmp(key, "pipe_abl")) { g_pipe_abl = value; return 0; }
     if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
     if (!strcmp(key, "conv_lds")) { g_conv_lds_dbg = value; return 0; }

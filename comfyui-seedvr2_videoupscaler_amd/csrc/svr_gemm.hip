@@ -1,4 +1,6 @@
 // bf16 MFMA GEMM / implicit-GEMM causal Conv3d for gfx950 (MI355X).
+// (A second, deeper-pipelined 256x256x64 kernel was built in round 1, measured equal (-4 .. +5 %, profiles/r1_kbench_ab.txt)
+// and removed in round 2; its ablations are what located this kernel's limit: staging, not barriers or fragment reads.)
 //
 //   C[M, N] = A[M, K] * W[N, K]^T  (+ fused epilogue)
 //
@@ -289,10 +291,6 @@ static int launch(const svr_gemm_args& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-// pipelined 256x256x64 kernel (svr_gemm_pipe.hip)
-template <bool CONV> static int launch_pipe(const svr_gemm_args& a, hipStream_t s);
-static bool pipe_eligible(const svr_gemm_args& a);
-
 // LDS-halo conv kernel (svr_conv_halo.hip)
 template <int BN> static int launch_conv_halo(const svr_gemm_args& a, hipStream_t s);
 static bool conv_halo_eligible(const svr_gemm_args& a);
@@ -302,16 +300,8 @@ static bool conv_thin_eligible(const svr_gemm_args& a);
 static int launch_conv_thin(const svr_gemm_args& a, hipStream_t s);
 int g_conv_impl = [] { const char* e = getenv("SVR_CONV_IMPL"); return e ? atoi(e) : 0; }();   // 0 auto, 1 generic, 2 first halo kernel, 3 second halo kernel without W_frag
 
-// Kernel selection (svr_set_option("gemm_impl", v); env SVR_GEMM_IMPL seeds it): 0 = auto (the
-// measured-best kernel per problem class), 1 = one-barrier-per-K-tile kernel everywhere,
-// 2 = pipelined kernel wherever it is eligible.  Used by A/B measurements and the kernel tests.
-int g_gemm_impl = [] { const char* e = getenv("SVR_GEMM_IMPL"); return e ? atoi(e) : 0; }();
+// measurement-only ablation selector of the conv kernels in -DSVR_ABLATIONS builds (svr_set_option("pipe_abl"))
 int g_pipe_abl = [] { const char* e = getenv("SVR_PIPE_ABL"); return e ? atoi(e) : 0; }();
-static bool use_pipe_kernel(const svr_gemm_args& a) {
-    if (g_gemm_impl == 1) return false;
-    if (g_gemm_impl == 2) return true;
-    return false;      // auto: the pipelined kernel does not beat the simple one yet (profiles/kbench_r1_ab.txt)
-}
 
 // per-frame partial blocks of fused GroupNorm statistics for this problem (0: not produced)
 static int conv_gn_blocks(const svr_gemm_args& a);
@@ -339,8 +329,6 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     if ((g_conv_impl == 0 || g_conv_impl == 3) && conv_halo2_eligible(a)) return launch_conv_halo2(a, s);
     if (g_conv_impl != 1 && conv_halo_eligible(a))
         return a.N <= 32 ? launch_conv_halo<32>(a, s) : launch_conv_halo<128>(a, s);
-    if (pipe_eligible(a) && use_pipe_kernel(a))
-        return a.conv.enabled ? launch_pipe<true>(a, s) : launch_pipe<false>(a, s);
     // 256-wide tiles when N allows it (otherwise W is padded to a multiple of 128 rows) -- unless they would leave CUs idle:
     // the VAE attention's P V product (16384 x 512 x 16384) has only 128 such tiles for 256 CUs
     const bool wide = (a.N % 256) == 0 &&

@@ -172,10 +172,12 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
                      float scale, float shift, void* stream);
 
 /* ---- misc ------------------------------------------------------------------------------------ */
-/* Tuning / measurement knobs (no effect on results): "gemm_impl" 0 auto | 1 simple | 2 pipelined,
+/* Tuning / measurement knobs (no effect on results):
  * "conv_impl" 0 auto (LDS-halo kernels for stride-1 3x3 convs; register-streamed weights when W_frag is given)
  * | 1 generic implicit GEMM everywhere | 2 first (8x32-patch) halo kernel | 3 second halo kernel ignoring W_frag,
  * "conv_lds" dynamic LDS bytes to request for the halo kernel (> 80 KiB forces one workgroup per CU),
+ * "attn_impl" 0 auto (second-generation window kernel for head_dim 128 / windows <= 2048 rows) | 1 first kernel everywhere,
+ * "attn_variant" build variant of the second-generation window kernel (0 default = 8 waves; 1 / 3 / 4: see svr_attn_win.hip),
  * "pipe_abl" measurement-only ablations in -DSVR_ABLATIONS builds (non-zero values give garbage). */
 int svr_set_option(const char* key, int32_t value);
 const char* svr_last_error(void);

@@ -21,14 +21,9 @@ TOL_BF16 = 2.5e-3
 TOL_F32 = 1e-3
 
 
-@pytest.fixture(scope="module", params=["auto", "pipelined"])
-def hip(request):
-    """Every kernel test runs twice: with the library's own kernel choice and with the pipelined GEMM
-    forced wherever it is eligible, so both GEMM kernels stay parity-green."""
-    ops = sub("ops").HipOps("cuda:0")
-    ops.set_option("gemm_impl", 2 if request.param == "pipelined" else 0)
-    yield ops
-    ops.set_option("gemm_impl", 0)
+@pytest.fixture(scope="module")
+def hip():
+    return sub("ops").HipOps("cuda:0")
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +45,7 @@ def packed(n, k, seed=1):
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 256), (257, 64, 192), (1, 2560, 256),
                                    (513, 384, 64), (2048, 1536, 2560),
-                                   # pipelined 256x256 kernel (N % 256 == 0): 1, 3 and 5 K tiles, ragged M
+                                   # 256-wide N tiles: 1, 3 and 5 K tiles, ragged M
                                    (300, 256, 64), (700, 512, 192), (255, 512, 320), (58, 2560, 5120),
                                    # >= 256 tiles of 256x256: the wide-tile kernel (fewer tiles run 256x128 so no CU idles)
                                    (4100, 4096, 128), (16384, 512, 256)])
@@ -65,10 +60,9 @@ def test_gemm_bias(hip, ref, M, N, K, out_f32):
     assert rel_err(out.float(), want) < (TOL_F32 if out_f32 else TOL_BF16)
 
 
-def test_gemm_pipelined_race_screen(hip, ref):
-    """The software-pipelined kernel keeps LDS-DMA loads in flight across barriers: repeated launches of a
-    many-K-tile problem must be bit-identical (a RAW/WAR race shows up as run-to-run differences) and
-    correct."""
+def test_gemm_race_screen(hip, ref):
+    """The GEMM kernel keeps the LDS-DMA loads of the next K tile in flight under the MFMAs: repeated launches of a
+    many-K-tile problem must be bit-identical (a RAW/WAR race shows up as run-to-run differences) and correct."""
     M, N, K = 3000, 2560, 6912
     A = rnd(M, K)
     w, W = packed(N, K)
