@@ -137,6 +137,7 @@ def test_gemm_swiglu(hip, ref):
 
 
 # ------------------------------------------------------------------ implicit-GEMM causal conv
+CONV_PF_DEFAULT = 0          # the library's default for svr_set_option("conv_pf", ...)
 CONV_CASES = [
     # Cin, Cout, k, stride, pad(lo,hi), T, H, W, halo_frames
     (128, 128, (3, 3, 3), (1, 1, 1), (1, 1), 3, 10, 12, 0),
@@ -159,17 +160,20 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("conv_impl", [0, 2, -1], ids=["halo16x32", "halo8x32", "halo16x32_wreg"])
+@pytest.mark.parametrize("conv_impl", [0, 2, -1, -2], ids=["halo16x32", "halo8x32", "halo16x32_wreg", "wreg_prefetch"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3d_implicit_gemm(hip, ref, case, conv_impl):
     """conv_impl 0: the library's choice (16x32-voxel LDS-halo kernel where eligible), 2: the first (8x32) halo
     kernel; geometries neither accepts run on the generic implicit-GEMM kernel in both.  "wreg": the library's
-    choice with the fragment-ordered weight copy supplied (weights streamed to registers, not through LDS)."""
+    choice with the fragment-ordered weight copy supplied (weights streamed to registers, not through LDS);
+    "wreg_prefetch": the same with the halo-row fragment reads prefetched under the MFMA bursts (conv_pf 1)."""
     hip.set_option("conv_impl", max(conv_impl, 0))
+    hip.set_option("conv_pf", 1 if conv_impl == -2 else 0)
     try:
         _conv_case(hip, ref, case, frag=conv_impl < 0)
     finally:
         hip.set_option("conv_impl", 0)
+        hip.set_option("conv_pf", CONV_PF_DEFAULT)
 
 
 @pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[9], CONV_CASES[10], CONV_CASES[3], CONV_CASES[7]],
@@ -229,12 +233,18 @@ def test_conv3d_halo_kernel_race_screen_and_generic_agreement(hip):
         outs.append(out)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    # weights streamed to registers from the fragment-ordered copy: same MFMAs in the same order -> same bits
+    # weights streamed to registers from the fragment-ordered copy: same MFMAs in the same order -> same bits;
+    # both schedules of that kernel (fragment reads before the burst / prefetched under the previous bursts)
     Wf = hip.pack_conv_frag(Wp, 3, Cin, Cout)
-    for _ in range(3):
-        out = torch.empty(T, H, W, Cout, device="cuda", dtype=torch.float32)
-        hip.gemm(x, Wp, out, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, out_f32=True, W_frag=Wf)
-        assert torch.equal(out, outs[0])
+    try:
+        for pf in (0, 1):
+            hip.set_option("conv_pf", pf)
+            for _ in range(4):
+                out = torch.full((T, H, W, Cout), float("nan"), device="cuda", dtype=torch.float32)
+                hip.gemm(x, Wp, out, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, out_f32=True, W_frag=Wf)
+                assert torch.equal(out, outs[0]), pf
+    finally:
+        hip.set_option("conv_pf", CONV_PF_DEFAULT)
     hip.set_option("conv_impl", 1)
     try:
         gen = torch.empty(T, H, W, Cout, device="cuda", dtype=torch.float32)

@@ -8,6 +8,7 @@ rm -rf gpurun_out/prof_${WL}_$TAG
 timeout 1500 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${WL}_$TAG -o prof --output-format csv -- \
     python bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof_${WL}_$TAG.json 2> gpurun_out/prof_${WL}_$TAG.err
 echo "prof rc=$?"; cut -c1-600 gpurun_out/prof_${WL}_$TAG.json
+python tools/trace_by_shape.py $(find gpurun_out/prof_${WL}_$TAG -name "*kernel_trace.csv" | head -1) > gpurun_out/prof_${WL}_${TAG}_by_shape.txt 2>&1
 find gpurun_out/prof_${WL}_$TAG -name "*kernel_trace.csv" -delete
 python - <<PY
 import csv,re
