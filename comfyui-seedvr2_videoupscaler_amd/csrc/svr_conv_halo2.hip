@@ -44,50 +44,23 @@ static_assert(CG_D < CG_NB, "ring slot of unit k + D must not hold a unit still 
 //   TY = 16, weights through the LDS ring   : 512 threads, 140.5 KiB LDS, one workgroup per CU
 //   TY =  8, weights in registers (WREG)    : 256 threads, 66 KiB LDS, 228 VGPRs -> TWO independent workgroups per CU:
 //            the prologue / epilogue of one overlaps the K loop of the other (what limited 128-channel layers)
-template <int TY, int MODE> struct cg_geom {          // MODE 0 weights through the LDS ring, 1 in registers, 2 thin input,
-                                                      // 3 in registers with the halo-row fragment reads prefetched under the MFMAs
+template <int TY, int MODE> struct cg_geom {          // MODE 0 weights through the LDS ring, 1 in registers, 2 thin input
     static constexpr int NT = TY * 32;                    // threads
     static constexpr int HY = TY + 2;
     static constexpr int ROWS = CG_HX * HY;               // halo pixels (612 / 340)
+    static constexpr int ABUF = ROWS * 64;                // 32 channels per pixel
     static constexpr int ACHUNKS = ROWS * 4;              // 16-byte chunks
     static constexpr int PIECES = (ACHUNKS + NT - 1) / NT;
-    // MODE 3 stages whole pieces from every wave (the tail reads the zero page) so that its vmcnt counts are compile-time
-    static constexpr int ABUF = MODE == 3 ? PIECES * NT * 16 : ROWS * 64;     // 32 channels per pixel
     static constexpr int BOFF = 2 * ABUF;
     static constexpr int EP_ROWS = MODE ? 4 : 8;          // patch rows per epilogue pass
     static constexpr int EP_BYTES = EP_ROWS * 32 * 528;
     static constexpr int THIN_PITCH = 272;                // im2col row of the thin-input variant: 128 k + 16 B pad
-    static constexpr int MAIN = MODE == 2 ? TY * 32 * THIN_PITCH : (MODE == 1 || MODE == 3 ? BOFF : BOFF + CG_NB * CG_BUNIT);
+    static constexpr int MAIN = MODE == 2 ? TY * 32 * THIN_PITCH : (MODE == 1 ? BOFF : BOFF + CG_NB * CG_BUNIT);
     static constexpr int LDS = MAIN > EP_BYTES ? MAIN : EP_BYTES;
     static_assert(PIECES <= 7, "the next halo must have landed before interval 8");
 };
 
 template <int N> SVR_DEVICE void cg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// MODE 3 helpers.  Fragment reads are issued from inline asm so that they can be in flight under MFMAs (hipcc's own schedule is
-// read -> s_waitcnt -> MFMA); hipcc does not count asm loads, so every consumer sits behind a counted wait that names the
-// destination registers "+v" (cdna_hip_programming.md 5.7 form (ii)) followed by a sched_barrier.
-template <int OFF> SVR_DEVICE void cg_rd2(bf16x8 (&r)[2], unsigned a0) {   // both k-steps of one halo row: chunk c and c ^ 2
-    const unsigned a1 = a0 ^ 32u;
-    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
-                 : "=&v"(r[0]), "=&v"(r[1]) : "v"(a0), "v"(a1), "n"(OFF) : "memory");
-}
-template <int N> SVR_DEVICE void cg_wait_rows(bf16x8 (&a)[2]) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N));
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int N> SVR_DEVICE void cg_wait_rows(bf16x8 (&a)[2], bf16x8 (&b)[2]) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int N> SVR_DEVICE void cg_wait_rows(bf16x8 (&a)[2], bf16x8 (&b)[2], bf16x8 (&c)[2], bf16x8 (&d)[2]) {
-    asm volatile("s_waitcnt lgkmcnt(%8)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1]), "+v"(d[0]), "+v"(d[1]) : "n"(N));
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int N> SVR_DEVICE void cg_wait_w(bf16x8 (&w)[2][2]) {               // counted vmcnt naming one interval's weights
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]) : "n"(N));
-    __builtin_amdgcn_sched_barrier(0);
-}
 
 #ifdef SVR_ABLATIONS
 __device__ unsigned long long g_conv_tl[4096][4];
@@ -99,7 +72,7 @@ __device__ unsigned long long g_conv_ep[4096][8];      // DBG 256: stamps inside
 template <int TY, int MODE, int DBG = 0>
 __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_args a) {
     typedef cg_geom<TY, MODE> G;
-    constexpr bool WREG = MODE == 1 || MODE == 3, WPF = MODE == 3, THIN = MODE == 2;
+    constexpr bool WREG = MODE == 1, THIN = MODE == 2;
     constexpr int CG_TY = TY, CG_ROWS = G::ROWS, CG_ABUF = G::ABUF, CG_ACHUNKS = G::ACHUNKS, CG_PIECES = G::PIECES,
                   CG_BOFF = G::BOFF, NT = G::NT;
     constexpr int MTW = 4, NTW = 2;                       // 32-voxel rows / 32-cout blocks per wave
@@ -359,149 +332,6 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             SVR_MM(1, r2, 2, 0); SVR_MM(1, r2, 2, 1); SVR_MM(1, r3, 3, 0); SVR_MM(1, r3, 3, 1);
 #undef SVR_MM
         };
-        if constexpr (WPF) {
-        // ---- MODE 3: one continuous MFMA stream per wave.  Nothing is read "just in time": a halo row's fragments are
-        // re-read into the registers of the row that the running burst has finished with (row 0 of the next column shift
-        // under burst dy = 0, row 1 under dy = 1, rows 2 and 3 under dy = 2; rows 4 and 5 of this shift at the start of
-        // dy = 0), the weight loads and the LDS-DMA pieces of the next A step sit between MFMA groups, and every wait is
-        // counted and retires operations issued at least half a burst earlier.  One workgroup barrier per A step, at the
-        // end of interval 6: by then every wave has finished reading this step's buffer (rows 4, 5 of dx = 2 were the
-        // last, lgkmcnt(0) just before) and its pieces of the next halo have landed (the vmcnt wait at the start of
-        // interval 6 leaves only weight loads in flight); the first reads of the next buffer follow in interval 7.
-        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-        unsigned fa[3];
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) fa[dx] = lds0 + (unsigned)rd_a0[dx];
-        auto stage_full = [&](auto qc, const char* fptr, int buf) {
-            constexpr int Q = decltype(qc)::value;
-            const int ck = (akeys >> (2 * Q)) & 3;
-            const char* src = poff[Q] == 0xffffffffu ? (const char*)g.zeros
-                                                     : fptr + ((int64_t)poff[Q] * g.Cin + ck * 8) * 2;
-            glds16(src, wave_dst + buf * CG_ABUF + Q * (NT * 16));
-        };
-#define SVR_RD(ROW, R, DXV, BUFOFF) cg_rd2<((R) * CG_HX + (DXV)) * 64>(ROW, fa[DXV] + (BUFOFF))
-#define SVR_MM(W, KS, ROW, MT, NTI) \
-        acc[MT][NTI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[NTI][KS], ROW[KS], acc[MT][NTI], 0, 0, 0)
-#define SVR_MM4(W, RA, MA, RB, MB) \
-        SVR_MM(W, 0, RA, MA, 0); SVR_MM(W, 0, RA, MA, 1); SVR_MM(W, 0, RB, MB, 0); SVR_MM(W, 0, RB, MB, 1); \
-        SVR_MM(W, 1, RA, MA, 0); SVR_MM(W, 1, RA, MA, 1); SVR_MM(W, 1, RB, MB, 0); SVR_MM(W, 1, RB, MB, 1)
-#define SVR_MM2(W, RA, MA) \
-        SVR_MM(W, 0, RA, MA, 0); SVR_MM(W, 0, RA, MA, 1); SVR_MM(W, 1, RA, MA, 0); SVR_MM(W, 1, RA, MA, 1)
-        auto intervalP = [&](auto jc, auto lastc, int s, const char* fnext, bf16x8 (&wc)[NTW][2], bf16x8 (&wn_)[NTW][2]) {
-            constexpr int J = decltype(jc)::value;
-            constexpr bool LAST = decltype(lastc)::value;
-            constexpr int DY = J % 3, DX = J / 3;
-            const int k = s * 9 + J;
-            const unsigned cur = (unsigned)((s & 1) * CG_ABUF), nxt = (unsigned)(((s + 1) & 1) * CG_ABUF);
-            // pieces of the next halo issued per interval: 2, 2, 1, 1 (after that interval's weight loads).  Younger than the
-            // weights of interval J (issued in J - 2): the pieces of J - 2, the weights and pieces of J - 1.
-            constexpr int NPC[9] = {2, 2, 1, 1, 0, 0, 0, 0, 0};
-            constexpr int NV = 4 + (LAST ? 0 : NPC[(J + 8) % 9] + NPC[(J + 7) % 9]);
-            static_assert(CG_PIECES == 6, "piece schedule below is written for six pieces");
-            if constexpr (DY == 0) {
-                cg_wait_rows<0>(ar0, ar1, ar2, ar3);
-                SVR_RD(ar4, 4, DX, cur);
-                SVR_RD(ar5, 5, DX, cur);
-            } else if constexpr (DY == 1 && J != 7) {
-                cg_wait_rows<4>(ar4);                    // in flight behind it: row 5, row 0 of the next shift
-            } else if constexpr (DY == 2 && J != 8) {
-                cg_wait_rows<4>(ar5);                    // row 0 and row 1 of the next shift
-            }
-            cg_wait_w<NV>(wc);
-            if constexpr (J == 7 && !LAST) SVR_RD(ar0, 0, 0, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((DBG & 512) != 0) __builtin_amdgcn_s_setprio(1);
-            if constexpr (DY == 0) { SVR_MM4(wc, ar0, 0, ar1, 1); }
-            else if constexpr (DY == 1) { SVR_MM4(wc, ar1, 0, ar2, 1); }
-            else { SVR_MM4(wc, ar2, 0, ar3, 1); }
-            if constexpr ((DBG & 512) != 0) __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (DX < 2) {
-                if constexpr (DY == 0) SVR_RD(ar0, 0, DX + 1, cur);
-                else if constexpr (DY == 1) SVR_RD(ar1, 1, DX + 1, cur);
-                else { SVR_RD(ar2, 2, DX + 1, cur); SVR_RD(ar3, 3, DX + 1, cur); }
-            } else if constexpr (!LAST) {
-                if constexpr (DY == 1) SVR_RD(ar1, 1, 0, nxt);
-                else if constexpr (DY == 2) { SVR_RD(ar2, 2, 0, nxt); SVR_RD(ar3, 3, 0, nxt); }
-            }
-            wload(wn_, k + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((DBG & 512) != 0) __builtin_amdgcn_s_setprio(1);
-            if constexpr (DY == 0) { SVR_MM2(wc, ar2, 2); }
-            else if constexpr (DY == 1) { SVR_MM2(wc, ar3, 2); }
-            else { SVR_MM2(wc, ar4, 2); }
-            if constexpr ((DBG & 512) != 0) __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!LAST) {
-                if constexpr (J == 0) { stage_full(std::integral_constant<int, 0>{}, fnext, (s + 1) & 1); stage_full(std::integral_constant<int, 1>{}, fnext, (s + 1) & 1); }
-                if constexpr (J == 1) { stage_full(std::integral_constant<int, 2>{}, fnext, (s + 1) & 1); stage_full(std::integral_constant<int, 3>{}, fnext, (s + 1) & 1); }
-                if constexpr (J == 2) stage_full(std::integral_constant<int, 4>{}, fnext, (s + 1) & 1);
-                if constexpr (J == 3) stage_full(std::integral_constant<int, 5>{}, fnext, (s + 1) & 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((DBG & 512) != 0) __builtin_amdgcn_s_setprio(1);
-            if constexpr (DY == 0) { SVR_MM2(wc, ar3, 3); }
-            else if constexpr (DY == 1) { SVR_MM2(wc, ar4, 3); }
-            else { SVR_MM2(wc, ar5, 3); }
-            if constexpr ((DBG & 512) != 0) __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (J == 6) {
-                cg_wait_rows<0>(ar4, ar5);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        {
-            const char* f0 = frame_ptr(0);
-            stage_full(std::integral_constant<int, 0>{}, f0, 0);
-            stage_full(std::integral_constant<int, 1>{}, f0, 0);
-            stage_full(std::integral_constant<int, 2>{}, f0, 0);
-            stage_full(std::integral_constant<int, 3>{}, f0, 0);
-            stage_full(std::integral_constant<int, 4>{}, f0, 0);
-            stage_full(std::integral_constant<int, 5>{}, f0, 0);
-            wload(w0, 0);
-            wload(w1, 1);
-            cg_wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            SVR_RD(ar0, 0, 0, 0u);
-            SVR_RD(ar1, 1, 0, 0u);
-            SVR_RD(ar2, 2, 0, 0u);
-            SVR_RD(ar3, 3, 0, 0u);
-        }
-        const std::false_type more{};
-        const std::true_type last{};
-        for (int s = 0; s + 1 < nA; ++s) {
-            const char* fnext = frame_ptr(s + 1);
-            intervalP(std::integral_constant<int, 0>{}, more, s, fnext, w0, w2);
-            intervalP(std::integral_constant<int, 1>{}, more, s, fnext, w1, w0);
-            intervalP(std::integral_constant<int, 2>{}, more, s, fnext, w2, w1);
-            intervalP(std::integral_constant<int, 3>{}, more, s, fnext, w0, w2);
-            intervalP(std::integral_constant<int, 4>{}, more, s, fnext, w1, w0);
-            intervalP(std::integral_constant<int, 5>{}, more, s, fnext, w2, w1);
-            intervalP(std::integral_constant<int, 6>{}, more, s, fnext, w0, w2);
-            intervalP(std::integral_constant<int, 7>{}, more, s, fnext, w1, w0);
-            intervalP(std::integral_constant<int, 8>{}, more, s, fnext, w2, w1);
-        }
-        {
-            const int s = nA - 1;
-            intervalP(std::integral_constant<int, 0>{}, last, s, nullptr, w0, w2);
-            intervalP(std::integral_constant<int, 1>{}, last, s, nullptr, w1, w0);
-            intervalP(std::integral_constant<int, 2>{}, last, s, nullptr, w2, w1);
-            intervalP(std::integral_constant<int, 3>{}, last, s, nullptr, w0, w2);
-            intervalP(std::integral_constant<int, 4>{}, last, s, nullptr, w1, w0);
-            intervalP(std::integral_constant<int, 5>{}, last, s, nullptr, w2, w1);
-            intervalP(std::integral_constant<int, 6>{}, last, s, nullptr, w0, w2);
-            intervalP(std::integral_constant<int, 7>{}, last, s, nullptr, w1, w0);
-            intervalP(std::integral_constant<int, 8>{}, last, s, nullptr, w2, w1);
-            cg_wait_vmcnt<0>();       // drain the hand-issued weight loads before the epilogue reuses their registers
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef SVR_RD
-#undef SVR_MM
-#undef SVR_MM4
-#undef SVR_MM2
-        } else {
         bool a_prev3 = false;
         auto interval3 = [&](auto jc, int s, const char* fnext, const bf16x8 (&wc)[NTW][2], bf16x8 (&wn_)[NTW][2]) {
             constexpr int J = decltype(jc)::value;
@@ -575,7 +405,6 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             interval3(std::integral_constant<int, 6>{}, s, fnext, w0, w2);
             interval3(std::integral_constant<int, 7>{}, s, fnext, w1, w0);
             interval3(std::integral_constant<int, 8>{}, s, fnext, w2, w1);
-        }
         }
     } else {
     // ---- prologue: halo of step 0, weight units 0 .. CG_D-1
@@ -817,7 +646,6 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
 #endif
 }
 
-int g_conv_pf = [] { const char* e = getenv("SVR_CONV_PF"); return e ? atoi(e) : 0; }();   // 1: MODE 3 (prefetched fragment reads)
 int g_conv_lds_dbg = [] { const char* e = getenv("SVR_CONV_LDS"); return e ? atoi(e) : 0; }();    // measurement knob: dynamic LDS bytes to request (forces one workgroup per CU when > 80 KiB)
 static bool conv_halo2_wreg(const svr_gemm_args& a) { return a.W_frag != nullptr && g_conv_impl == 0; }
 
@@ -853,9 +681,7 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
         default: break;
     }
 #endif
-    if (conv_halo2_wreg(a))
-        return g_conv_pf == 2 ? launch_conv_halo2_t<8, 3, 512>(a, s) : g_conv_pf ? launch_conv_halo2_t<8, 3>(a, s) : launch_conv_halo2_t<8, 1>(a, s);
-    return launch_conv_halo2_t<16, 0>(a, s);
+    return conv_halo2_wreg(a) ? launch_conv_halo2_t<8, 1>(a, s) : launch_conv_halo2_t<16, 0>(a, s);
 }
 
 // thin-input variant: Cin = 4 (RGB padded), 3x3 spatial taps, stride 1, the whole K in one 128-wide image

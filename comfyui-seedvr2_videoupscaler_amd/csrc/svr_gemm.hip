@@ -119,7 +119,77 @@ SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+// Store side of the LDS-staged epilogue: one thread finishes 8 consecutive output columns (n .. n + 7) of row m -- same
+// arithmetic, in the same order, as epilogue_store() -- and writes them with one 16-byte store (two for fp32 output);
+// the residual is read the same way.  `u`: the SwiGLU "in" values (ignored otherwise).  bias8 / gate8: this thread's
+// columns (loaded once, every store iteration of a thread has the same column chunk).
+SVR_DEVICE void epilogue_store8(const svr_gemm_args& a, const float (&acc8)[8], const float (&u)[8], int m, int n,
+                                const float (&bias8)[8], const float (&gate8)[8]) {
+    float v[8];
+    const int epi = a.epilogue;
+    if (epi == SVR_EPI_SWIGLU) {
+        const int hid = ((n >> 5) << 4) + (n & 15);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu(acc8[e]) * u[e];
+        if (a.out_f32) {
+            float* cp = (float*)a.C + (int64_t)m * a.ldc + hid;
+            *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            *(uint4*)((bf16_t*)a.C + (int64_t)m * a.ldc + hid) = pack8(v);
+        }
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = acc8[e] + bias8[e];
+    if (epi == SVR_EPI_BIAS_SILU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+    } else if (epi == SVR_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+    } else if (epi == SVR_EPI_RESID_GATE) {
+        if (a.gate) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gate8[e];
+        }
+        if (a.resid) {
+            float r8[8];
+            unpack8(*(const uint4*)((const bf16_t*)a.resid + (int64_t)m * a.ldr + n), r8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r8[e];
+        }
+    }
+    int64_t off;
+    if (a.ps.enabled) {
+        const int pw = m % a.ps.W;
+        const int r2 = m / a.ps.W;
+        const int ph = r2 % a.ps.H;
+        const int pf = r2 / a.ps.H;
+        const int C = a.ps.C;
+        const int blk = n / C, c = n - blk * C;
+        const int z = blk % a.ps.rz;
+        const int xy = blk / a.ps.rz;
+        int fo = pf * a.ps.rz + z;
+        if (a.ps.drop_first) {
+            if (fo == 1) return;
+            if (fo > 1) fo -= 1;
+        }
+        const int yo = ph * 2 + (xy >> 1), xo = pw * 2 + (xy & 1);
+        off = (((int64_t)fo * (2 * a.ps.H) + yo) * (2 * a.ps.W) + xo) * C + c;
+    } else {
+        off = (int64_t)m * a.ldc + n;
+    }
+    if (a.out_f32) {
+        float* cp = (float*)a.C + off;
+        *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        *(uint4*)((bf16_t*)a.C + off) = pack8(v);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV, bool EPI_LDS = false>
 __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
     constexpr int WAVES_N = BN / WN;
     constexpr int FM = WM / 16, FN = WN / 16;
@@ -263,6 +333,66 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
 
     // ---- epilogue.  Lane holds C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) + 0..3].
     const int ng = (lane >> 4) * 4;
+    if constexpr (EPI_LDS) {
+        // Through LDS (the K loop's stage buffers are free after its last barrier): passes of RI row fragments per wave
+        // are parked as fp32 [rows][BN + 4] and leave row-contiguous, 8 columns (16 bytes of bf16) per thread, so every
+        // global store / residual load instruction covers whole 128-byte lines.  For short-K problems (1x1 convs, the
+        // pixel-shuffle upsamplers: 2 .. 8 K tiles per output tile) the direct epilogue's 8-byte scattered stores
+        // -- 16 rows x 32 bytes per instruction -- were most of the kernel's time.
+        constexpr int WAVES_M = BM / WM;
+        constexpr int RI = 2;
+        constexpr int PASS_ROWS = WAVES_M * RI * 16;
+        constexpr int PITCH = BN * 4 + 16;
+        constexpr int CH = BN / 8, ROWS_IT = THREADS / CH, ITERS = PASS_ROWS / ROWS_IT;
+        static_assert(PASS_ROWS * PITCH <= 2 * STAGE_BYTES && FM % RI == 0 && PASS_ROWS % ROWS_IT == 0, "epilogue staging fits the stage buffers");
+        const int c8 = tid % CH, r_it = tid / CH;
+        const int n = n0 + c8 * 8;
+        const bool swiglu = a.epilogue == SVR_EPI_SWIGLU;
+        const bool col_ok = n < a.N && !(swiglu && (c8 & 2));      // SwiGLU: "in" blocks are consumed by their gate block's threads
+        float bias8[8], gate8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; gate8[e] = 1.f; }
+        if (col_ok && !swiglu) {
+            if (a.bias) {
+                const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
+                bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+                bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+            }
+            if (a.gate && a.epilogue == SVR_EPI_RESID_GATE) {
+                const float4 g0 = *(const float4*)(a.gate + n), g1 = *(const float4*)(a.gate + n + 4);
+                gate8[0] = g0.x; gate8[1] = g0.y; gate8[2] = g0.z; gate8[3] = g0.w;
+                gate8[4] = g1.x; gate8[5] = g1.y; gate8[6] = g1.z; gate8[7] = g1.w;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < FM / RI; ++p) {
+            if (p > 0) __syncthreads();                     // the previous pass has been read out
+#pragma unroll
+            for (int ii = 0; ii < RI; ++ii) {
+                char* row = smem + (((wave / WAVES_N) * RI + ii) * 16 + frow) * PITCH;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) *(f32x4*)(row + (wn0 + 16 * j + ng) * 4) = acc[p * RI + ii][j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int lr = it * ROWS_IT + r_it;         // parked row -> (wave row, fragment, row in fragment)
+                const int m = m0 + (lr / (RI * 16)) * WM + 16 * (p * RI + ((lr >> 4) % RI)) + (lr & 15);
+                if (!col_ok || m >= a.M) continue;
+                const char* src = smem + lr * PITCH + c8 * 32;
+                const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 16);
+                const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                float u8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (swiglu) {
+                    const f32x4 ul = *(const f32x4*)(src + 64), uh = *(const f32x4*)(src + 80);
+                    u8[0] = ul[0]; u8[1] = ul[1]; u8[2] = ul[2]; u8[3] = ul[3];
+                    u8[4] = uh[0]; u8[5] = uh[1]; u8[6] = uh[2]; u8[7] = uh[3];
+                }
+                epilogue_store8(a, v8, u8, m, n, bias8, gate8);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm0 + 16 * i + frow;
@@ -276,11 +406,11 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, bool EPI_LDS = false>
 static int launch(const svr_gemm_args& a, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
-    auto kern = gemm_kernel<BM, BN, WM, WN, CONV>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, CONV, EPI_LDS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -302,6 +432,20 @@ int g_conv_impl = [] { const char* e = getenv("SVR_CONV_IMPL"); return e ? atoi(
 
 // measurement-only ablation selector of the conv kernels in -DSVR_ABLATIONS builds (svr_set_option("pipe_abl"))
 int g_pipe_abl = [] { const char* e = getenv("SVR_PIPE_ABL"); return e ? atoi(e) : 0; }();
+
+// epilogue of gemm_kernel (svr_set_option("gemm_epi")): 0 auto, 1 always direct, 2 through LDS wherever the layout allows it.
+// Auto = through LDS except for long-K SwiGLU (measured, profiles/r2_gemm_epilogue.txt: pixel-shuffle upsamplers x2.2-2.5,
+// 1x1 convs x1.5, DiT attn-out x1.12, qkv / mlp-out x1.02-1.03, mlp-in SwiGLU x0.98).
+int g_gemm_epi = [] { const char* e = getenv("SVR_GEMM_EPI"); return e ? atoi(e) : 0; }();
+constexpr int GEMM_EPI_LDS_MAX_K_SWIGLU = 1024;
+static bool gemm_epi_lds(const svr_gemm_args& a) {
+    if (g_gemm_epi == 1) return false;
+    const bool aligned = (a.N % 8) == 0 && ((uintptr_t)a.C % 16) == 0 && (!a.resid || (((uintptr_t)a.resid % 16) == 0 && (a.ldr % 8) == 0)) &&
+                         (!a.bias || ((uintptr_t)a.bias % 16) == 0) && (!a.gate || ((uintptr_t)a.gate % 16) == 0) &&
+                         (a.ps.enabled ? (a.ps.C % 8) == 0 : (a.ldc % 8) == 0);
+    if (!aligned) return false;
+    return g_gemm_epi == 2 || a.epilogue != SVR_EPI_SWIGLU || a.K <= GEMM_EPI_LDS_MAX_K_SWIGLU;
+}
 
 // per-frame partial blocks of fused GroupNorm statistics for this problem (0: not produced)
 static int conv_gn_blocks(const svr_gemm_args& a);
@@ -333,6 +477,10 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     // the VAE attention's P V product (16384 x 512 x 16384) has only 128 such tiles for 256 CUs
     const bool wide = (a.N % 256) == 0 &&
                       (int64_t)((a.M + 255) / 256) * (a.N / 256) >= (a.conv.enabled ? 0 : 256);
+    if (gemm_epi_lds(a)) {
+        if (a.conv.enabled) return wide ? launch<256, 256, 128, 64, true, true>(a, s) : launch<256, 128, 64, 64, true, true>(a, s);
+        return wide ? launch<256, 256, 128, 64, false, true>(a, s) : launch<256, 128, 64, 64, false, true>(a, s);
+    }
     if (a.conv.enabled) {
         return wide ? launch<256, 256, 128, 64, true>(a, s) : launch<256, 128, 64, 64, true>(a, s);
     }

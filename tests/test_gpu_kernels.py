@@ -31,6 +31,15 @@ def ref():
     return TorchOps("cuda:0", act_dtype=torch.float32)
 
 
+@pytest.fixture(params=[1, 2], ids=["epi_direct", "epi_lds"])
+def gemm_epi(request, hip):
+    """Both epilogues of svr::gemm_kernel on the same problem: 1 = stores straight from the accumulator layout, 2 = through
+    LDS with row-contiguous 16-byte stores wherever the layout allows it (the library picks per problem by default)."""
+    hip.set_option("gemm_epi", request.param)
+    yield request.param
+    hip.set_option("gemm_epi", 0)
+
+
 def rnd(*shape, scale=1.0, seed=0, dtype=BF16):
     g = torch.Generator(device="cuda").manual_seed(seed + sum(shape))
     return (torch.randn(*shape, generator=g, device="cuda") * scale).to(dtype)
@@ -50,7 +59,7 @@ def packed(n, k, seed=1):
                                    # >= 256 tiles of 256x256: the wide-tile kernel (fewer tiles run 256x128 so no CU idles)
                                    (4100, 4096, 128), (16384, 512, 256)])
 @pytest.mark.parametrize("out_f32", [False, True])
-def test_gemm_bias(hip, ref, M, N, K, out_f32):
+def test_gemm_bias(hip, ref, gemm_epi, M, N, K, out_f32):
     A = rnd(M, K)
     w, W = packed(N, K)
     bias = rnd(N, dtype=torch.float32, seed=3)
@@ -89,7 +98,7 @@ def test_gemm_transpose_detecting(hip):
     assert torch.equal(out, w.t().contiguous())
 
 
-def test_gemm_epilogues(hip, ref):
+def test_gemm_epilogues(hip, ref, gemm_epi):
     M, N, K = 777, 512, 320
     A = rnd(M, K)
     w, W = packed(N, K)
@@ -118,7 +127,7 @@ def test_gemm_epilogues(hip, ref):
     assert torch.equal(buf[M:], tail)
 
 
-def test_gemm_swiglu(hip, ref):
+def test_gemm_swiglu(hip, ref, gemm_epi):
     packing = sub("packing")
     M, K, Hd = 515, 256, 768
     A = rnd(M, K)
@@ -137,7 +146,6 @@ def test_gemm_swiglu(hip, ref):
 
 
 # ------------------------------------------------------------------ implicit-GEMM causal conv
-CONV_PF_DEFAULT = 0          # the library's default for svr_set_option("conv_pf", ...)
 CONV_CASES = [
     # Cin, Cout, k, stride, pad(lo,hi), T, H, W, halo_frames
     (128, 128, (3, 3, 3), (1, 1, 1), (1, 1), 3, 10, 12, 0),
@@ -160,20 +168,17 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("conv_impl", [0, 2, -1, -2], ids=["halo16x32", "halo8x32", "halo16x32_wreg", "wreg_prefetch"])
+@pytest.mark.parametrize("conv_impl", [0, 2, -1], ids=["halo16x32", "halo8x32", "halo16x32_wreg"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3d_implicit_gemm(hip, ref, case, conv_impl):
     """conv_impl 0: the library's choice (16x32-voxel LDS-halo kernel where eligible), 2: the first (8x32) halo
     kernel; geometries neither accepts run on the generic implicit-GEMM kernel in both.  "wreg": the library's
-    choice with the fragment-ordered weight copy supplied (weights streamed to registers, not through LDS);
-    "wreg_prefetch": the same with the halo-row fragment reads prefetched under the MFMA bursts (conv_pf 1)."""
+    choice with the fragment-ordered weight copy supplied (weights streamed to registers, not through LDS)."""
     hip.set_option("conv_impl", max(conv_impl, 0))
-    hip.set_option("conv_pf", 1 if conv_impl == -2 else 0)
     try:
         _conv_case(hip, ref, case, frag=conv_impl < 0)
     finally:
         hip.set_option("conv_impl", 0)
-        hip.set_option("conv_pf", CONV_PF_DEFAULT)
 
 
 @pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[9], CONV_CASES[10], CONV_CASES[3], CONV_CASES[7]],
@@ -233,18 +238,12 @@ def test_conv3d_halo_kernel_race_screen_and_generic_agreement(hip):
         outs.append(out)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    # weights streamed to registers from the fragment-ordered copy: same MFMAs in the same order -> same bits;
-    # both schedules of that kernel (fragment reads before the burst / prefetched under the previous bursts)
+    # weights streamed to registers from the fragment-ordered copy: same MFMAs in the same order -> same bits
     Wf = hip.pack_conv_frag(Wp, 3, Cin, Cout)
-    try:
-        for pf in (0, 1):
-            hip.set_option("conv_pf", pf)
-            for _ in range(4):
-                out = torch.full((T, H, W, Cout), float("nan"), device="cuda", dtype=torch.float32)
-                hip.gemm(x, Wp, out, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, out_f32=True, W_frag=Wf)
-                assert torch.equal(out, outs[0]), pf
-    finally:
-        hip.set_option("conv_pf", CONV_PF_DEFAULT)
+    for _ in range(3):
+        out = torch.empty(T, H, W, Cout, device="cuda", dtype=torch.float32)
+        hip.gemm(x, Wp, out, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, out_f32=True, W_frag=Wf)
+        assert torch.equal(out, outs[0])
     hip.set_option("conv_impl", 1)
     try:
         gen = torch.empty(T, H, W, Cout, device="cuda", dtype=torch.float32)
@@ -294,7 +293,7 @@ def test_conv3d_thin_input_fused(hip, ref, kt, T, H, W, hf, resid_on):
 
 
 @pytest.mark.parametrize("rz,drop", [(1, False), (2, False), (2, True)])
-def test_upscale_pixel_shuffle_epilogue(hip, ref, rz, drop):
+def test_upscale_pixel_shuffle_epilogue(hip, ref, gemm_epi, rz, drop):
     packing, opsmod = sub("packing"), sub("ops")
     F_, H, W, Cc = 3, 5, 6, 256
     x = rnd(F_ * H * W, Cc)
@@ -314,6 +313,78 @@ def test_upscale_pixel_shuffle_epilogue(hip, ref, rz, drop):
     assert rel_err(want, y) < 1e-5
     assert not torch.isnan(out.float()).any()
     assert rel_err(out.float(), want) < TOL_BF16
+
+
+def test_gemm_epilogue_paths_bit_identical(hip):
+    """The LDS-staged epilogue performs the direct epilogue's arithmetic in the same order: identical bits, for every fused
+    epilogue, the fp32 test store, the pixel-shuffle scatter, the generic (strided / 1x1) conv and ragged M."""
+    packing, opsmod = sub("packing"), sub("ops")
+
+    def both(fn):
+        outs = []
+        for mode in (1, 2):
+            hip.set_option("gemm_epi", mode)
+            try:
+                outs.append(fn())
+            finally:
+                hip.set_option("gemm_epi", 0)
+        torch.cuda.synchronize()
+        assert outs[0].dtype == outs[1].dtype and not torch.isnan(outs[0].float()).any()
+        assert torch.equal(outs[0], outs[1])
+
+    M, N, K = 1531, 768, 192
+    A = rnd(M, K)
+    _, W = packed(N, K)
+    bias, gate, resid = rnd(N, dtype=torch.float32, seed=3), rnd(N, dtype=torch.float32, seed=4), rnd(M, N, seed=5)
+    for epi, kw in ((EPI_BIAS, {}), (EPI_BIAS_SILU, {}), (EPI_BIAS_GELU, {}), (EPI_RESID_GATE, dict(gate=gate, resid=resid)),
+                    (EPI_RESID_GATE, dict(resid=resid))):
+        for f32 in (False, True):
+            def run(epi=epi, kw=kw, f32=f32):
+                out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if f32 else BF16)
+                hip.gemm(A, W, out, N=N, K=K, bias=bias, epilogue=epi, out_f32=f32, **kw)
+                return out
+            both(run)
+    # wide (256 x 256) tiles, many of them, K = 2 tiles: the pixel-shuffle upsampler's shape class
+    F_, H, Wd, Cc, rz = 3, 40, 48, 256, 2
+    x = rnd(F_ * H * Wd, Cc)
+    _, Wp = packed(4 * rz * Cc, Cc)
+    b2 = rnd(4 * rz * Cc, dtype=torch.float32, seed=3)
+    for drop in (False, True):
+        def run_ps(drop=drop):
+            ps = opsmod.PixelShuffleGeom(F_, H, Wd, rz, Cc, drop)
+            out = torch.full((F_ * rz - (1 if drop else 0), 2 * H, 2 * Wd, Cc), float("nan"), device="cuda", dtype=BF16)
+            hip.gemm(x, Wp, out, N=4 * rz * Cc, K=Cc, M=F_ * H * Wd, bias=b2, ps=ps)
+            return out
+        both(run_ps)
+    # SwiGLU
+    Hd = 1024
+    Wsw = packing.pack_swiglu(rnd(Hd, K, scale=1 / 16, seed=7), rnd(Hd, K, scale=1 / 16, seed=8), "cuda")
+    for f32 in (False, True):
+        def run_sw(f32=f32):
+            out = torch.full((M, Hd), float("nan"), device="cuda", dtype=torch.float32 if f32 else BF16)
+            hip.gemm(A, Wsw, out, N=2 * Hd, K=K, epilogue=EPI_SWIGLU, out_f32=f32)
+            return out
+        both(run_sw)
+    # generic implicit-GEMM conv: stride 2 with a residual, and a 1x1x1 shortcut conv
+    for Cin, Cout, k, stride, pads in ((256, 256, (3, 3, 3), (2, 2, 2), (0, 1)), (256, 128, (1, 1, 1), (1, 1, 1), (0, 0))):
+        T, Hh, Ww = 5, 24, 20
+        xin = rnd(T, Hh, Ww, Cin)
+        w5 = rnd(Cout, Cin, *k, scale=1.0 / math.sqrt(Cin * k[0] * k[1] * k[2]), seed=2)
+        Wc = packing.pack_conv3d(w5, "cuda")
+        pt = k[0] - 1
+        To = (T + pt - k[0]) // stride[0] + 1
+        Ho = (Hh + pads[0] + pads[1] - k[1]) // stride[1] + 1
+        Wo = (Ww + pads[0] + pads[1] - k[2]) // stride[2] + 1
+        geom = opsmod.Conv3dGeom(T, Hh, Ww, Cin, To, Ho, Wo, k, stride, (pt, pads[0], pads[0]), None)
+        rs = rnd(To, Ho, Wo, Cout, seed=11)
+        bc = rnd(Cout, dtype=torch.float32, seed=3)
+
+        def run_conv():
+            out = torch.full((To, Ho, Wo, Cout), float("nan"), device="cuda", dtype=BF16)
+            hip.gemm(xin, Wc, out, N=Cout, K=Wc.shape[1], bias=bc, conv=geom, epilogue=EPI_RESID_GATE, resid=rs,
+                     ldc=Cout, ldr=Cout)
+            return out
+        both(run_conv)
 
 
 @pytest.mark.parametrize("Cin,Cout,resid", [(128, 128, True), (256, 128, False), (128, 256, True), (128, 512, False)])

@@ -98,6 +98,46 @@ def main():
             sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, epilogue=epi, **kw), args.reps)
             report(name, sec, flops=2.0 * M * N * K)
             del a, w, c, kw
+    if "shortk" in only:
+        # short-K problems of the VAE (tools/shape_census.py): pixel-shuffle upsamplers, 1x1 shortcut convs, attention scores
+        for name, F_, H, W, Cc, rz in (("upsample gemm+pixel-shuffle 256->1024 @5x512^2", 5, 512, 512, 256, 1),
+                                       ("upsample gemm+pixel-shuffle 512->4096 @3x256^2", 3, 256, 256, 512, 2)):
+            x = rnd(F_ * H * W, Cc)
+            w = packing.pack_matrix(torch.randn(4 * rz * Cc, Cc, generator=g, device=dev) / math.sqrt(Cc), dev)
+            b = torch.zeros(4 * rz * Cc, dtype=torch.float32, device=dev)
+            y = ops.empty(F_ * rz, 2 * H, 2 * W, Cc)
+            ps = ops_mod.PixelShuffleGeom(F_, H, W, rz, Cc, False)
+            sec = timeit(lambda: ops.gemm(x, w, y, N=4 * rz * Cc, K=Cc, M=F_ * H * W, bias=b, ps=ps), args.reps)
+            report(name, sec, flops=2.0 * F_ * H * W * 4 * rz * Cc * Cc, bytes_=(x.numel() + y.numel()) * 2)
+            del x, w, y
+        for name, T, H, W, Ci, Co in (("conv1x1x1 256->128 @5x1024^2 (shortcut)", 5, 1024, 1024, 256, 128),
+                                      ("conv1x1x1 512->256 @5x512^2 (shortcut)", 5, 512, 512, 512, 256)):
+            x = rnd(T, H, W, Ci)
+            w = packing.pack_conv3d(torch.randn(Co, Ci, 1, 1, 1, generator=g, device=dev) / math.sqrt(Ci), dev)
+            b = torch.zeros(Co, dtype=torch.float32, device=dev)
+            y = ops.empty(T, H, W, Co)
+            geom = ops_mod.Conv3dGeom(T, H, W, Ci, T, H, W, (1, 1, 1), (1, 1, 1), (0, 0, 0), None)
+            sec = timeit(lambda: ops.gemm(x, w, y, N=Co, K=Ci, bias=b, conv=geom, ldc=Co), args.reps)
+            report(name, sec, flops=2.0 * T * H * W * Co * Ci, bytes_=(x.numel() + y.numel()) * 2)
+            del x, w, y
+        n = 16384
+        q, k = rnd(n, 512), rnd(n, 512)
+        S = torch.empty(n, n, dtype=torch.float32, device=dev)
+        sec = timeit(lambda: ops.gemm(q, k, S, N=n, K=512, out_f32=True), args.reps)
+        report("attention scores 16384x16384x512 (fp32 store)", sec, flops=2.0 * n * n * 512, bytes_=n * n * 4)
+        del q, k, S
+        for name, T, H, W, Ci, Co, k3, st in (("conv3x3x3 s2 256->256 @9x512^2 (downsample)", 9, 512, 512, 256, 256, (3, 3, 3), (2, 2, 2)),
+                                              ("conv1x3x3 s(1,2,2) 128->128 @9x1024^2 (downsample)", 9, 1024, 1024, 128, 128, (1, 3, 3), (1, 2, 2))):
+            x = rnd(T, H, W, Ci)
+            w = packing.pack_conv3d(torch.randn(Co, Ci, *k3, generator=g, device=dev) / math.sqrt(k3[0] * 9 * Ci), dev)
+            b = torch.zeros(Co, dtype=torch.float32, device=dev)
+            pt = k3[0] - 1
+            To, Ho, Wo = (T + pt - k3[0]) // st[0] + 1, (H + 1 - 3) // 2 + 1, (W + 1 - 3) // 2 + 1
+            y = ops.empty(To, Ho, Wo, Co)
+            geom = ops_mod.Conv3dGeom(T, H, W, Ci, To, Ho, Wo, k3, st, (pt, 0, 0), None)
+            sec = timeit(lambda: ops.gemm(x, w, y, N=Co, K=k3[0] * 9 * Ci, bias=b, conv=geom, ldc=Co), args.reps)
+            report(name, sec, flops=2.0 * To * Ho * Wo * Co * k3[0] * 9 * Ci)
+            del x, w, y
     if "attn" in only:
         windows, config = sub("windows"), sub("config")
         for method in ("720pwin_by_size_bysize", "720pswin_by_size_bysize"):
