@@ -242,7 +242,7 @@ static int launch_attn(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_ou
 
 // svr_set_option("attn_impl", v): 0 auto (second-generation window kernel, svr_attn_win.hip, wherever it applies),
 // 1 = this file's kernel everywhere.  Used by A/B measurements and the kernel tests.
-int g_attn_impl = [] { const char* e = getenv("SVR_ATTN_IMPL"); return e ? atoi(e) : 0; }();
+int g_attn_impl = 0;
 
 int attn_dispatch(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,
                   const int32_t* out_rows, const int32_t* cu, int n_seq, int max_len, int heads, int head_dim,

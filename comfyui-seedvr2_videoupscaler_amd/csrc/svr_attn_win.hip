@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
 
 // svr_set_option("attn_variant", v): A/B knob over the build variants -- 0 = default (8 waves; measured best on both window
 // families, profiles/r2_attn_kbench.jsonl), 1 = 4 waves + s_setprio, 2 = 8 waves, 3 = 8 waves + s_setprio, 4 = 4 waves
-int g_attn_variant = [] { const char* e = getenv("SVR_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
+int g_attn_variant = 0;
 
 template <int NW, bool PRIO>
 static int launch_attn_win_t(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,

@@ -44,38 +44,68 @@ static_assert(CG_D < CG_NB, "ring slot of unit k + D must not hold a unit still 
 //   TY = 16, weights through the LDS ring   : 512 threads, 140.5 KiB LDS, one workgroup per CU
 //   TY =  8, weights in registers (WREG)    : 256 threads, 66 KiB LDS, 228 VGPRs -> TWO independent workgroups per CU:
 //            the prologue / epilogue of one overlaps the K loop of the other (what limited 128-channel layers)
-template <int TY, int MODE> struct cg_geom {          // MODE 0 weights through the LDS ring, 1 in registers, 2 thin input
-    static constexpr int NT = TY * 32;                    // threads
+template <int TY, int MODE> struct cg_geom {          // MODE 0 weights through the LDS ring, 1 in registers, 2 thin input,
+                                                      // 3 in registers, 8 rows per wave, one wave per SIMD (see below)
+    static constexpr int MTW = MODE == 3 ? 8 : 4;         // 32-voxel patch rows per wave
+    static constexpr int NT = MODE == 3 ? 256 : TY * 32;  // threads (MODE 3: TY = 16 rows = 2 wave rows x 8)
     static constexpr int HY = TY + 2;
     static constexpr int ROWS = CG_HX * HY;               // halo pixels (612 / 340)
-    static constexpr int ABUF = ROWS * 64;                // 32 channels per pixel
     static constexpr int ACHUNKS = ROWS * 4;              // 16-byte chunks
     static constexpr int PIECES = (ACHUNKS + NT - 1) / NT;
+    // MODE 3 stages whole pieces from every wave (the tail reads the zero page) so that its vmcnt counts are compile-time
+    static constexpr int ABUF = MODE == 3 ? PIECES * NT * 16 : ROWS * 64;     // 32 channels per pixel
     static constexpr int BOFF = 2 * ABUF;
     static constexpr int EP_ROWS = MODE ? 4 : 8;          // patch rows per epilogue pass
     static constexpr int EP_BYTES = EP_ROWS * 32 * 528;
     static constexpr int THIN_PITCH = 272;                // im2col row of the thin-input variant: 128 k + 16 B pad
-    static constexpr int MAIN = MODE == 2 ? TY * 32 * THIN_PITCH : (MODE == 1 ? BOFF : BOFF + CG_NB * CG_BUNIT);
+    static constexpr int MAIN = MODE == 2 ? TY * 32 * THIN_PITCH : (MODE == 1 || MODE == 3 ? BOFF : BOFF + CG_NB * CG_BUNIT);
     static constexpr int LDS = MAIN > EP_BYTES ? MAIN : EP_BYTES;
-    static_assert(PIECES <= 7, "the next halo must have landed before interval 8");
+    static_assert(MODE == 3 || PIECES <= 7, "the next halo must have landed before interval 8");
 };
 
 template <int N> SVR_DEVICE void cg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// MODE 3 helpers.  Fragment reads are issued from inline asm so that they can be in flight under MFMAs (hipcc's own schedule is
+// read -> s_waitcnt -> MFMA); hipcc does not count asm loads, so every consumer sits behind a counted wait that names the
+// destination registers "+v" (cdna_hip_programming.md 5.7 form (ii)) followed by a sched_barrier.
+template <int OFF> SVR_DEVICE void cg_rd2(bf16x8 (&r)[2], unsigned a0) {   // both k-steps of one halo row: chunk c and c ^ 2
+    const unsigned a1 = a0 ^ 32u;
+    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"
+                 : "=&v"(r[0]), "=&v"(r[1]) : "v"(a0), "v"(a1), "n"(OFF) : "memory");
+}
+template <int N> SVR_DEVICE void cg_wait_rows(bf16x8 (&a)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N> SVR_DEVICE void cg_wait_rows(bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N> SVR_DEVICE void cg_wait_rows(bf16x8 (&a)[2], bf16x8 (&b)[2], bf16x8 (&c)[2], bf16x8 (&d)[2], bf16x8 (&e)[2],
+                                              bf16x8 (&f)[2], bf16x8 (&g)[2], bf16x8 (&h)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(%16)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1]), "+v"(d[0]), "+v"(d[1]),
+                   "+v"(e[0]), "+v"(e[1]), "+v"(f[0]), "+v"(f[1]), "+v"(g[0]), "+v"(g[1]), "+v"(h[0]), "+v"(h[1]) : "n"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N> SVR_DEVICE void cg_wait_w(bf16x8 (&w)[2][2]) {               // counted vmcnt naming one interval's weights
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]) : "n"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 #ifdef SVR_ABLATIONS
 __device__ unsigned long long g_conv_tl[4096][4];
-__device__ unsigned long long g_conv_ep[4096][8];      // DBG 256: stamps inside the epilogue (thread 0)       // DBG 256: s_memtime at kernel start / after prologue / after K loop / end
+__device__ unsigned long long g_conv_ep[4096][16];      // DBG 256: stamps inside the epilogue (thread 0)       // DBG 256: s_memtime at kernel start / after prologue / after K loop / end
 #endif
 // DBG (builds with -DSVR_ABLATIONS only; results invalid): 1 no weight loads, 2 no halo LDS-DMA, 4 no global stores,
 // 8 no workgroup barrier in the K loop, 16 halo staged once in the prologue (real data) and never again,
 // 32 weights always from the same four (L1-hot) units, 64 halo-row fragments read from LDS in the first A step only, 128 halo re-staged every step but always from the same (cache-hot) addresses
 template <int TY, int MODE, int DBG = 0>
-__global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_args a) {
+__global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void conv_halo2_kernel(const svr_gemm_args a) {
     typedef cg_geom<TY, MODE> G;
-    constexpr bool WREG = MODE == 1, THIN = MODE == 2;
+    constexpr bool WREG = MODE == 1 || MODE == 3, W8 = MODE == 3, THIN = MODE == 2;
     constexpr int CG_TY = TY, CG_ROWS = G::ROWS, CG_ABUF = G::ABUF, CG_ACHUNKS = G::ACHUNKS, CG_PIECES = G::PIECES,
                   CG_BOFF = G::BOFF, NT = G::NT;
-    constexpr int MTW = 4, NTW = 2;                       // 32-voxel rows / 32-cout blocks per wave
+    constexpr int MTW = G::MTW, NTW = 2;                  // 32-voxel rows / 32-cout blocks per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
@@ -87,7 +117,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;                            // (TY = 16) the two waves of a SIMD are in different groups
-    const int wm = wave >> 1, wn = wave & 1;              // rows 4 wm .. 4 wm + 3, couts 64 wn .. 64 wn + 63
+    const int wm = wave >> 1, wn = wave & 1;              // rows MTW wm .. MTW wm + MTW - 1, couts 64 wn .. 64 wn + 63
 
     // ---- tile id -> (frame, patch row, patch column, cout tile); XCD-contiguous bands
     const int tiles_x = (g.W + CG_TX - 1) / CG_TX;
@@ -174,6 +204,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             for (int e = 0; e < 16; ++e) acc[y][z][e] = 0.f;
     // halo-row fragments [k-step]; row r = wave row 0..5 (separate small arrays: a [6][2] array lands in scratch)
     bf16x8 ar0[2], ar1[2], ar2[2], ar3[2], ar4[2], ar5[2], wf[NTW][2];
+    bf16x8 ar6[2], ar7[2], ar8[2], ar9[2];                // MODE 3: ten halo rows per column shift
 
     // Interval position J of an A step = spatial tap (dy = J % 3, dx = J / 3).  dy = 0 loads wave rows 0..3,
     // dy = 1 adds row 4, dy = 2 row 5.
@@ -332,6 +363,154 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             SVR_MM(1, r2, 2, 0); SVR_MM(1, r2, 2, 1); SVR_MM(1, r3, 3, 0); SVR_MM(1, r3, 3, 1);
 #undef SVR_MM
         };
+        if constexpr (W8) {
+        // ---- MODE 3: 8 patch rows x 64 couts per wave (16 accumulators = 256 registers), ONE wave per SIMD.
+        // Why: the kernel is bound by the power-managed clock, not by issue slots (profiles/r2_conv_experiments.txt: half the
+        // resident waves or a stall-free schedule change nothing), and tools/ubench/operand_cost prices the operand paths of
+        // the 4-row kernel at 24 % of a bare MFMA loop -- weight fragments from L1 7 %, fragment reads from LDS 5 %, halo
+        // staging 4-12 %.  Eight rows per wave reuse every weight fragment twice as often (half the L1 bytes per MFMA), need
+        // 10 halo rows per 8 output rows instead of 6 per 4 (-17 % LDS bytes) and an 18 x 34 halo per 16 x 32 patch (-10 %
+        // staged bytes).
+        // With no second wave on the SIMD to cover latencies the wave runs ONE continuous MFMA stream: a halo row's fragments
+        // are re-read into the registers of a row the running burst has finished with (rows 8, 9 of this column shift at the
+        // start of dy = 0; row 0 of the next shift under dy = 0, row 1 under dy = 1, rows 2..7 under dy = 2 as their pairs
+        // retire), the weight loads and the LDS-DMA pieces of the next A step sit between MFMA groups, and every wait is
+        // counted and retires operations issued at least a quarter burst (256 cycles) earlier.  One workgroup barrier per A
+        // step, at the end of interval 6: by then every wave has finished reading this step's buffer (rows 8, 9 of dx = 2
+        // were the last) and its pieces of the next halo have landed; the first reads of the next buffer follow in interval 7.
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        unsigned fa[3];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) fa[dx] = lds0 + (unsigned)rd_a0[dx];
+        auto stage_full = [&](auto qc, const char* fptr, int buf) {
+            constexpr int Q = decltype(qc)::value;
+            const int ck = (akeys >> (2 * Q)) & 3;
+            const char* src = (poff[Q] == 0xffffffffu || fptr == nullptr) ? (const char*)g.zeros
+                                                                          : fptr + ((int64_t)poff[Q] * g.Cin + ck * 8) * 2;
+            glds16(src, wave_dst + buf * CG_ABUF + Q * (NT * 16));
+        };
+        static_assert(CG_PIECES == 10, "piece schedule below is written for ten pieces, two per interval 0..4");
+#define SVR_RD(ROW, R, DXV, BUFOFF) cg_rd2<((R) * CG_HX + (DXV)) * 64>(ROW, fa[DXV] + (BUFOFF))
+#define SVR_MM(W, KS, ROW, MT, NTI) \
+        acc[MT][NTI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[NTI][KS], ROW[KS], acc[MT][NTI], 0, 0, 0)
+#define SVR_MM8(W, RA, MA, RB, MB) \
+        SVR_MM(W, 0, RA, MA, 0); SVR_MM(W, 0, RA, MA, 1); SVR_MM(W, 0, RB, MB, 0); SVR_MM(W, 0, RB, MB, 1); \
+        SVR_MM(W, 1, RA, MA, 0); SVR_MM(W, 1, RA, MA, 1); SVR_MM(W, 1, RB, MB, 0); SVR_MM(W, 1, RB, MB, 1)
+        // (The last A step runs the same code: its "next halo" pieces stage the zero page into the idle buffer and its
+        // look-ahead reads fetch those zeros -- one code path keeps every vmcnt count a compile-time constant, and a peeled
+        // copy made hipcc shuffle the 256 accumulators between register files at its entry.)
+        auto interval8 = [&](auto jc, int s, const char* fnext, bf16x8 (&wc)[NTW][2], bf16x8 (&wn_)[NTW][2]) {
+            constexpr int J = decltype(jc)::value;
+            constexpr int DY = J % 3, DX = J / 3;
+            const int k = s * 9 + J;
+            const unsigned cur = (unsigned)((s & 1) * CG_ABUF), nxt = (unsigned)(((s + 1) & 1) * CG_ABUF);
+            // VMEM issue order per interval: 4 weight loads, then (J < 5) 2 halo pieces.  Younger than the
+            // weights of interval J (issued in J - 2): the pieces of J - 2, the weights and pieces of J - 1.
+            constexpr int NPC[9] = {2, 2, 2, 2, 2, 0, 0, 0, 0};
+            constexpr int NV = 4 + NPC[(J + 8) % 9] + NPC[(J + 7) % 9];
+            if constexpr (DY == 0) {
+                cg_wait_rows<0>(ar0, ar1, ar2, ar3, ar4, ar5, ar6, ar7);
+                SVR_RD(ar8, 8, DX, cur);
+                SVR_RD(ar9, 9, DX, cur);
+            } else if constexpr (DY == 1 && J != 7) {
+                cg_wait_rows<4>(ar8);                    // in flight behind it: row 9, row 0 of the next shift
+            } else if constexpr (DY == 2 && J != 8) {
+                cg_wait_rows<4>(ar9);                    // row 0 and row 1 of the next shift
+            }
+            cg_wait_w<NV>(wc);
+            if constexpr (J == 7) SVR_RD(ar0, 0, 0, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            // group 1
+            if constexpr (DY == 0) { SVR_MM8(wc, ar0, 0, ar1, 1); }
+            else if constexpr (DY == 1) { SVR_MM8(wc, ar1, 0, ar2, 1); }
+            else { SVR_MM8(wc, ar2, 0, ar3, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DX < 2) {
+                if constexpr (DY == 0) SVR_RD(ar0, 0, DX + 1, cur);
+                else if constexpr (DY == 1) SVR_RD(ar1, 1, DX + 1, cur);
+                else { SVR_RD(ar2, 2, DX + 1, cur); SVR_RD(ar3, 3, DX + 1, cur); }
+            } else {
+                if constexpr (DY == 1) SVR_RD(ar1, 1, 0, nxt);
+                else if constexpr (DY == 2) { SVR_RD(ar2, 2, 0, nxt); SVR_RD(ar3, 3, 0, nxt); }
+            }
+            wload(wn_, k + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            // group 2
+            if constexpr (DY == 0) { SVR_MM8(wc, ar2, 2, ar3, 3); }
+            else if constexpr (DY == 1) { SVR_MM8(wc, ar3, 2, ar4, 3); }
+            else { SVR_MM8(wc, ar4, 2, ar5, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DY == 2) {
+                if constexpr (DX < 2) { SVR_RD(ar4, 4, DX + 1, cur); SVR_RD(ar5, 5, DX + 1, cur); }
+                else { SVR_RD(ar4, 4, 0, nxt); SVR_RD(ar5, 5, 0, nxt); }
+            }
+            if constexpr (J < 5) {
+                stage_full(std::integral_constant<int, (J < 5 ? 2 * J : 0)>{}, fnext, (s + 1) & 1);
+                stage_full(std::integral_constant<int, (J < 5 ? 2 * J + 1 : 0)>{}, fnext, (s + 1) & 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // group 3
+            if constexpr (DY == 0) { SVR_MM8(wc, ar4, 4, ar5, 5); }
+            else if constexpr (DY == 1) { SVR_MM8(wc, ar5, 4, ar6, 5); }
+            else { SVR_MM8(wc, ar6, 4, ar7, 5); }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DY == 2) {
+                if constexpr (DX < 2) { SVR_RD(ar6, 6, DX + 1, cur); SVR_RD(ar7, 7, DX + 1, cur); }
+                else { SVR_RD(ar6, 6, 0, nxt); SVR_RD(ar7, 7, 0, nxt); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // group 4
+            if constexpr (DY == 0) { SVR_MM8(wc, ar6, 6, ar7, 7); }
+            else if constexpr (DY == 1) { SVR_MM8(wc, ar7, 6, ar8, 7); }
+            else { SVR_MM8(wc, ar8, 6, ar9, 7); }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (J == 6) {
+                cg_wait_rows<0>(ar8, ar9);                // the last reads of this step's buffer
+                cg_wait_vmcnt<8>();                       // the pieces of interval 4 (younger: the weight loads of 5 and 6)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        {
+            const char* f0 = frame_ptr(0);
+            stage_full(std::integral_constant<int, 0>{}, f0, 0);
+            stage_full(std::integral_constant<int, 1>{}, f0, 0);
+            stage_full(std::integral_constant<int, 2>{}, f0, 0);
+            stage_full(std::integral_constant<int, 3>{}, f0, 0);
+            stage_full(std::integral_constant<int, 4>{}, f0, 0);
+            stage_full(std::integral_constant<int, 5>{}, f0, 0);
+            stage_full(std::integral_constant<int, 6>{}, f0, 0);
+            stage_full(std::integral_constant<int, 7>{}, f0, 0);
+            stage_full(std::integral_constant<int, 8>{}, f0, 0);
+            stage_full(std::integral_constant<int, 9>{}, f0, 0);
+            wload(w0, 0);
+            wload(w1, 1);
+            cg_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            SVR_RD(ar0, 0, 0, 0u); SVR_RD(ar1, 1, 0, 0u); SVR_RD(ar2, 2, 0, 0u); SVR_RD(ar3, 3, 0, 0u);
+            SVR_RD(ar4, 4, 0, 0u); SVR_RD(ar5, 5, 0, 0u); SVR_RD(ar6, 6, 0, 0u); SVR_RD(ar7, 7, 0, 0u);
+        }
+        for (int s = 0; s < nA; ++s) {
+            const char* fnext = s + 1 < nA ? frame_ptr(s + 1) : nullptr;
+            interval8(std::integral_constant<int, 0>{}, s, fnext, w0, w2);
+            interval8(std::integral_constant<int, 1>{}, s, fnext, w1, w0);
+            interval8(std::integral_constant<int, 2>{}, s, fnext, w2, w1);
+            interval8(std::integral_constant<int, 3>{}, s, fnext, w0, w2);
+            interval8(std::integral_constant<int, 4>{}, s, fnext, w1, w0);
+            interval8(std::integral_constant<int, 5>{}, s, fnext, w2, w1);
+            interval8(std::integral_constant<int, 6>{}, s, fnext, w0, w2);
+            interval8(std::integral_constant<int, 7>{}, s, fnext, w1, w0);
+            interval8(std::integral_constant<int, 8>{}, s, fnext, w2, w1);
+        }
+        // drain: the hand-issued weight loads (the epilogue reuses their registers) and the look-ahead fragment reads
+        cg_wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#undef SVR_RD
+#undef SVR_MM
+#undef SVR_MM8
+        } else {
         bool a_prev3 = false;
         auto interval3 = [&](auto jc, int s, const char* fnext, const bf16x8 (&wc)[NTW][2], bf16x8 (&wn_)[NTW][2]) {
             constexpr int J = decltype(jc)::value;
@@ -405,6 +584,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             interval3(std::integral_constant<int, 6>{}, s, fnext, w0, w2);
             interval3(std::integral_constant<int, 7>{}, s, fnext, w1, w0);
             interval3(std::integral_constant<int, 8>{}, s, fnext, w2, w1);
+        }
         }
     } else {
     // ---- prologue: halo of step 0, weight units 0 .. CG_D-1
@@ -508,7 +688,8 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
     // 8-cout chunk (tid & 15), so it keeps two quad sums over its 16 voxels
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
     constexpr int EP_ROWS = G::EP_ROWS;                             // patch rows per pass
-    static_assert(TY / EP_ROWS == 2 && EP_ROWS * 32 * 16 == 8 * NT && MTW == 4, "two passes, eight store iterations each");
+    constexpr int NPASS = MTW / 2;                                  // every wave parks two of its MTW rows per pass
+    static_assert(TY / EP_ROWS == NPASS && EP_ROWS * 32 * 16 == 8 * NT, "MTW / 2 passes, eight store iterations each");
     // The body is instantiated once per option set of the production calls (bf16 output, no SiLU, no gate; residual and
     // fused statistics on / off) so that the loops carry no per-element option branches -- a taken scalar branch costs a
     // wave ~40 cycles of instruction refetch, and with one per LDS write / five per store iteration they made up a third
@@ -518,9 +699,9 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
         constexpr bool RT = F < 0, F_RESID = !RT && (F & 1), F_GN = !RT && (F & 2);
         const bool with_resid = RT ? (resid_gate && a.resid != nullptr) : F_RESID;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            // every wave parks two of its four rows per pass (all waves write in both passes): LDS slot row wm * 2 + j
-            // holds patch row wm * 4 + 2 * pass + j
+        for (int pass = 0; pass < NPASS; ++pass) {
+            // every wave parks two of its MTW rows per pass (all waves write in every pass): LDS slot row wm * 2 + j
+            // holds patch row wm * MTW + 2 * pass + j
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 char* row = smem + ((wm * 2 + j) * 32 + l31) * EP_PITCH;
@@ -550,7 +731,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             for (int it = 0; it < 4; ++it) {
                 const int vox = ((half * 4 + it) * NT + tid) >> 4;      // voxel slot of this pass
                 const int r = vox >> 5;
-                const int y = y0 + (r >> 1) * 4 + 2 * pass + (r & 1), x = x0 + (vox & 31);
+                const int y = y0 + (r >> 1) * MTW + 2 * pass + (r & 1), x = x0 + (vox & 31);
                 ok[it] = y < g.H && x < g.W;
                 if constexpr ((DBG & 4) != 0) ok[it] = false;
                 mrow[it] = ((int64_t)to * g.H + min(y, g.H - 1)) * g.W + min(x, g.W - 1);
@@ -602,7 +783,7 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
             }
             }
             SVR_EP_STAMP(3 + 3 * pass)                     // stores issued
-            if (pass == 0) __syncthreads();
+            if (pass + 1 < NPASS) __syncthreads();
         }
     };
     if (a.epilogue != SVR_EPI_BIAS_SILU && !a.out_f32 && a.gate == nullptr) {
@@ -646,7 +827,8 @@ __global__ __launch_bounds__(TY * 32, 2) void conv_halo2_kernel(const svr_gemm_a
 #endif
 }
 
-int g_conv_lds_dbg = [] { const char* e = getenv("SVR_CONV_LDS"); return e ? atoi(e) : 0; }();    // measurement knob: dynamic LDS bytes to request (forces one workgroup per CU when > 80 KiB)
+int g_conv_rows = 8;   // rows per wave of the register-streamed kernel: 4 | 8
+int g_conv_lds_dbg = 0;    // measurement knob: dynamic LDS bytes to request (forces one workgroup per CU when > 80 KiB)
 static bool conv_halo2_wreg(const svr_gemm_args& a) { return a.W_frag != nullptr && g_conv_impl == 0; }
 
 template <int TY, int MODE, int DBG = 0> static int launch_conv_halo2_t(const svr_gemm_args& a, hipStream_t s) {
@@ -681,7 +863,8 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
         default: break;
     }
 #endif
-    return conv_halo2_wreg(a) ? launch_conv_halo2_t<8, 1>(a, s) : launch_conv_halo2_t<16, 0>(a, s);
+    if (conv_halo2_wreg(a)) return g_conv_rows == 8 ? launch_conv_halo2_t<16, 3>(a, s) : launch_conv_halo2_t<8, 1>(a, s);
+    return launch_conv_halo2_t<16, 0>(a, s);
 }
 
 // thin-input variant: Cin = 4 (RGB padded), 3x3 spatial taps, stride 1, the whole K in one 128-wide image
@@ -703,7 +886,7 @@ static int conv_gn_blocks(const svr_gemm_args& a) {
     if ((g_conv_impl != 0 && g_conv_impl != 3) || !conv_halo_eligible(a) || (a.N % 128) != 0 || a.conv.Cin % 32 != 0 || a.out_f32) return 0;
     const int cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 0;          // channels per group: 4, 8 or 16
     if (cpg < 4 || (cpg & 3) || a.N % a.gn_groups || 128 % cpg) return 0;
-    const int ty = conv_halo2_wreg(a) ? 8 : 16;
+    const int ty = conv_halo2_wreg(a) && g_conv_rows != 8 ? 8 : 16;
     return ((a.conv.H + ty - 1) / ty) * ((a.conv.W + CG_TX - 1) / CG_TX);
 }
 

@@ -428,15 +428,15 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s);
 static bool conv_halo2_eligible(const svr_gemm_args& a);
 static bool conv_thin_eligible(const svr_gemm_args& a);
 static int launch_conv_thin(const svr_gemm_args& a, hipStream_t s);
-int g_conv_impl = [] { const char* e = getenv("SVR_CONV_IMPL"); return e ? atoi(e) : 0; }();   // 0 auto, 1 generic, 2 first halo kernel, 3 second halo kernel without W_frag
+int g_conv_impl = 0;   // 0 auto, 1 generic, 2 first halo kernel, 3 second halo kernel without W_frag
 
 // measurement-only ablation selector of the conv kernels in -DSVR_ABLATIONS builds (svr_set_option("pipe_abl"))
-int g_pipe_abl = [] { const char* e = getenv("SVR_PIPE_ABL"); return e ? atoi(e) : 0; }();
+int g_pipe_abl = 0;
 
 // epilogue of gemm_kernel (svr_set_option("gemm_epi")): 0 auto, 1 always direct, 2 through LDS wherever the layout allows it.
 // Auto = through LDS except for long-K SwiGLU (measured, profiles/r2_gemm_epilogue.txt: pixel-shuffle upsamplers x2.2-2.5,
 // 1x1 convs x1.5, DiT attn-out x1.12, qkv / mlp-out x1.02-1.03, mlp-in SwiGLU x0.98).
-int g_gemm_epi = [] { const char* e = getenv("SVR_GEMM_EPI"); return e ? atoi(e) : 0; }();
+int g_gemm_epi = 0;
 constexpr int GEMM_EPI_LDS_MAX_K_SWIGLU = 1024;
 static bool gemm_epi_lds(const svr_gemm_args& a) {
     if (g_gemm_epi == 1) return false;

@@ -132,6 +132,12 @@ def lib():
         fn.restype, fn.argtypes = res, args
     if handle.svr_abi_version() != 3:
         raise HipLibraryError("libseedvr2_hip.so ABI version mismatch; rebuild")
+    # measurement knobs from the environment, e.g. SVR_OPTIONS="conv_rows=8,gemm_epi=1" (svr_set_option keys; an unknown key
+    # or a malformed item is an error, not a silently ignored setting)
+    for item in filter(None, (t.strip() for t in os.environ.get("SVR_OPTIONS", "").split(","))):
+        key, sep, val = item.partition("=")
+        if not sep or handle.svr_set_option(key.strip().encode(), int(val)) != 0:
+            raise HipLibraryError(f"SVR_OPTIONS: bad item {item!r}")
     _lib = handle
     return _lib
 

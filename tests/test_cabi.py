@@ -49,3 +49,29 @@ def test_product_fails_loudly_without_gpu():
         ops.HipOps("cpu")
     with pytest.raises(Exception):
         ops.HipOps("cuda:0")
+
+
+def test_svr_options_environment_reaches_the_library():
+    """SVR_OPTIONS="key=value,..." is applied through svr_set_option when the library is loaded (the measurement scripts'
+    only channel: round 2 found getenv() calls inside static-initialiser lambdas of the .hip sources reading the WRONG
+    variable, which silently turned three A/B runs into A/A runs); an unknown key or a malformed item is an error."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import ctypes, importlib, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "m = importlib.import_module('comfyui-seedvr2_videoupscaler_amd.hip_lib')\n"
+        "L = m.lib()\n"
+        "print(ctypes.c_int.in_dll(L, '_ZN3svr11g_conv_rowsE').value, ctypes.c_int.in_dll(L, '_ZN3svr10g_gemm_epiE').value,"
+        " ctypes.c_int.in_dll(L, '_ZN3svr14g_conv_lds_dbgE').value)\n")
+    env = dict(os.environ, SVR_OPTIONS="conv_rows=8, gemm_epi=2,conv_lds=100000")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["8", "2", "100000"]
+    env.pop("SVR_OPTIONS")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split()[1:] == ["0", "0"], (r.stdout, r.stderr)      # defaults
+    for bad in ("no_such_key=1", "conv_rows"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(env, SVR_OPTIONS=bad), capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "SVR_OPTIONS" in r.stderr

@@ -146,6 +146,7 @@ def test_gemm_swiglu(hip, ref, gemm_epi):
 
 
 # ------------------------------------------------------------------ implicit-GEMM causal conv
+CONV_ROWS_DEFAULT = 8        # the library's default for svr_set_option("conv_rows", ...)
 CONV_CASES = [
     # Cin, Cout, k, stride, pad(lo,hi), T, H, W, halo_frames
     (128, 128, (3, 3, 3), (1, 1, 1), (1, 1), 3, 10, 12, 0),
@@ -168,17 +169,20 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("conv_impl", [0, 2, -1], ids=["halo16x32", "halo8x32", "halo16x32_wreg"])
+@pytest.mark.parametrize("conv_impl", [0, 2, -1, -2], ids=["halo16x32", "halo8x32", "wreg_4rows", "wreg_8rows"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3d_implicit_gemm(hip, ref, case, conv_impl):
     """conv_impl 0: the library's choice (16x32-voxel LDS-halo kernel where eligible), 2: the first (8x32) halo
-    kernel; geometries neither accepts run on the generic implicit-GEMM kernel in both.  "wreg": the library's
-    choice with the fragment-ordered weight copy supplied (weights streamed to registers, not through LDS)."""
+    kernel; geometries neither accepts run on the generic implicit-GEMM kernel in both.  "wreg_*": the library's
+    choice with the fragment-ordered weight copy supplied (weights streamed to registers, not through LDS), with 4
+    patch rows per wave and two workgroups per CU, or 8 rows per wave and one wave per SIMD (conv_rows)."""
     hip.set_option("conv_impl", max(conv_impl, 0))
+    hip.set_option("conv_rows", 8 if conv_impl == -2 else 4)
     try:
         _conv_case(hip, ref, case, frag=conv_impl < 0)
     finally:
         hip.set_option("conv_impl", 0)
+        hip.set_option("conv_rows", CONV_ROWS_DEFAULT)
 
 
 @pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[1], CONV_CASES[9], CONV_CASES[10], CONV_CASES[3], CONV_CASES[7]],
@@ -238,12 +242,18 @@ def test_conv3d_halo_kernel_race_screen_and_generic_agreement(hip):
         outs.append(out)
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    # weights streamed to registers from the fragment-ordered copy: same MFMAs in the same order -> same bits
+    # weights streamed to registers from the fragment-ordered copy: same MFMAs in the same order -> same bits,
+    # in both shapes of that kernel (4 rows per wave, two workgroups per CU / 8 rows per wave, one wave per SIMD)
     Wf = hip.pack_conv_frag(Wp, 3, Cin, Cout)
-    for _ in range(3):
-        out = torch.empty(T, H, W, Cout, device="cuda", dtype=torch.float32)
-        hip.gemm(x, Wp, out, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, out_f32=True, W_frag=Wf)
-        assert torch.equal(out, outs[0])
+    try:
+        for rows in (4, 8):
+            hip.set_option("conv_rows", rows)
+            for _ in range(4):
+                out = torch.full((T, H, W, Cout), float("nan"), device="cuda", dtype=torch.float32)
+                hip.gemm(x, Wp, out, N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, out_f32=True, W_frag=Wf)
+                assert torch.equal(out, outs[0]), rows
+    finally:
+        hip.set_option("conv_rows", CONV_ROWS_DEFAULT)
     hip.set_option("conv_impl", 1)
     try:
         gen = torch.empty(T, H, W, Cout, device="cuda", dtype=torch.float32)
@@ -387,8 +397,17 @@ def test_gemm_epilogue_paths_bit_identical(hip):
         both(run_conv)
 
 
+@pytest.fixture(params=[0, 4, 8], ids=["lds_weights", "wreg_4rows", "wreg_8rows"])
+def conv_variant(request, hip):
+    """The three shapes of the second LDS-halo conv kernel: weights through the LDS ring (no fragment-ordered copy), weights
+    streamed to registers with 4 or with 8 patch rows per wave.  -> rows per wave (0: no fragment-ordered copy)."""
+    hip.set_option("conv_rows", request.param or CONV_ROWS_DEFAULT)
+    yield request.param
+    hip.set_option("conv_rows", CONV_ROWS_DEFAULT)
+
+
 @pytest.mark.parametrize("Cin,Cout,resid", [(128, 128, True), (256, 128, False), (128, 256, True), (128, 512, False)])
-def test_conv_fused_groupnorm_stats(hip, ref, Cin, Cout, resid):
+def test_conv_fused_groupnorm_stats(hip, ref, conv_variant, Cin, Cout, resid):
     """GroupNorm (sum, sumsq) fused into the LDS-halo conv epilogue == statistics of the tensor it stored
     (same bf16 values; fp64 reductions in a fixed order), bit-reproducible, ragged patches masked."""
     packing, opsmod = sub("packing"), sub("ops")
@@ -400,7 +419,8 @@ def test_conv_fused_groupnorm_stats(hip, ref, Cin, Cout, resid):
     geom = opsmod.Conv3dGeom(T, H, W, Cin, T, H, W, (3, 3, 3), (1, 1, 1), (2, 1, 1), None)
     res = rnd(T, H, W, Cout, seed=11) if resid else None
     kw = dict(N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, ldr=Cout,
-              epilogue=EPI_RESID_GATE if resid else EPI_BIAS, resid=res)
+              epilogue=EPI_RESID_GATE if resid else EPI_BIAS, resid=res,
+              W_frag=hip.pack_conv_frag(Wp, 3, Cin, Cout) if conv_variant else None)
     out = torch.empty(T, H, W, Cout, device="cuda", dtype=BF16)
     got, stats = hip.gemm(x, Wp, out, gn_groups=32, **kw)
     assert got is out and stats is not None and stats.shape == (T, 32, 2)
