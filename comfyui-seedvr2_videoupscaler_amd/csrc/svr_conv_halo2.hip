@@ -322,7 +322,9 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             };
             const char* p0 = uniform_ptr(wp0 + (int64_t)min(k, P - 1) * 2048);
             const char* p1 = uniform_ptr(wp1 + (int64_t)min(k, P - 1) * 2048);
-            if constexpr (DBG & 1) {
+            if constexpr ((DBG & 1) != 0 && W8) {
+                if (k > 2) return;                                  // 8-row kernel: the three register sets keep their first (real) contents
+            } else if constexpr (DBG & 1) {
                 const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                 w[0][0] = z; w[0][1] = z; w[1][0] = z; w[1][1] = z;
                 return;
@@ -390,7 +392,10 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             glds16(src, wave_dst + buf * CG_ABUF + Q * (NT * 16));
         };
         static_assert(CG_PIECES == 10, "piece schedule below is written for ten pieces, two per interval 0..4");
-#define SVR_RD(ROW, R, DXV, BUFOFF) cg_rd2<((R) * CG_HX + (DXV)) * 64>(ROW, fa[DXV] + (BUFOFF))
+        // (measurement builds, results invalid: DBG 16 no halo staging in the loop, 1 no weight loads, 64 no fragment reads in
+        // the loop -- the counted waits that would then be wrong are dropped with them)
+        constexpr bool ABL_NO_DMA = (DBG & 16) != 0, ABL_NO_W = (DBG & 1) != 0, ABL_NO_RD = (DBG & 64) != 0;
+#define SVR_RD(ROW, R, DXV, BUFOFF) do { if constexpr (!ABL_NO_RD) cg_rd2<((R) * CG_HX + (DXV)) * 64>(ROW, fa[DXV] + (BUFOFF)); } while (0)
 #define SVR_MM(W, KS, ROW, MT, NTI) \
         acc[MT][NTI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[NTI][KS], ROW[KS], acc[MT][NTI], 0, 0, 0)
 #define SVR_MM8(W, RA, MA, RB, MB) \
@@ -417,7 +422,8 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             } else if constexpr (DY == 2 && J != 8) {
                 cg_wait_rows<4>(ar9);                    // row 0 and row 1 of the next shift
             }
-            cg_wait_w<NV>(wc);
+            if constexpr (!ABL_NO_DMA && !ABL_NO_W) cg_wait_w<NV>(wc);
+            else if constexpr (ABL_NO_DMA && !ABL_NO_W) cg_wait_w<4>(wc);
             if constexpr (J == 7) SVR_RD(ar0, 0, 0, nxt);
             __builtin_amdgcn_sched_barrier(0);
             // group 1
@@ -444,7 +450,7 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
                 if constexpr (DX < 2) { SVR_RD(ar4, 4, DX + 1, cur); SVR_RD(ar5, 5, DX + 1, cur); }
                 else { SVR_RD(ar4, 4, 0, nxt); SVR_RD(ar5, 5, 0, nxt); }
             }
-            if constexpr (J < 5) {
+            if constexpr (J < 5 && !ABL_NO_DMA) {
                 stage_full(std::integral_constant<int, (J < 5 ? 2 * J : 0)>{}, fnext, (s + 1) & 1);
                 stage_full(std::integral_constant<int, (J < 5 ? 2 * J + 1 : 0)>{}, fnext, (s + 1) & 1);
             }
@@ -466,7 +472,7 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (J == 6) {
                 cg_wait_rows<0>(ar8, ar9);                // the last reads of this step's buffer
-                cg_wait_vmcnt<8>();                       // the pieces of interval 4 (younger: the weight loads of 5 and 6)
+                if constexpr (!ABL_NO_DMA && !ABL_NO_W) cg_wait_vmcnt<8>();   // the pieces of interval 4 (younger: the weight loads of 5 and 6)
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -485,12 +491,19 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             stage_full(std::integral_constant<int, 9>{}, f0, 0);
             wload(w0, 0);
             wload(w1, 1);
+            if constexpr (ABL_NO_W) wload(w2, 2);
             cg_wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            SVR_RD(ar0, 0, 0, 0u); SVR_RD(ar1, 1, 0, 0u); SVR_RD(ar2, 2, 0, 0u); SVR_RD(ar3, 3, 0, 0u);
-            SVR_RD(ar4, 4, 0, 0u); SVR_RD(ar5, 5, 0, 0u); SVR_RD(ar6, 6, 0, 0u); SVR_RD(ar7, 7, 0, 0u);
+#define SVR_RD0(ROW, R) cg_rd2<((R) * CG_HX) * 64>(ROW, fa[0])
+            SVR_RD0(ar0, 0); SVR_RD0(ar1, 1); SVR_RD0(ar2, 2); SVR_RD0(ar3, 3);
+            SVR_RD0(ar4, 4); SVR_RD0(ar5, 5); SVR_RD0(ar6, 6); SVR_RD0(ar7, 7);
+            if constexpr (ABL_NO_RD) { SVR_RD0(ar8, 8); SVR_RD0(ar9, 9); }
+#undef SVR_RD0
         }
+#ifdef SVR_ABLATIONS
+        if constexpr ((DBG & 256) != 0) { if (tid == 0 && blockIdx.x < 4096) g_conv_tl[blockIdx.x][1] = __builtin_amdgcn_s_memtime(); }
+#endif
         for (int s = 0; s < nA; ++s) {
             const char* fnext = s + 1 < nA ? frame_ptr(s + 1) : nullptr;
             interval8(std::integral_constant<int, 0>{}, s, fnext, w0, w2);
@@ -847,6 +860,15 @@ template <int TY, int MODE, int DBG = 0> static int launch_conv_halo2_t(const sv
 
 static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
 #ifdef SVR_ABLATIONS
+    if (conv_halo2_wreg(a) && g_conv_rows == 8) switch (g_pipe_abl) {
+        case 256: return launch_conv_halo2_t<16, 3, 256>(a, s);
+        case 16: return launch_conv_halo2_t<16, 3, 16>(a, s);
+        case 1: return launch_conv_halo2_t<16, 3, 1>(a, s);
+        case 64: return launch_conv_halo2_t<16, 3, 64>(a, s);
+        case 17: return launch_conv_halo2_t<16, 3, 17>(a, s);
+        case 81: return launch_conv_halo2_t<16, 3, 81>(a, s);
+        default: break;
+    }
     if (conv_halo2_wreg(a)) switch (g_pipe_abl) {
         case 1: return launch_conv_halo2_t<8, 1, 1>(a, s);
         case 2: return launch_conv_halo2_t<8, 1, 2>(a, s);

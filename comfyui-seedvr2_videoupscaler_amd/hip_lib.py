@@ -10,7 +10,8 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libseedvr2_hip.so")
+# (SVR_BUILD_ABLATIONS=1 selects the measurement build, kept in its own file so that it never replaces the product library)
+LIB_PATH = os.path.join(CSRC, "libseedvr2_hip_abl.so" if os.environ.get("SVR_BUILD_ABLATIONS") else "libseedvr2_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "seedvr2_hip.h")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",

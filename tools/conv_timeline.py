@@ -9,6 +9,8 @@ ops_mod, packing, hip_lib = sub("ops"), sub("packing"), sub("hip_lib")
 ops = ops_mod.HipOps("cuda")
 if os.environ.get("CONV_LDS"):
     ops.set_option("conv_lds", int(os.environ["CONV_LDS"]))
+ROWS = int(os.environ.get("CONV_ROWS", "8"))
+ops.set_option("conv_rows", ROWS)
 T, H, W, Ci, Co = (int(v) for v in os.environ.get("SHAPE", "5,1024,1024,128,128").split(","))
 g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randn(T, H, W, Ci, device="cuda", generator=g).bfloat16()
@@ -31,16 +33,16 @@ t = buf.astype(np.int64)
 d = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]], 1)
 first = d[:512]            # the first resident wave of workgroups (cold start), then steady state
 late = d[2048:4096]
+print(f"shape T,H,W,Cin,Cout = {T},{H},{W},{Ci},{Co}; {ROWS} rows per wave; {27 * Ci // 32} tap intervals per tile")
 for name, v in (("first 512 workgroups", first), ("workgroups 2048..4095", late)):
     print(name, "median ticks: prologue %d, K loop %d, epilogue %d, total %d" % tuple(np.median(v, 0)))
     print("   p90: prologue %d, K loop %d, epilogue %d" % tuple(np.percentile(v[:, :3], 90, 0)))
-ep = np.zeros((4096, 8), dtype=np.uint64)
+ep = np.zeros((4096, 16), dtype=np.uint64)
 lib.svr_debug_conv_epilogue.argtypes = [C.c_void_p, C.c_int64]
 assert lib.svr_debug_conv_epilogue(ep.ctypes.data, ep.nbytes) == 0
 e = ep.astype(np.int64)[2048:4096]
 base = t[2048:4096, 2]
-names = ["bias landed", "pass0 LDS writes issued", "pass0 barrier passed", "pass0 stores issued", "pass1 LDS writes issued",
-         "pass1 barrier passed", "pass1 stores issued"]
+names = ["bias landed"] + [f"pass{p} {what}" for p in range(ROWS // 2) for what in ("LDS writes issued", "barrier passed", "stores issued")]
 prev = base
 for i, nme in enumerate(names):
     print("   epilogue +%-26s median %6d ticks" % (nme, np.median(e[:, i] - prev)))
