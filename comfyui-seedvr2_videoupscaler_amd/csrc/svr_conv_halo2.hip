@@ -505,7 +505,7 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
         if constexpr ((DBG & 256) != 0) { if (tid == 0 && blockIdx.x < 4096) g_conv_tl[blockIdx.x][1] = __builtin_amdgcn_s_memtime(); }
 #endif
         for (int s = 0; s < nA; ++s) {
-            const char* fnext = s + 1 < nA ? frame_ptr(s + 1) : nullptr;
+            const char* fnext = s + 1 < nA ? frame_ptr((DBG & 128) ? 0 : s + 1) : nullptr;     // (128: always the same, cache-hot halo)
             interval8(std::integral_constant<int, 0>{}, s, fnext, w0, w2);
             interval8(std::integral_constant<int, 1>{}, s, fnext, w1, w0);
             interval8(std::integral_constant<int, 2>{}, s, fnext, w2, w1);
@@ -867,6 +867,7 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
         case 64: return launch_conv_halo2_t<16, 3, 64>(a, s);
         case 17: return launch_conv_halo2_t<16, 3, 17>(a, s);
         case 81: return launch_conv_halo2_t<16, 3, 81>(a, s);
+        case 128: return launch_conv_halo2_t<16, 3, 128>(a, s);
         default: break;
     }
     if (conv_halo2_wreg(a)) switch (g_pipe_abl) {

@@ -3,7 +3,7 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp SVR_BUILD_ABLATIONS=1
-for abl in 0 16 1 64 17 81 0; do
+for abl in ${ABLS:-0 16 1 64 17 81 0}; do
   SVR_OPTIONS="pipe_abl=$abl" timeout 300 python tools/kbench.py --only conv --reps 5 > gpurun_out/abl8_$abl.jsonl 2> gpurun_out/abl8_$abl.err
   echo -n "abl=$abl rc=$? : "; python - <<PY
 import json
