@@ -282,7 +282,7 @@ def main():
             # trimmed from the output, so the useful rate is (frames - 1) / frames of `value` for the padded workloads
             useful_per_step = world * (frames - 1 if frames > 1 and frames % 4 == 1 else frames)
         kern = ops.summary()
-        # dominant kernel: the LDS-halo implicit-GEMM conv (70 % of the step, profiles/r1_cfg3_kernel_stats.csv)
+        # dominant kernel: the LDS-halo implicit-GEMM conv (73 % of the step, profiles/r2_cfg3_kernel_stats.csv)
         dom = kern.get("conv_halo") or kern.get("conv_generic") or kern["gemm"]
         c_flops, c_sec, c_n = dom["flops"], dom["seconds"], dom["launches"]
         traffic, traffic_note = None, None
@@ -298,7 +298,7 @@ def main():
                     break
             except (OSError, KeyError, ValueError):
                 continue
-        roof = {"bound": "mfma", "kernel": "svr::conv_halo2_kernel<8, register-streamed weights> (LDS-halo implicit-GEMM causal Conv3d, 8x32-voxel patches x 128 couts, 3x3 spatial taps)",
+        roof = {"bound": "mfma", "kernel": "svr::conv_halo2_kernel<16, 3> (LDS-halo implicit-GEMM causal Conv3d, register-streamed weights, 16x32-voxel patches x 128 couts, 8 rows x 64 couts per wave, 3x3 spatial taps)",
                 "achieved": c_flops / max(c_sec, 1e-12) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": c_flops / max(c_sec, 1e-12) / 1e12 / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "traffic_note": traffic_note,
