@@ -175,7 +175,10 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
 /* Tuning / measurement knobs (no effect on results):
  * "conv_impl" 0 auto (LDS-halo kernels for stride-1 3x3 convs; register-streamed weights when W_frag is given)
  * | 1 generic implicit GEMM everywhere | 2 first (8x32-patch) halo kernel | 3 second halo kernel ignoring W_frag,
+ * "conv_rows" patch rows per wave of the register-streamed conv kernel: 8 (default: 256 accumulators, one wave per SIMD) | 4
+ * (two workgroups per CU),
  * "conv_lds" dynamic LDS bytes to request for the halo kernel (> 80 KiB forces one workgroup per CU),
+ * "gemm_epi" epilogue of the GEMM kernel: 0 auto | 1 stores straight from the accumulators | 2 through LDS wherever possible,
  * "attn_impl" 0 auto (second-generation window kernel for head_dim 128 / windows <= 2048 rows) | 1 first kernel everywhere,
  * "attn_variant" build variant of the second-generation window kernel (0 default = 8 waves; 1 / 3 / 4: see svr_attn_win.hip),
  * "pipe_abl" measurement-only ablations in -DSVR_ABLATIONS builds (non-zero values give garbage). */
