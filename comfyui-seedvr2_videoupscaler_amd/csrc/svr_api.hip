@@ -38,6 +38,7 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
     if (!strcmp(key, "gemm_epi")) { g_gemm_epi = value; return 0; }
     if (!strcmp(key, "conv_rows")) { g_conv_rows = value; return 0; }
+    if (!strcmp(key, "conv_band")) { g_conv_band = value; return 0; }
     if (!strcmp(key, "conv_lds")) { g_conv_lds_dbg = value; return 0; }
     if (!strcmp(key, "attn_impl")) { g_attn_impl = value; return 0; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return 0; }

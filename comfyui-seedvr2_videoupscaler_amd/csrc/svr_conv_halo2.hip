@@ -100,7 +100,7 @@ __device__ unsigned long long g_conv_ep[4096][16];      // DBG 256: stamps insid
 // 8 no workgroup barrier in the K loop, 16 halo staged once in the prologue (real data) and never again,
 // 32 weights always from the same four (L1-hot) units, 64 halo-row fragments read from LDS in the first A step only, 128 halo re-staged every step but always from the same (cache-hot) addresses
 template <int TY, int MODE, int DBG = 0>
-__global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void conv_halo2_kernel(const svr_gemm_args a) {
+__global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void conv_halo2_kernel(const svr_gemm_args a, const int band_rows) {
     typedef cg_geom<TY, MODE> G;
     constexpr bool WREG = MODE == 1 || MODE == 3, W8 = MODE == 3, THIN = MODE == 2;
     constexpr int CG_TY = TY, CG_ROWS = G::ROWS, CG_ABUF = G::ABUF, CG_ACHUNKS = G::ACHUNKS, CG_PIECES = G::PIECES,
@@ -129,11 +129,25 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
         const int xcd = bid & 7, j = bid >> 3, q = nwg >> 3, r = nwg & 7;
         tl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
+    // Order: cout tile fastest, then x, then y inside a band of band_rows tile rows, then the OUTPUT FRAME, then the band: the
+    // three temporal consumers of an input region run within one band's worth of traffic of each other, so two of the three
+    // fetches of an input frame find it in the memory-side cache instead of HBM (band_rows = 0: frame outermost, round 1's
+    // order).  Measured: 1 row per band +1..2.4 % on the kernel, wider bands and column groups nothing (profiles/r2_conv_experiments.txt).
     const int tn = tl % tiles_n;
     int rr = tl / tiles_n;
     const int tx = rr % tiles_x; rr /= tiles_x;
-    const int ty = rr % tiles_y;
-    const int to = rr / tiles_y;
+    int ty, to;
+    if (band_rows > 0 && band_rows < tiles_y) {
+        const int per_band = band_rows * g.To;            // (tile rows x frames) of a full band
+        const int b = rr / per_band;                      // band index; the last band may be shorter
+        const int rows_b = min(band_rows, tiles_y - b * band_rows);
+        const int r2 = rr - b * per_band;
+        to = r2 / rows_b;
+        ty = b * band_rows + (r2 - to * rows_b);
+    } else {
+        ty = rr % tiles_y;
+        to = rr / tiles_y;
+    }
     const int y0 = ty * CG_TY, x0 = tx * CG_TX, n0 = tn * 128;
 
     const int cpk = THIN ? 1 : g.Cin / 32;                // 32-channel slices per tap
@@ -840,6 +854,7 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
 #endif
 }
 
+int g_conv_band = 1;       // tile rows per band of the frame-inner tile order (0: frame outermost); svr_set_option("conv_band")
 int g_conv_rows = 8;   // rows per wave of the register-streamed kernel: 4 | 8
 int g_conv_lds_dbg = 0;    // measurement knob: dynamic LDS bytes to request (forces one workgroup per CU when > 80 KiB)
 static bool conv_halo2_wreg(const svr_gemm_args& a) { return a.W_frag != nullptr && g_conv_impl == 0; }
@@ -854,7 +869,8 @@ template <int TY, int MODE, int DBG = 0> static int launch_conv_halo2_t(const sv
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_halo2_kernel<TY, MODE, DBG>), dim3(tiles), dim3(G::NT), g_conv_lds_dbg > G::LDS ? g_conv_lds_dbg : G::LDS, s, a);
+    hipLaunchKernelGGL((conv_halo2_kernel<TY, MODE, DBG>), dim3(tiles), dim3(G::NT), g_conv_lds_dbg > G::LDS ? g_conv_lds_dbg : G::LDS, s, a,
+                       g_conv_band);
     return (int)hipGetLastError();
 }
 
