@@ -177,6 +177,7 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * | 1 generic implicit GEMM everywhere | 2 first (8x32-patch) halo kernel | 3 second halo kernel ignoring W_frag,
  * "conv_rows" patch rows per wave of the register-streamed conv kernel: 8 (default: 256 accumulators, one wave per SIMD) | 4
  * (two workgroups per CU),
+ * "conv_band" tile rows per band of the conv kernel's frame-inner tile order (default 1; 0: frame outermost),
  * "conv_lds" dynamic LDS bytes to request for the halo kernel (> 80 KiB forces one workgroup per CU),
  * "gemm_epi" epilogue of the GEMM kernel: 0 auto | 1 stores straight from the accumulators | 2 through LDS wherever possible,
  * "attn_impl" 0 auto (second-generation window kernel for head_dim 128 / windows <= 2048 rows) | 1 first kernel everywhere,
