@@ -8,5 +8,5 @@ timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider --durations=6 
 echo "pytest rc=$?"; grep -E "rel-err|PSNR" gpurun_out/r2h_pytest_gpu.log | tail -24; tail -12 gpurun_out/r2h_pytest_gpu.log
 timeout 400 python __graft_entry__.py smoke > gpurun_out/r2h_smoke.log 2>&1
 echo "smoke rc=$?"; tail -4 gpurun_out/r2h_smoke.log
-timeout 900 python bench.py --steps 2 --warmup 1 > gpurun_out/r2h_bench_cfg3.json 2> gpurun_out/r2h_bench_cfg3.err
+timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/r2h_bench_cfg3.json 2> gpurun_out/r2h_bench_cfg3.err
 echo "bench cfg3 rc=$?"; cut -c1-400 gpurun_out/r2h_bench_cfg3.json; tail -3 gpurun_out/r2h_bench_cfg3.err | cut -c1-300
