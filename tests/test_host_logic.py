@@ -119,3 +119,33 @@ def test_runner_api_surface():
     with pytest.raises(NotImplementedError):
         r.configure_diffusion()
     assert r.inference([], [], [], []) == []
+
+
+def test_conv_tile_order_is_a_bijection():
+    """The conv kernel's tile id -> (frame, tile row, tile column, cout tile) decode (svr_conv_halo2.hip, frame index INSIDE a
+    band of tile rows), restated: every tile is visited exactly once for ragged band counts, single frames, bands wider than
+    the image, and the frame-outermost order (band 0); within a band the frames of one tile row are adjacent."""
+    def decode(tl, tiles_n, tiles_x, tiles_y, To, band):
+        tn, rr = tl % tiles_n, tl // tiles_n
+        tx, rr = rr % tiles_x, rr // tiles_x
+        if 0 < band < tiles_y:
+            per_band = band * To
+            b = rr // per_band
+            rows_b = min(band, tiles_y - b * band)
+            r2 = rr - b * per_band
+            to = r2 // rows_b
+            ty = b * band + (r2 - to * rows_b)
+        else:
+            ty, to = rr % tiles_y, rr // tiles_y
+        return to, ty, tx, tn
+
+    for tiles_n, tiles_x, tiles_y, To, band in ((1, 32, 64, 5, 1), (2, 3, 7, 4, 3), (4, 1, 10, 3, 4), (1, 5, 3, 9, 2),
+                                                (1, 2, 5, 1, 4), (3, 2, 4, 2, 8), (1, 4, 6, 3, 0)):
+        total = tiles_n * tiles_x * tiles_y * To
+        seen = [decode(t, tiles_n, tiles_x, tiles_y, To, band) for t in range(total)]
+        assert len(set(seen)) == total
+        assert set(seen) == {(a, b, c, d) for a in range(To) for b in range(tiles_y) for c in range(tiles_x) for d in range(tiles_n)}
+    # one-row bands: the To frames of a tile row occupy consecutive runs of tiles_x * tiles_n ids
+    run = 32 * 1
+    first = [decode(t * run, 1, 32, 64, 5, 1) for t in range(10)]
+    assert [f[:2] for f in first] == [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (1, 1), (2, 1), (3, 1), (4, 1)]
