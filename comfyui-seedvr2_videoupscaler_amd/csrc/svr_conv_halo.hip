@@ -401,7 +401,7 @@ static bool conv_halo_eligible(const svr_gemm_args& a) {
     const svr_conv_geom& g = a.conv;
     return g.enabled && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.st == 1 && g.ph == 1 && g.pw == 1 &&
            g.Ho == g.H && g.Wo == g.W && g.Cin % 64 == 0 && g.kt >= 1 && g.kt <= 3 &&
-           g.To == g.T + g.pt - g.kt + 1 && !a.ps.enabled && a.epilogue != SVR_EPI_SWIGLU &&
+           g.To == g.T + g.pt - g.kt + 1 && !a.ps.enabled && !a.phase.enabled && a.epilogue != SVR_EPI_SWIGLU &&
            (a.N <= 32 || ((a.N % 128) == 0 && (a.ldc % 8) == 0 && (!a.resid || (a.ldr % 8) == 0))) &&
            (int64_t)g.H * g.W * g.Cin * 2 < (int64_t)1 << 32;
 }

@@ -34,6 +34,17 @@ struct RowSrc {           // per-thread description of one A-tile row it stages
     int t, y, x;          // conv: top-left-front input coordinate of the receptive field
 };
 
+// Sub-pixel convolution (a.phase): element offset of conv output voxel m, column n in the 2x upsampled tensor, and the border
+// class of the voxel (0 interior, 1 row border, 2 column border, 3 both) that selects its bias vector.
+SVR_DEVICE int64_t phase_offset(const svr_gemm_args& a, int m, int n, int& border) {
+    const int xo = m % a.conv.Wo;
+    const int r2 = m / a.conv.Wo;
+    const int yo = r2 % a.conv.Ho;
+    const int to = r2 / a.conv.Ho;
+    border = (yo == (a.phase.py ? a.conv.Ho - 1 : 0) ? 1 : 0) | (xo == (a.phase.px ? a.conv.Wo - 1 : 0) ? 2 : 0);
+    return (((int64_t)to * (2 * a.conv.Ho) + 2 * yo + a.phase.py) * (2 * a.conv.Wo) + 2 * xo + a.phase.px) * a.N + n;
+}
+
 // One lane's 4 consecutive output columns of row m (n .. n+3): fused epilogue + store.
 SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f32x4 u, int m, int n) {
     float v[4] = {accv[0], accv[1], accv[2], accv[3]};
@@ -53,9 +64,14 @@ SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f
         return;
     }
     const bool full = (n + 3 < a.N);
-    if (a.bias) {
+    int border = 0;
+    const int64_t poff = a.phase.enabled ? phase_offset(a, m, n, border) : 0;
+    {
+        const float* bias = (border && a.phase.bias_border) ? a.phase.bias_border + (int64_t)(border - 1) * a.N : a.bias;
+        if (bias) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += a.bias[n + r];
+            for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += bias[n + r];
+        }
     }
     if (epi == SVR_EPI_BIAS_SILU) {
 #pragma unroll
@@ -81,7 +97,9 @@ SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f
         }
     }
     int64_t off;   // element offset of v[0] in C
-    if (a.ps.enabled) {
+    if (a.phase.enabled) {
+        off = poff;
+    } else if (a.ps.enabled) {
         const int pw = m % a.ps.W;
         const int r2 = m / a.ps.W;
         const int ph = r2 % a.ps.H;
@@ -140,8 +158,16 @@ SVR_DEVICE void epilogue_store8(const svr_gemm_args& a, const float (&acc8)[8], 
         }
         return;
     }
+    int border = 0;
+    const int64_t poff = a.phase.enabled ? phase_offset(a, m, n, border) : 0;
+    if (border && a.phase.bias_border) {            // (rare: one-voxel frame of the image)
+        const float* bb = a.phase.bias_border + (int64_t)(border - 1) * a.N + n;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = acc8[e] + bias8[e];
+        for (int e = 0; e < 8; ++e) v[e] = acc8[e] + bb[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc8[e] + bias8[e];
+    }
     if (epi == SVR_EPI_BIAS_SILU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
@@ -161,7 +187,9 @@ SVR_DEVICE void epilogue_store8(const svr_gemm_args& a, const float (&acc8)[8], 
         }
     }
     int64_t off;
-    if (a.ps.enabled) {
+    if (a.phase.enabled) {
+        off = poff;
+    } else if (a.ps.enabled) {
         const int pw = m % a.ps.W;
         const int r2 = m / a.ps.W;
         const int ph = r2 % a.ps.H;
@@ -442,7 +470,8 @@ static bool gemm_epi_lds(const svr_gemm_args& a) {
     if (g_gemm_epi == 1) return false;
     const bool aligned = (a.N % 8) == 0 && ((uintptr_t)a.C % 16) == 0 && (!a.resid || (((uintptr_t)a.resid % 16) == 0 && (a.ldr % 8) == 0)) &&
                          (!a.bias || ((uintptr_t)a.bias % 16) == 0) && (!a.gate || ((uintptr_t)a.gate % 16) == 0) &&
-                         (a.ps.enabled ? (a.ps.C % 8) == 0 : (a.ldc % 8) == 0);
+                         (a.ps.enabled ? (a.ps.C % 8) == 0 : a.phase.enabled ? true : (a.ldc % 8) == 0) &&
+                         (!a.phase.bias_border || ((uintptr_t)a.phase.bias_border % 16) == 0);
     if (!aligned) return false;
     return g_gemm_epi == 2 || a.epilogue != SVR_EPI_SWIGLU || a.K <= GEMM_EPI_LDS_MAX_K_SWIGLU;
 }
@@ -467,6 +496,13 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     if (a.epilogue == SVR_EPI_SWIGLU && (a.N % 32) != 0) { *why = "svr_gemm_bf16: SWIGLU needs N % 32 == 0"; return -1; }
     if (a.ps.enabled && (a.N != 4 * a.ps.rz * a.ps.C || a.M != a.ps.F * a.ps.H * a.ps.W || (a.ps.C % 4) != 0)) {
         *why = "svr_gemm_bf16: bad pixel-shuffle geometry"; return -1;
+    }
+    if (a.phase.enabled) {
+        const svr_conv_geom& g = a.conv;
+        if (!g.enabled || g.st != 1 || g.sh != 1 || g.sw != 1 || g.Ho != g.H || g.Wo != g.W || a.ps.enabled || a.resid || a.gn_partial ||
+            a.epilogue == SVR_EPI_SWIGLU || (unsigned)a.phase.py > 1u || (unsigned)a.phase.px > 1u) {
+            *why = "svr_gemm_bf16: phase scatter needs a stride-1 same-size conv without ps / residual / SwiGLU / fused statistics"; return -1;
+        }
     }
     if (a.gn_partial && conv_gn_blocks(a) == 0) { *why = "svr_gemm_bf16: gn_partial set but this launch cannot produce fused GroupNorm statistics"; return -1; }
     if (conv_thin_eligible(a)) return launch_conv_thin(a, s);

@@ -66,7 +66,10 @@ def vae_encode_flops(cfg: VAEConfig, T: int, H: int, W: int) -> dict:
     return {"conv": conv, "attn": m_attn, "total": conv + m_attn}
 
 
-def vae_decode_flops(cfg: VAEConfig, Tl: int, h: int, w: int) -> dict:
+def vae_decode_flops(cfg: VAEConfig, Tl: int, h: int, w: int, merged_upsamplers: bool = False) -> dict:
+    """``merged_upsamplers``: count the spatial-only upsampler as the engine runs it by default (four sub-pixel convs over
+    the low-resolution input, subpixel.py: 3 x 2 x 2 taps per output voxel, no upscale_conv) instead of as the reference's
+    upscale_conv + 3x3x3 conv."""
     ch = list(reversed(cfg.block_out_channels))
     n = len(ch)
     t, c = Tl, ch[0]
@@ -80,6 +83,10 @@ def vae_decode_flops(cfg: VAEConfig, Tl: int, h: int, w: int) -> dict:
         if i != n - 1:
             temporal = i < cfg.temporal_scale_num
             rz = 2 if temporal else 1
+            if merged_upsamplers and not temporal:
+                h, w = h * 2, w * 2
+                conv += conv_flops(c, c, (3, 2, 2), t * h * w)
+                continue
             conv += conv_flops(c, c * 4 * rz, (1, 1, 1), t * h * w)
             t, h, w = (t * 2 - 1 if temporal else t), h * 2, w * 2
             conv += conv_flops(c, c, (3, 3, 3), t * h * w)
@@ -98,18 +105,20 @@ def _tiles(total, tile, overlap):
     return out
 
 
-def vae_flops_tiled(cfg: VAEConfig, T: int, H: int, W: int, tiled: bool, tile=(1024, 1024), overlap=(128, 128)) -> dict:
+def vae_flops_tiled(cfg: VAEConfig, T: int, H: int, W: int, tiled: bool, tile=(1024, 1024), overlap=(128, 128),
+                    merged_upsamplers: bool = False) -> dict:
     """Encode + decode FLOPs of one clip [T, H, W] (pixels), with the reference's tile grid if tiled."""
     s = cfg.spatial_downsample_factor
     Tl = (T - 1) // cfg.temporal_downsample_factor + 1
     Hl, Wl = (H + s - 1) // s, (W + s - 1) // s
     if not tiled or (H <= tile[0] and W <= tile[1]):
-        return {"encode": vae_encode_flops(cfg, T, H, W)["total"], "decode": vae_decode_flops(cfg, Tl, Hl, Wl)["total"]}
+        return {"encode": vae_encode_flops(cfg, T, H, W)["total"],
+                "decode": vae_decode_flops(cfg, Tl, Hl, Wl, merged_upsamplers)["total"]}
     lth, ltw = tile[0] // s, tile[1] // s
     loh, low = min(overlap[0] // s, lth - 1), min(overlap[1] // s, ltw - 1)
     enc = dec = 0.0
     for (y0, y1) in _tiles(Hl, lth, loh):
         for (x0, x1) in _tiles(Wl, ltw, low):
             enc += vae_encode_flops(cfg, T, min(y1 * s, H) - y0 * s, min(x1 * s, W) - x0 * s)["total"]
-            dec += vae_decode_flops(cfg, Tl, y1 - y0, x1 - x0)["total"]
+            dec += vae_decode_flops(cfg, Tl, y1 - y0, x1 - x0, merged_upsamplers)["total"]
     return {"encode": enc, "decode": dec}

@@ -36,6 +36,11 @@ class PixelShuffle(C.Structure):
                 ("rz", C.c_int32), ("C", C.c_int32), ("drop_first", C.c_int32)]
 
 
+class PhaseScatter(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("py", C.c_int32), ("px", C.c_int32), ("pad_", C.c_int32),
+                ("bias_border", C.c_void_p)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int64),
                 ("W", C.c_void_p),
@@ -46,7 +51,8 @@ class GemmArgs(C.Structure):
                 ("epilogue", C.c_int32), ("out_f32", C.c_int32),
                 ("conv", ConvGeom), ("ps", PixelShuffle),
                 ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
-                ("W_frag", C.c_void_p)]
+                ("W_frag", C.c_void_p),
+                ("phase", PhaseScatter)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/seedvr2_hip.h
@@ -131,7 +137,7 @@ def lib():
         except AttributeError as e:
             raise HipLibraryError(f"{LIB_PATH} does not export {name} (stale build?)") from e
         fn.restype, fn.argtypes = res, args
-    if handle.svr_abi_version() != 3:
+    if handle.svr_abi_version() != 4:
         raise HipLibraryError("libseedvr2_hip.so ABI version mismatch; rebuild")
     # measurement knobs from the environment, e.g. SVR_OPTIONS="conv_rows=8,gemm_epi=1" (svr_set_option keys; an unknown key
     # or a malformed item is an error, not a silently ignored setting)

@@ -40,6 +40,15 @@ class PixelShuffleGeom:
     drop_first: bool
 
 
+@dataclass
+class PhaseScatter:
+    """Sub-pixel convolution launch: the conv's output voxel (t, y, x) lands at out[t, 2y + py, 2x + px]; ``bias_border``
+    fp32 [3, N]: bias on the voxels whose window loses its border tap (row border | column border | both)."""
+    py: int
+    px: int
+    bias_border: Optional[torch.Tensor] = None
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -97,7 +106,7 @@ class HipOps:
 
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
              out_f32=False, conv: Optional[Conv3dGeom] = None, ps: Optional[PixelShuffleGeom] = None,
-             lda=None, ldc=None, ldr=None, gn_groups: int = 0, W_frag=None):
+             lda=None, ldc=None, ldr=None, gn_groups: int = 0, W_frag=None, phase: Optional[PhaseScatter] = None):
         """out[M, N] = A[M, K] @ W[:N, :K]^T with fused epilogue.  W is [Npad, K] bf16 (Npad % 128 == 0).
         With ``gn_groups`` > 0 (conv mode) returns ``(out, stats)``: per-frame GroupNorm (sum, sumsq) of the stored
         output [To, groups, 2] fp64 fused into the conv epilogue, or ``None`` when the kernel serving this
@@ -129,6 +138,17 @@ class HipOps:
                 M = A.shape[0]
             if lda is None:
                 lda = A.stride(0) if A.dim() == 2 else K
+        if phase is not None:
+            if conv is None or ps is not None or resid is not None or gn_groups:
+                raise ValueError("phase scatter: conv mode only, without pixel shuffle / residual / fused statistics")
+            if out.numel() != 4 * M * N:
+                raise ValueError("phase scatter: out must be the dense [To, 2*Ho, 2*Wo, N] tensor")
+            a.phase.enabled, a.phase.py, a.phase.px = 1, int(phase.py), int(phase.px)
+            if phase.bias_border is not None:
+                if tuple(phase.bias_border.shape) != (3, N):
+                    raise ValueError("phase scatter: bias_border must be [3, N]")
+                a.phase.bias_border = self._chk(phase.bias_border, torch.float32, "bias_border").data_ptr()
+            ldc = 0
         if ps is not None:
             a.ps.enabled = 1
             a.ps.F, a.ps.H, a.ps.W, a.ps.rz, a.ps.C = ps.F, ps.H, ps.W, ps.rz, ps.C

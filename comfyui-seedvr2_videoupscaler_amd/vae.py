@@ -23,8 +23,9 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from .config import VAEConfig
-from .ops import EPI_BIAS, EPI_RESID_GATE, Conv3dGeom, PixelShuffleGeom
-from .packing import pack_conv3d, pack_matrix, pack_vec
+from . import subpixel
+from .ops import EPI_BIAS, EPI_RESID_GATE, Conv3dGeom, PhaseScatter, PixelShuffleGeom
+from .packing import BF16, pack_conv3d, pack_matrix, pack_vec
 
 BF16 = torch.bfloat16
 
@@ -76,6 +77,9 @@ class _Up:
     conv: _Conv
     temporal: bool
     C: int
+    # spatial-only upsamplers: the four sub-pixel convs that replace upscale_conv + pixel shuffle + conv (subpixel.py):
+    # [(py, px, packed weight [Cout, kt*2*2*C], bias [Cout], bias_border [3, Cout])]
+    merged: Optional[list] = None
 
 
 def _tile_ranges(total: int, tile: int, overlap: int) -> List[Tuple[int, int]]:
@@ -110,7 +114,10 @@ def _cos_ramp(n: int) -> Optional[torch.Tensor]:
 
 class VideoVAEEngine:
     def __init__(self, cfg: VAEConfig, state_dict: Dict[str, torch.Tensor], ops,
-                 act_budget_bytes: int = 12 << 30):
+                 act_budget_bytes: int = 12 << 30, merge_upsamplers: bool = True):
+        """``merge_upsamplers``: run the spatial-only upsampler (upscale_conv + pixel shuffle + 3x3x3 conv) as four sub-pixel
+        convs over its low-resolution input (subpixel.py) -- same function, 12 instead of 28 MACs per output voxel and channel
+        pair, no upsampled intermediate; False keeps the reference's two steps."""
         self.cfg, self.ops = cfg, ops
         self.device = ops.device
         self.act_budget_bytes = act_budget_bytes
@@ -180,6 +187,13 @@ class VideoVAEEngine:
                 w = sd[u + ".upscale_conv.weight"]
                 up = _Up(pack_matrix(w.reshape(w.shape[0], w.shape[1]), dev), pack_vec(sd[u + ".upscale_conv.bias"], dev),
                          conv(u + ".conv"), i < cfg.temporal_scale_num, w.shape[1])
+                if merge_upsamplers and not up.temporal and w.shape[1] % 64 == 0:
+                    # (weights as the reference holds them: cast to bf16 at load, model_loader.py:583-584; merged in fp32)
+                    w3 = sd[u + ".conv.weight"]
+                    parts = subpixel.merge_spatial_upsampler(
+                        w.reshape(w.shape[0], w.shape[1]).to(device=dev, dtype=BF16), sd[u + ".upscale_conv.bias"].to(device=dev, dtype=BF16),
+                        w3.to(device=dev, dtype=BF16), sd[u + ".conv.bias"].to(device=dev, dtype=BF16))
+                    up.merged = [(py, px, pack_conv3d(wm, dev), b.contiguous(), bb.contiguous()) for py, px, wm, b, bb in parts]
             self.dec_up.append((res, up))
         self.dec_norm_out = norm("decoder.conv_norm_out")
         self.dec_conv_out = conv("decoder.conv_out")
@@ -341,6 +355,8 @@ class VideoVAEEngine:
     def _upsample(self, up: _Up, x, st, first):
         ops = self.ops
         T, H, W, Cc = x.shape
+        if up.merged is not None:
+            return self._upsample_subpixel(up, x, st, first)
         rz = 2 if up.temporal else 1
         drop = up.temporal and first                       # remove_head on the first slice only
         To = T * rz - (1 if drop else 0)
@@ -348,6 +364,33 @@ class VideoVAEEngine:
         ops.gemm(x.reshape(T * H * W, Cc), up.upscale_w, y, N=4 * rz * Cc, K=Cc, M=T * H * W, bias=up.upscale_b,
                  ps=PixelShuffleGeom(T, H, W, rz, Cc, drop))
         return self._conv(up.conv, y, st, first, gn=True)
+
+    def _upsample_subpixel(self, up: _Up, x, st, first):
+        """Spatial-only upsampler as four (kt, 2, 2)-tap convs over the low-resolution input, one per output phase, each
+        scattering into its positions of the 2x grid.  The causal memory of the reference's conv (the last kt - 1 frames of
+        its upsampled input) becomes the last kt - 1 frames of the LOW-resolution input: the upsampling is pointwise in
+        time.  -> (y, None): GroupNorm statistics are taken by the caller (these launches cannot fuse them)."""
+        ops, cw = self.ops, up.conv
+        T, H, W, Cc = x.shape
+        kt = cw.k[0]
+        key = cw.name + "#subpixel"
+        halo = None if first else st.get(key)
+        if not first and kt > 1 and halo is None:
+            raise RuntimeError(f"{cw.name}: missing temporal halo for a non-initial slice")
+        pt = (kt - 1) if first else (halo.shape[0] if halo is not None else 0)
+        To = T + pt - kt + 1
+        y = ops.empty(To, 2 * H, 2 * W, cw.cout)
+        for py, px, w, b, bb in up.merged:
+            geom = Conv3dGeom(T, H, W, Cc, To, H, W, (kt, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
+            ops.gemm(x, w, y, N=cw.cout, K=w.shape[1], bias=b, conv=geom, phase=PhaseScatter(py, px, bb))
+        carry = kt - 1
+        if carry > 0 and not st.get("__last_slice__", False):
+            if T >= carry:
+                st[key] = x[T - carry:].clone()
+            else:
+                prev = halo if halo is not None else x[:1].expand(pt, H, W, Cc)
+                st[key] = torch.cat([prev, x], dim=0)[-carry:].contiguous()
+        return y, None
 
     # ------------------------------------------------------------------ one temporal slice through a network
     # (hs = GroupNorm statistics of h when the conv that produced h fused them into its epilogue, else None)

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SVR_ABI_VERSION 3
+#define SVR_ABI_VERSION 4
 
 /* ---- GEMM / implicit-GEMM convolution epilogues ------------------------------------------ */
 #define SVR_EPI_BIAS        0   /* C = acc + bias                                              */
@@ -54,6 +54,19 @@ typedef struct svr_pixel_shuffle {
     int32_t drop_first;         /* 1: drop the duplicated 2nd output frame (first slice only)  */
 } svr_pixel_shuffle;
 
+typedef struct svr_phase_scatter {
+    int32_t enabled;            /* conv mode, stride 1: this launch computes ONE output phase of a 2x spatially upsampled
+                                   grid ("sub-pixel convolution"): output voxel (to, yo, xo) of the conv is stored at
+                                   C[to][2*yo + py][2*xo + px][n], C dense [To, 2*Ho, 2*Wo, N].  Used to run Upsample3D's
+                                   1x1x1 upscale_conv + pixel shuffle + 3x3x3 conv (attn_video_vae.py:110-174) as four
+                                   (kt, 2, 2)-tap convs over the LOW-resolution input with merged weights.            */
+    int32_t py, px;             /* 0 | 1                                                                              */
+    int32_t pad_;
+    const float* bias_border;   /* fp32 [3][N] or NULL: bias used INSTEAD of `bias` on the voxels whose window loses its
+                                   border tap to the zero padding of the upsampled grid -- row yo == (py ? Ho-1 : 0):
+                                   [0]; column xo == (px ? Wo-1 : 0): [1]; both: [2]                                  */
+} svr_phase_scatter;
+
 typedef struct svr_gemm_args {
     const void* A;  int64_t lda;        /* bf16 [M, K] (ignored rows/K layout when conv.enabled: A = input tensor) */
     const void* W;                      /* bf16 [Npad, K] row-major (nn.Linear layout), K % 64 == 0,
@@ -78,6 +91,7 @@ typedef struct svr_gemm_args {
      * MFMA-fragment order as written by svr_conv_pack_frag().  When set, the LDS-halo conv kernel streams the
      * weights from this copy straight into registers instead of staging W through LDS.  NULL: off.        */
     const void* W_frag;
+    svr_phase_scatter phase;            /* conv mode only; not together with ps / SWIGLU / gn_partial / resid           */
 } svr_gemm_args;
 
 /* W [N, K = kt * 9 * Cin] (conv weight rows, K order (dt, dy, dx, c)) -> out (same byte size, N * K bf16) in the

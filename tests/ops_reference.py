@@ -29,11 +29,11 @@ class TorchOps:
 
     # ------------------------------------------------------------------ GEMM / conv
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
-             out_f32=False, conv=None, ps=None, lda=None, ldc=None, ldr=None, gn_groups=0, W_frag=None):
+             out_f32=False, conv=None, ps=None, lda=None, ldc=None, ldr=None, gn_groups=0, W_frag=None, phase=None):
         """``gn_groups`` > 0: return ``(out, None)`` like a HIP launch whose kernel cannot fuse the statistics."""
         if gn_groups > 0:
             return self.gemm(A, W, out, N=N, K=K, M=M, bias=bias, epilogue=epilogue, gate=gate, resid=resid,
-                             out_f32=out_f32, conv=conv, ps=ps, lda=lda, ldc=ldc, ldr=ldr), None
+                             out_f32=out_f32, conv=conv, ps=ps, lda=lda, ldc=ldc, ldr=ldr, phase=phase), None
         Wf = W[:N, :K].float()
         if conv is not None:
             g = conv
@@ -65,6 +65,17 @@ class TorchOps:
             res = acc
             if bias is not None:
                 res = res + bias[:N].float()
+            if phase is not None and phase.bias_border is not None:      # border voxels take their own bias vector
+                g = conv
+                r4 = res.reshape(g.To, g.Ho, g.Wo, N).clone()
+                a4 = acc.reshape(g.To, g.Ho, g.Wo, N)
+                yb = g.Ho - 1 if phase.py else 0
+                xb = g.Wo - 1 if phase.px else 0
+                bb = phase.bias_border.float()
+                r4[:, yb, :, :] = a4[:, yb, :, :] + bb[0]
+                r4[:, :, xb, :] = a4[:, :, xb, :] + bb[1]
+                r4[:, yb, xb, :] = a4[:, yb, xb, :] + bb[2]
+                res = r4.reshape(-1, N)
             if epilogue == EPI_BIAS_GELU:
                 res = F.gelu(res, approximate="tanh")
             elif epilogue == EPI_BIAS_SILU:
@@ -74,6 +85,11 @@ class TorchOps:
                     res = res * gate[:N].float()
                 if resid is not None:
                     res = res + resid.reshape(M, -1)[:, :N].float()
+        if phase is not None:
+            g = conv
+            o4 = out.reshape(g.To, 2 * g.Ho, 2 * g.Wo, N)
+            o4[:, phase.py::2, phase.px::2, :] = res.reshape(g.To, g.Ho, g.Wo, N).to(out.dtype)
+            return out
         if ps is not None:
             r = res.reshape(ps.F, ps.H, ps.W, 2, 2, ps.rz, ps.C).permute(0, 5, 1, 3, 2, 4, 6)
             r = r.reshape(ps.F * ps.rz, 2 * ps.H, 2 * ps.W, ps.C)

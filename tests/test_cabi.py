@@ -30,8 +30,8 @@ def test_library_builds_loads_and_exports_header_symbols():
         assert hasattr(lib, name), f"{name} declared in seedvr2_hip.h but not exported"
     assert sorted(hip_lib.SYMBOLS) == declared, "ctypes table and header disagree"
     lib.svr_abi_version.restype = ctypes.c_int
-    assert lib.svr_abi_version() == 3
-    assert hip_lib.lib().svr_abi_version() == 3
+    assert lib.svr_abi_version() == 4
+    assert hip_lib.lib().svr_abi_version() == 4
 
 
 def test_struct_layout_matches_header():
@@ -39,6 +39,7 @@ def test_struct_layout_matches_header():
     # svr_conv_geom: 18 int32 + 2 pointers; svr_pixel_shuffle: 7 int32
     assert ctypes.sizeof(hip_lib.ConvGeom) == 18 * 4 + 2 * 8
     assert ctypes.sizeof(hip_lib.PixelShuffle) == 7 * 4
+    assert ctypes.sizeof(hip_lib.PhaseScatter) == 4 * 4 + 8 and hip_lib.GemmArgs.phase.offset % 8 == 0
     assert hip_lib.GemmArgs.conv.offset % 8 == 0
 
 

@@ -397,6 +397,58 @@ def test_gemm_epilogue_paths_bit_identical(hip):
         both(run_conv)
 
 
+@pytest.mark.parametrize("T,H,W,Cin,Cout,hf", [(3, 9, 11, 128, 128, 0), (2, 16, 20, 256, 256, 2), (4, 1, 5, 64, 128, 0)])
+def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, T, H, W, Cin, Cout, hf):
+    """Sub-pixel convolution launches (svr_gemm_args.phase): four (3, 2, 2)-tap convs over the low-resolution input, each
+    scattering into its phase of the 2x grid with its own border bias == the torch restatement; together they write every
+    voxel of the output exactly once (NaN canary)."""
+    packing, opsmod = sub("packing"), sub("ops")
+    x = rnd(T, H, W, Cin)
+    halo = rnd(hf, H, W, Cin, seed=9) if hf else None
+    pt = hf if hf else 2
+    To = T + pt - 3 + 1
+    out = torch.full((To, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=BF16)
+    want = torch.full((To, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=torch.float32)
+    for ph, (py, px) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+        w5 = rnd(Cout, Cin, 3, 2, 2, scale=1.0 / math.sqrt(Cin * 12), seed=20 + ph)
+        Wp = packing.pack_conv3d(w5, "cuda")
+        bias = rnd(Cout, dtype=torch.float32, seed=30 + ph)
+        bb = rnd(3, Cout, dtype=torch.float32, seed=40 + ph)
+        geom = opsmod.Conv3dGeom(T, H, W, Cin, To, H, W, (3, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
+        kw = dict(N=Cout, K=Wp.shape[1], bias=bias, conv=geom, phase=opsmod.PhaseScatter(py, px, bb))
+        hip.gemm(x, Wp, out, **kw)
+        ref.gemm(x, Wp, want, **kw)
+        # independent check of the restatement on this phase: F.conv3d of the padded input + per-voxel bias
+        head = halo.float() if hf else x[:1].float().expand(pt, H, W, Cin)
+        xin = torch.nn.functional.pad(torch.cat([head, x.float()], 0).permute(3, 0, 1, 2)[None], (1 - px, px, 1 - py, py))
+        y = torch.nn.functional.conv3d(xin, w5.float())[0].permute(1, 2, 3, 0)
+        b = bias.expand(To, H, W, Cout).clone()
+        rb, cb = (H - 1 if py else 0), (W - 1 if px else 0)
+        b[:, rb] = bb[0]
+        b[:, :, cb] = bb[1]
+        b[:, rb, cb] = bb[2]
+        assert rel_err(want[:, py::2, px::2], y + b) < 1e-5
+    assert not torch.isnan(out.float()).any() and not torch.isnan(want).any()
+    assert rel_err(out.float(), want) < TOL_BF16
+
+
+def test_vae_subpixel_upsampler_matches_two_step_on_gpu(hip):
+    """The engine's sub-pixel upsampler against the reference's two steps on the device (bf16 storage both): they differ by
+    one rounding of the merged weights / of the upsampled intermediate, far below the parity budget of the decoder."""
+    config, weights, vae_mod = sub("config"), sub("weights"), sub("vae")
+    cfg = config.VAE_V3
+    sd = weights.synth_vae_state_dict(cfg, device="cuda")
+    z = (torch.randn(3, 12, 10, cfg.latent_channels, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 0.5).to(BF16)
+    a = vae_mod.VideoVAEEngine(cfg, sd, hip, merge_upsamplers=False).decode(z).float()
+    eng = vae_mod.VideoVAEEngine(cfg, sd, hip)
+    assert any(up is not None and up.merged is not None for _, up in eng.dec_up)
+    b = eng.decode(z).float()
+    e = rel_err(b, a)
+    print(f"sub-pixel vs two-step upsampler, decode rel-err {e:.3e}")
+    assert a.shape == b.shape and e < 8e-3
+    assert torch.equal(eng.decode(z, latents_per_slice=1).float(), b)          # temporal slicing stays bit-exact
+
+
 @pytest.fixture(params=[0, 4, 8], ids=["lds_weights", "wreg_4rows", "wreg_8rows"])
 def conv_variant(request, hip):
     """The three shapes of the second LDS-halo conv kernel: weights through the LDS ring (no fragment-ordered copy), weights

@@ -17,7 +17,58 @@ def vae_setup():
     config, weights, vae = sub("config"), sub("weights"), sub("vae")
     cfg = config.VAE_V3
     sd = weights.synth_vae_state_dict(cfg)
-    return cfg, sd, vae.VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=torch.float32))
+    # (the reference's two-step upsampler: with fp32 storage the engine then reproduces the goldens to ~1e-6; the sub-pixel
+    # form rounds MERGED weights to bf16 and has its own tests below)
+    return cfg, sd, vae.VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=torch.float32), merge_upsamplers=False)
+
+
+def test_subpixel_merge_matches_the_two_step_upsampler():
+    """upscale_conv (1x1x1) -> pixel shuffle -> causal 3x3x3 conv == four (3, 2, 2)-tap convs over the low-resolution input
+    with merged weights and border-aware bias, exactly (fp64), incl. one-voxel images where both borders coincide."""
+    import itertools
+    F = torch.nn.functional
+    subpixel = sub("subpixel")
+    gen = torch.Generator().manual_seed(0)
+    C, Cout = 8, 6
+    for T, H, W in ((4, 5, 7), (1, 1, 1), (3, 2, 1), (2, 1, 4)):
+        rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)
+        x, w1, b1, w3, b3 = rnd(T, H, W, C), rnd(4 * C, C), rnd(4 * C), rnd(Cout, C, 3, 3, 3), rnd(Cout)
+        # the reference's two steps ("b (x y z c) f h w -> b c (f z) (h x) (w y)", z = 1; replicate-first causal head)
+        y = (x @ w1.t() + b1).reshape(T, H, W, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(T, 2 * H, 2 * W, C)
+        z = y.permute(3, 0, 1, 2)[None]
+        z = F.pad(torch.cat([z[:, :, :1]] * 2 + [z], 2), (1, 1, 1, 1))
+        want = F.conv3d(z, w3, b3)[0].permute(1, 2, 3, 0)
+        got = torch.zeros_like(want)
+        xi = x.permute(3, 0, 1, 2)[None]
+        xi = torch.cat([xi[:, :, :1]] * 2 + [xi], 2)
+        parts = subpixel.merge_spatial_upsampler(w1, b1, w3, b3)
+        assert [(p[0], p[1]) for p in parts] == list(itertools.product(range(2), range(2)))
+        for py, px, wm, bias, bb in parts:
+            wm, bias, bb = wm.double(), bias.double(), bb.double()       # (the merge works in fp32: compare at that precision)
+            o = F.conv3d(F.pad(xi, (1 - px, px, 1 - py, py)), wm)[0].permute(1, 2, 3, 0)
+            b = bias.expand(T, H, W, Cout).clone()
+            rb, cb = (H - 1 if py else 0), (W - 1 if px else 0)
+            b[:, rb] = bb[0]
+            b[:, :, cb] = bb[1]
+            b[:, rb, cb] = bb[2]
+            got[:, py::2, px::2] = o + b
+        assert rel_err(got, want) < 2e-6
+
+
+def test_vae_subpixel_upsampler_in_the_engine(vae_setup):
+    """Engine with the sub-pixel upsampler == engine with the reference's two steps up to the bf16 rounding of the merged
+    weights (fp32 activations on CPU): untiled, temporally sliced (the causal memory is the low-resolution input's tail) and
+    tiled."""
+    cfg, sd, two_step = vae_setup
+    merged = sub("vae").VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=torch.float32))
+    assert any(up is not None and up.merged is not None for _, up in merged.dec_up)
+    assert all(up is None or up.merged is None for _, up in two_step.dec_up)
+    z = torch.randn(3, 6, 5, cfg.latent_channels, generator=torch.Generator().manual_seed(3)) * 0.5
+    a, b = two_step.decode(z), merged.decode(z)
+    assert a.shape == b.shape and 1e-5 < rel_err(b, a) < 4e-3
+    assert rel_err(merged.decode(z, latents_per_slice=1), b) < 1e-5      # (fp32 torch convs: not bit-stable across shapes)
+    tile = dict(tiled=True, tile_size=(32, 32), tile_overlap=(8, 8))
+    assert rel_err(merged.decode(z, **tile), two_step.decode(z, **tile)) < 4e-3
 
 
 def test_dit_engine_host_logic_matches_reference_golden():
