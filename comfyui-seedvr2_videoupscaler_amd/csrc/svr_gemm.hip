@@ -42,7 +42,7 @@ SVR_DEVICE int64_t phase_offset(const svr_gemm_args& a, int m, int n, int& borde
     const int yo = r2 % a.conv.Ho;
     const int to = r2 / a.conv.Ho;
     border = (yo == (a.phase.py ? a.conv.Ho - 1 : 0) ? 1 : 0) | (xo == (a.phase.px ? a.conv.Wo - 1 : 0) ? 2 : 0);
-    return (((int64_t)to * (2 * a.conv.Ho) + 2 * yo + a.phase.py) * (2 * a.conv.Wo) + 2 * xo + a.phase.px) * a.N + n;
+    return (((int64_t)to * a.phase.t_stride * (2 * a.conv.Ho) + 2 * yo + a.phase.py) * (2 * a.conv.Wo) + 2 * xo + a.phase.px) * a.N + n;
 }
 
 // One lane's 4 consecutive output columns of row m (n .. n+3): fused epilogue + store.
@@ -500,7 +500,8 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     if (a.phase.enabled) {
         const svr_conv_geom& g = a.conv;
         if (!g.enabled || g.st != 1 || g.sh != 1 || g.sw != 1 || g.Ho != g.H || g.Wo != g.W || a.ps.enabled || a.resid || a.gn_partial ||
-            a.epilogue == SVR_EPI_SWIGLU || (unsigned)a.phase.py > 1u || (unsigned)a.phase.px > 1u) {
+            a.epilogue == SVR_EPI_SWIGLU || (unsigned)a.phase.py > 1u || (unsigned)a.phase.px > 1u ||
+            (a.phase.t_stride != 1 && a.phase.t_stride != 2)) {
             *why = "svr_gemm_bf16: phase scatter needs a stride-1 same-size conv without ps / residual / SwiGLU / fused statistics"; return -1;
         }
     }

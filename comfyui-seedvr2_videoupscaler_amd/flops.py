@@ -67,9 +67,9 @@ def vae_encode_flops(cfg: VAEConfig, T: int, H: int, W: int) -> dict:
 
 
 def vae_decode_flops(cfg: VAEConfig, Tl: int, h: int, w: int, merged_upsamplers: bool = False) -> dict:
-    """``merged_upsamplers``: count the spatial-only upsampler as the engine runs it by default (four sub-pixel convs over
-    the low-resolution input, subpixel.py: 3 x 2 x 2 taps per output voxel, no upscale_conv) instead of as the reference's
-    upscale_conv + 3x3x3 conv."""
+    """``merged_upsamplers``: count the upsamplers as the engine runs them by default (sub-pixel convs over the
+    low-resolution input, subpixel.py: 3 x 2 x 2 taps per output voxel for the spatial-only one, 2 x 2 x 2 for the temporal
+    ones, no upscale_conv) instead of as the reference's upscale_conv + 3x3x3 conv."""
     ch = list(reversed(cfg.block_out_channels))
     n = len(ch)
     t, c = Tl, ch[0]
@@ -83,9 +83,9 @@ def vae_decode_flops(cfg: VAEConfig, Tl: int, h: int, w: int, merged_upsamplers:
         if i != n - 1:
             temporal = i < cfg.temporal_scale_num
             rz = 2 if temporal else 1
-            if merged_upsamplers and not temporal:
-                h, w = h * 2, w * 2
-                conv += conv_flops(c, c, (3, 2, 2), t * h * w)
+            if merged_upsamplers:                          # sub-pixel form: (3, 2, 2) / (2, 2, 2) taps per output voxel
+                t, h, w = (t * 2 - 1 if temporal else t), h * 2, w * 2
+                conv += conv_flops(c, c, (2 if temporal else 3, 2, 2), t * h * w)
                 continue
             conv += conv_flops(c, c * 4 * rz, (1, 1, 1), t * h * w)
             t, h, w = (t * 2 - 1 if temporal else t), h * 2, w * 2

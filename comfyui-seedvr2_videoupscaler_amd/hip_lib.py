@@ -37,7 +37,7 @@ class PixelShuffle(C.Structure):
 
 
 class PhaseScatter(C.Structure):
-    _fields_ = [("enabled", C.c_int32), ("py", C.c_int32), ("px", C.c_int32), ("pad_", C.c_int32),
+    _fields_ = [("enabled", C.c_int32), ("py", C.c_int32), ("px", C.c_int32), ("t_stride", C.c_int32),
                 ("bias_border", C.c_void_p)]
 
 

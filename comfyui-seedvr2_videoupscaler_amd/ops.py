@@ -42,11 +42,13 @@ class PixelShuffleGeom:
 
 @dataclass
 class PhaseScatter:
-    """Sub-pixel convolution launch: the conv's output voxel (t, y, x) lands at out[t, 2y + py, 2x + px]; ``bias_border``
-    fp32 [3, N]: bias on the voxels whose window loses its border tap (row border | column border | both)."""
+    """Sub-pixel convolution launch: the conv's output voxel (t, y, x) lands at out[t * t_stride, 2y + py, 2x + px] (``out``
+    = the upsampled tensor from the launch's first frame on); ``bias_border`` fp32 [3, N]: bias on the voxels whose window
+    loses its border tap (row border | column border | both)."""
     py: int
     px: int
     bias_border: Optional[torch.Tensor] = None
+    t_stride: int = 1
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -141,9 +143,9 @@ class HipOps:
         if phase is not None:
             if conv is None or ps is not None or resid is not None or gn_groups:
                 raise ValueError("phase scatter: conv mode only, without pixel shuffle / residual / fused statistics")
-            if out.numel() != 4 * M * N:
-                raise ValueError("phase scatter: out must be the dense [To, 2*Ho, 2*Wo, N] tensor")
-            a.phase.enabled, a.phase.py, a.phase.px = 1, int(phase.py), int(phase.px)
+            if out.numel() < ((conv.To - 1) * phase.t_stride + 1) * 4 * conv.Ho * conv.Wo * N or not out.is_contiguous():
+                raise ValueError("phase scatter: out must be the dense [frames, 2*Ho, 2*Wo, N] tensor from the launch's first frame on")
+            a.phase.enabled, a.phase.py, a.phase.px, a.phase.t_stride = 1, int(phase.py), int(phase.px), int(phase.t_stride)
             if phase.bias_border is not None:
                 if tuple(phase.bias_border.shape) != (3, N):
                     raise ValueError("phase scatter: bias_border must be [3, N]")

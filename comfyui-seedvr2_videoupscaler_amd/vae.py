@@ -77,9 +77,9 @@ class _Up:
     conv: _Conv
     temporal: bool
     C: int
-    # spatial-only upsamplers: the four sub-pixel convs that replace upscale_conv + pixel shuffle + conv (subpixel.py):
-    # [(py, px, packed weight [Cout, kt*2*2*C], bias [Cout], bias_border [3, Cout])]
-    merged: Optional[list] = None
+    # sub-pixel form (subpixel.py): signature -> (temporal window length, [(py, px, packed weight [Cout, kt'*2*2*C], bias [Cout],
+    # bias_border [3, Cout])]) for the tap patterns this upsampler meets (1 if spatial-only, 5 if temporal)
+    merged: Optional[dict] = None
 
 
 def _tile_ranges(total: int, tile: int, overlap: int) -> List[Tuple[int, int]]:
@@ -187,13 +187,21 @@ class VideoVAEEngine:
                 w = sd[u + ".upscale_conv.weight"]
                 up = _Up(pack_matrix(w.reshape(w.shape[0], w.shape[1]), dev), pack_vec(sd[u + ".upscale_conv.bias"], dev),
                          conv(u + ".conv"), i < cfg.temporal_scale_num, w.shape[1])
-                if merge_upsamplers and not up.temporal and w.shape[1] % 64 == 0:
+                if merge_upsamplers and w.shape[1] % 64 == 0:
                     # (weights as the reference holds them: cast to bf16 at load, model_loader.py:583-584; merged in fp32)
-                    w3 = sd[u + ".conv.weight"]
-                    parts = subpixel.merge_spatial_upsampler(
-                        w.reshape(w.shape[0], w.shape[1]).to(device=dev, dtype=BF16), sd[u + ".upscale_conv.bias"].to(device=dev, dtype=BF16),
-                        w3.to(device=dev, dtype=BF16), sd[u + ".conv.bias"].to(device=dev, dtype=BF16))
-                    up.merged = [(py, px, pack_conv3d(wm, dev), b.contiguous(), bb.contiguous()) for py, px, wm, b, bb in parts]
+                    rz = 2 if up.temporal else 1
+                    w1 = w.reshape(w.shape[0], w.shape[1]).to(device=dev, dtype=BF16)
+                    b1 = sd[u + ".upscale_conv.bias"].to(device=dev, dtype=BF16)
+                    w3, b3 = sd[u + ".conv.weight"].to(device=dev, dtype=BF16), sd[u + ".conv.bias"].to(device=dev, dtype=BF16)
+                    up.merged = {}
+                    # temporal: the three head patterns + the two steady-state parities; spatial-only: the steady-state window
+                    # (the conv's own replicate-first padding serves the head)
+                    for i in (range(5) if up.temporal else (w3.shape[2] - 1,)):
+                        sig = subpixel.signature(i, rz, w3.shape[2])
+                        if sig not in up.merged:
+                            srcs, parts = subpixel.merge_upsampler(w1, b1, w3, b3, rz, sig)
+                            up.merged[sig] = (len(srcs), [(py, px, pack_conv3d(wm, dev), b.contiguous(), bb.contiguous())
+                                                          for py, px, wm, b, bb in parts])
             self.dec_up.append((res, up))
         self.dec_norm_out = norm("decoder.conv_norm_out")
         self.dec_conv_out = conv("decoder.conv_out")
@@ -366,30 +374,67 @@ class VideoVAEEngine:
         return self._conv(up.conv, y, st, first, gn=True)
 
     def _upsample_subpixel(self, up: _Up, x, st, first):
-        """Spatial-only upsampler as four (kt, 2, 2)-tap convs over the low-resolution input, one per output phase, each
-        scattering into its positions of the 2x grid.  The causal memory of the reference's conv (the last kt - 1 frames of
-        its upsampled input) becomes the last kt - 1 frames of the LOW-resolution input: the upsampling is pointwise in
-        time.  -> (y, None): GroupNorm statistics are taken by the caller (these launches cannot fuse them)."""
+        """Upsampler as (kt', 2, 2)-tap convs over the low-resolution input, one launch per output phase, each scattering
+        into its positions of the upsampled tensor (subpixel.py).  The causal memory of the reference's conv (the last frames
+        of its upsampled input) becomes the last frame(s) of the LOW-resolution input, and the tap pattern of an output
+        frame depends on its index in the whole clip, so the number of low-resolution frames consumed so far travels in
+        the slice state.  -> (y, None): GroupNorm statistics are taken by the caller (these launches cannot fuse them)."""
         ops, cw = self.ops, up.conv
         T, H, W, Cc = x.shape
+        rz = 2 if up.temporal else 1
         kt = cw.k[0]
         key = cw.name + "#subpixel"
-        halo = None if first else st.get(key)
-        if not first and kt > 1 and halo is None:
-            raise RuntimeError(f"{cw.name}: missing temporal halo for a non-initial slice")
-        pt = (kt - 1) if first else (halo.shape[0] if halo is not None else 0)
-        To = T + pt - kt + 1
-        y = ops.empty(To, 2 * H, 2 * W, cw.cout)
-        for py, px, w, b, bb in up.merged:
-            geom = Conv3dGeom(T, H, W, Cc, To, H, W, (kt, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
-            ops.gemm(x, w, y, N=cw.cout, K=w.shape[1], bias=b, conv=geom, phase=PhaseScatter(py, px, bb))
-        carry = kt - 1
-        if carry > 0 and not st.get("__last_slice__", False):
-            if T >= carry:
-                st[key] = x[T - carry:].clone()
+        t0 = 0 if first else st.get(key + "#frames")
+        mem = None if first else st.get(key)
+        if not first and (t0 is None or mem is None):
+            raise RuntimeError(f"{cw.name}: missing temporal state for a non-initial slice")
+        carry = kt - 1 if rz == 1 else 1                   # low-resolution frames the next slice needs
+        outs = [subpixel.output_frames(t0 + tl, rz) for tl in range(T)]
+        y = ops.empty(sum(len(o) for o in outs), 2 * H, 2 * W, cw.cout)
+
+        def launch(sig, a, b, base, t_stride):
+            """frames a..b-1 of this slice -> y[base + j * t_stride] with the merged weights of `sig`."""
+            n_src, parts = up.merged[sig]
+            pt = n_src - 1
+            if pt == 0:
+                halo = None
+            elif a >= pt:
+                halo = x[a - pt:a]
+            elif mem is None:                                # head of the clip: replicate frame 0 (only rz = 1 gets here)
+                halo = None if a == 0 else torch.cat([x[:1].expand(pt - a, H, W, Cc), x[:a]], 0).contiguous()
             else:
-                prev = halo if halo is not None else x[:1].expand(pt, H, W, Cc)
-                st[key] = torch.cat([prev, x], dim=0)[-carry:].contiguous()
+                halo = mem[mem.shape[0] - pt:] if a == 0 else torch.cat([mem[mem.shape[0] - (pt - a):], x[:a]], 0).contiguous()
+            geom_in = x[a:b]
+            for py, px, w, bias, bb in parts:
+                geom = Conv3dGeom(b - a, H, W, Cc, b - a, H, W, (n_src, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
+                ops.gemm(geom_in, w, y[base:], N=cw.cout, K=w.shape[1], bias=bias, conv=geom,
+                         phase=PhaseScatter(py, px, bb, t_stride))
+
+        if rz == 1:
+            launch(subpixel.signature(kt - 1, 1, kt), 0, T, 0, 1)
+        else:
+            base, tl = 0, 0
+            while tl < T:
+                tg = t0 + tl
+                if tg == 0:                                  # frame 0 of the clip: its single output frame
+                    launch(subpixel.signature(0, 2, kt), tl, tl + 1, base, 1)
+                    base, tl = base + 1, tl + 1
+                elif tg == 1:                                # the two head patterns that still see frame 0's dropped sub-frame
+                    launch(subpixel.signature(1, 2, kt), tl, tl + 1, base, 1)
+                    launch(subpixel.signature(2, 2, kt), tl, tl + 1, base + 1, 1)
+                    base, tl = base + 2, tl + 1
+                else:                                        # steady state: both temporal phases of every remaining frame
+                    launch(subpixel.signature(3, 2, kt), tl, T, base, 2)
+                    launch(subpixel.signature(4, 2, kt), tl, T, base + 1, 2)
+                    base, tl = base + 2 * (T - tl), T
+        if not st.get("__last_slice__", False):
+            st[key + "#frames"] = t0 + T
+            if carry > 0:
+                if T >= carry:
+                    st[key] = x[T - carry:].clone()
+                else:
+                    prev = mem if mem is not None else x[:1].expand(carry, H, W, Cc)
+                    st[key] = torch.cat([prev, x], dim=0)[-carry:].contiguous()
         return y, None
 
     # ------------------------------------------------------------------ one temporal slice through a network

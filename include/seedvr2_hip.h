@@ -57,11 +57,13 @@ typedef struct svr_pixel_shuffle {
 typedef struct svr_phase_scatter {
     int32_t enabled;            /* conv mode, stride 1: this launch computes ONE output phase of a 2x spatially upsampled
                                    grid ("sub-pixel convolution"): output voxel (to, yo, xo) of the conv is stored at
-                                   C[to][2*yo + py][2*xo + px][n], C dense [To, 2*Ho, 2*Wo, N].  Used to run Upsample3D's
-                                   1x1x1 upscale_conv + pixel shuffle + 3x3x3 conv (attn_video_vae.py:110-174) as four
-                                   (kt, 2, 2)-tap convs over the LOW-resolution input with merged weights.            */
+                                   C[to * t_stride][2*yo + py][2*xo + px][n], C dense [*, 2*Ho, 2*Wo, N] (the caller offsets C to
+                                   the first frame of the launch).  Used to run Upsample3D's 1x1x1 upscale_conv + pixel
+                                   shuffle + 3x3x3 conv (attn_video_vae.py:110-174) as (kt', 2, 2)-tap convs over the
+                                   LOW-resolution input with merged weights: four spatial phases, and for a temporal
+                                   upsampler two temporal phases (t_stride 2) interleaving their frames.              */
     int32_t py, px;             /* 0 | 1                                                                              */
-    int32_t pad_;
+    int32_t t_stride;           /* 1 | 2: output frames between consecutive conv output frames                        */
     const float* bias_border;   /* fp32 [3][N] or NULL: bias used INSTEAD of `bias` on the voxels whose window loses its
                                    border tap to the zero padding of the upsampled grid -- row yo == (py ? Ho-1 : 0):
                                    [0]; column xo == (px ? Wo-1 : 0): [1]; both: [2]                                  */

@@ -87,8 +87,9 @@ class TorchOps:
                     res = res + resid.reshape(M, -1)[:, :N].float()
         if phase is not None:
             g = conv
-            o4 = out.reshape(g.To, 2 * g.Ho, 2 * g.Wo, N)
-            o4[:, phase.py::2, phase.px::2, :] = res.reshape(g.To, g.Ho, g.Wo, N).to(out.dtype)
+            ts = getattr(phase, "t_stride", 1)
+            o4 = out.reshape(-1, 2 * g.Ho, 2 * g.Wo, N)
+            o4[0:(g.To - 1) * ts + 1:ts, phase.py::2, phase.px::2, :] = res.reshape(g.To, g.Ho, g.Wo, N).to(out.dtype)
             return out
         if ps is not None:
             r = res.reshape(ps.F, ps.H, ps.W, 2, 2, ps.rz, ps.C).permute(0, 5, 1, 3, 2, 4, 6)

@@ -397,37 +397,39 @@ def test_gemm_epilogue_paths_bit_identical(hip):
         both(run_conv)
 
 
-@pytest.mark.parametrize("T,H,W,Cin,Cout,hf", [(3, 9, 11, 128, 128, 0), (2, 16, 20, 256, 256, 2), (4, 1, 5, 64, 128, 0)])
-def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, T, H, W, Cin, Cout, hf):
-    """Sub-pixel convolution launches (svr_gemm_args.phase): four (3, 2, 2)-tap convs over the low-resolution input, each
-    scattering into its phase of the 2x grid with its own border bias == the torch restatement; together they write every
-    voxel of the output exactly once (NaN canary)."""
+@pytest.mark.parametrize("T,H,W,Cin,Cout,hf,kt,ts", [(3, 9, 11, 128, 128, 0, 3, 1), (2, 16, 20, 256, 256, 2, 3, 1), (4, 1, 5, 64, 128, 0, 3, 1),
+                                                     (3, 7, 9, 128, 128, 1, 2, 2), (1, 4, 4, 64, 128, 0, 1, 1)])
+def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, T, H, W, Cin, Cout, hf, kt, ts):
+    """Sub-pixel convolution launches (svr_gemm_args.phase): (kt, 2, 2)-tap convs over the low-resolution input, each
+    scattering into its spatial phase of the 2x grid -- and, with t_stride 2, into every other frame from its first one on --
+    with its own border bias == the torch restatement; together they write every voxel of the output exactly once (NaN canary)."""
     packing, opsmod = sub("packing"), sub("ops")
     x = rnd(T, H, W, Cin)
     halo = rnd(hf, H, W, Cin, seed=9) if hf else None
-    pt = hf if hf else 2
-    To = T + pt - 3 + 1
-    out = torch.full((To, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=BF16)
-    want = torch.full((To, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=torch.float32)
-    for ph, (py, px) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
-        w5 = rnd(Cout, Cin, 3, 2, 2, scale=1.0 / math.sqrt(Cin * 12), seed=20 + ph)
-        Wp = packing.pack_conv3d(w5, "cuda")
-        bias = rnd(Cout, dtype=torch.float32, seed=30 + ph)
-        bb = rnd(3, Cout, dtype=torch.float32, seed=40 + ph)
-        geom = opsmod.Conv3dGeom(T, H, W, Cin, To, H, W, (3, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
-        kw = dict(N=Cout, K=Wp.shape[1], bias=bias, conv=geom, phase=opsmod.PhaseScatter(py, px, bb))
-        hip.gemm(x, Wp, out, **kw)
-        ref.gemm(x, Wp, want, **kw)
-        # independent check of the restatement on this phase: F.conv3d of the padded input + per-voxel bias
-        head = halo.float() if hf else x[:1].float().expand(pt, H, W, Cin)
-        xin = torch.nn.functional.pad(torch.cat([head, x.float()], 0).permute(3, 0, 1, 2)[None], (1 - px, px, 1 - py, py))
-        y = torch.nn.functional.conv3d(xin, w5.float())[0].permute(1, 2, 3, 0)
-        b = bias.expand(To, H, W, Cout).clone()
-        rb, cb = (H - 1 if py else 0), (W - 1 if px else 0)
-        b[:, rb] = bb[0]
-        b[:, :, cb] = bb[1]
-        b[:, rb, cb] = bb[2]
-        assert rel_err(want[:, py::2, px::2], y + b) < 1e-5
+    pt = hf if hf else kt - 1
+    To = T + pt - kt + 1
+    out = torch.full((To * ts, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=BF16)
+    want = torch.full((To * ts, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=torch.float32)
+    for tz in range(ts):                                                           # temporal phase = first frame of the launch
+        for ph, (py, px) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+            w5 = rnd(Cout, Cin, kt, 2, 2, scale=1.0 / math.sqrt(Cin * 4 * kt), seed=20 + ph + 7 * tz)
+            Wp = packing.pack_conv3d(w5, "cuda")
+            bias = rnd(Cout, dtype=torch.float32, seed=30 + ph)
+            bb = rnd(3, Cout, dtype=torch.float32, seed=40 + ph)
+            geom = opsmod.Conv3dGeom(T, H, W, Cin, To, H, W, (kt, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
+            kw = dict(N=Cout, K=Wp.shape[1], bias=bias, conv=geom, phase=opsmod.PhaseScatter(py, px, bb, ts))
+            hip.gemm(x, Wp, out[tz:], **kw)
+            ref.gemm(x, Wp, want[tz:], **kw)
+            # independent check of the restatement on this phase: F.conv3d of the padded input + per-voxel bias
+            head = halo.float() if hf else x[:1].float().expand(pt, H, W, Cin)
+            xin = torch.nn.functional.pad(torch.cat([head, x.float()], 0).permute(3, 0, 1, 2)[None], (1 - px, px, 1 - py, py))
+            y = torch.nn.functional.conv3d(xin, w5.float())[0].permute(1, 2, 3, 0)
+            b = bias.expand(To, H, W, Cout).clone()
+            rb, cb = (H - 1 if py else 0), (W - 1 if px else 0)
+            b[:, rb] = bb[0]
+            b[:, :, cb] = bb[1]
+            b[:, rb, cb] = bb[2]
+            assert rel_err(want[tz::ts, py::2, px::2], y + b) < 1e-5
     assert not torch.isnan(out.float()).any() and not torch.isnan(want).any()
     assert rel_err(out.float(), want) < TOL_BF16
 
@@ -438,15 +440,18 @@ def test_vae_subpixel_upsampler_matches_two_step_on_gpu(hip):
     config, weights, vae_mod = sub("config"), sub("weights"), sub("vae")
     cfg = config.VAE_V3
     sd = weights.synth_vae_state_dict(cfg, device="cuda")
-    z = (torch.randn(3, 12, 10, cfg.latent_channels, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 0.5).to(BF16)
+    z = (torch.randn(5, 12, 10, cfg.latent_channels, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 0.5).to(BF16)
     a = vae_mod.VideoVAEEngine(cfg, sd, hip, merge_upsamplers=False).decode(z).float()
     eng = vae_mod.VideoVAEEngine(cfg, sd, hip)
-    assert any(up is not None and up.merged is not None for _, up in eng.dec_up)
+    assert all(up is None or up.merged is not None for _, up in eng.dec_up)
     b = eng.decode(z).float()
     e = rel_err(b, a)
-    print(f"sub-pixel vs two-step upsampler, decode rel-err {e:.3e}")
-    assert a.shape == b.shape and e < 8e-3
-    assert torch.equal(eng.decode(z, latents_per_slice=1).float(), b)          # temporal slicing stays bit-exact
+    print(f"sub-pixel vs two-step upsamplers, decode rel-err {e:.3e}")
+    assert a.shape == b.shape and e < 2e-2          # (two bf16 paths, each ~1e-2 from the fp32 reference: tests/test_gpu_parity.py holds the real bound)
+    for per_slice in (1, 2, 3):                                                # temporal slicing stays bit-exact
+        assert torch.equal(eng.decode(z, latents_per_slice=per_slice).float(), b), per_slice
+    one = eng.decode(z[:1]).float()                                            # a single latent frame: the head pattern only
+    assert rel_err(one, vae_mod.VideoVAEEngine(cfg, sd, hip, merge_upsamplers=False).decode(z[:1]).float()) < 2e-2
 
 
 @pytest.fixture(params=[0, 4, 8], ids=["lds_weights", "wreg_4rows", "wreg_8rows"])

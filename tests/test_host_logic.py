@@ -22,37 +22,56 @@ def vae_setup():
     return cfg, sd, vae.VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=torch.float32), merge_upsamplers=False)
 
 
-def test_subpixel_merge_matches_the_two_step_upsampler():
-    """upscale_conv (1x1x1) -> pixel shuffle -> causal 3x3x3 conv == four (3, 2, 2)-tap convs over the low-resolution input
-    with merged weights and border-aware bias, exactly (fp64), incl. one-voxel images where both borders coincide."""
-    import itertools
+def _two_step_upsampler(x, w1, b1, w3, b3, rz):
+    """The reference's Upsample3D in torch: upscale_conv, "b (x y z c) f h w -> b c (f z) (h x) (w y)", remove_head on a temporal
+    upsampler, replicate-first causal head, zero spatial padding, 3x3x3 conv (attn_video_vae.py:110-174)."""
+    F = torch.nn.functional
+    T, H, W, C = x.shape
+    y = (x @ w1.t() + b1).reshape(T, H, W, 2, 2, rz, C).permute(0, 5, 1, 3, 2, 4, 6).reshape(rz * T, 2 * H, 2 * W, C)
+    if rz == 2:
+        y = torch.cat([y[:1], y[2:]], 0)
+    z = y.permute(3, 0, 1, 2)[None]
+    z = F.pad(torch.cat([z[:, :, :1]] * 2 + [z], 2), (1, 1, 1, 1))
+    return F.conv3d(z, w3, b3)[0].permute(1, 2, 3, 0)
+
+
+@pytest.mark.parametrize("rz", [1, 2])
+def test_subpixel_merge_matches_the_two_step_upsampler(rz):
+    """upscale_conv -> pixel shuffle -> (remove_head) -> causal 3x3x3 conv == small convs over the low-resolution input with
+    merged weights and border-aware bias, exactly (fp64), for any temporal slicing, incl. one-voxel images where both borders
+    coincide and clips shorter than the head patterns."""
     F = torch.nn.functional
     subpixel = sub("subpixel")
-    gen = torch.Generator().manual_seed(0)
-    C, Cout = 8, 6
-    for T, H, W in ((4, 5, 7), (1, 1, 1), (3, 2, 1), (2, 1, 4)):
+    gen = torch.Generator().manual_seed(rz)
+    C, Cout = 4, 5
+    for T, H, W, slices in ((5, 3, 4, [5]), (5, 3, 4, [1, 1, 1, 1, 1]), (6, 2, 2, [2, 3, 1]), (1, 1, 1, [1]), (2, 1, 3, [1, 1]), (4, 5, 1, [3, 1])):
         rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)
-        x, w1, b1, w3, b3 = rnd(T, H, W, C), rnd(4 * C, C), rnd(4 * C), rnd(Cout, C, 3, 3, 3), rnd(Cout)
-        # the reference's two steps ("b (x y z c) f h w -> b c (f z) (h x) (w y)", z = 1; replicate-first causal head)
-        y = (x @ w1.t() + b1).reshape(T, H, W, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(T, 2 * H, 2 * W, C)
-        z = y.permute(3, 0, 1, 2)[None]
-        z = F.pad(torch.cat([z[:, :, :1]] * 2 + [z], 2), (1, 1, 1, 1))
-        want = F.conv3d(z, w3, b3)[0].permute(1, 2, 3, 0)
-        got = torch.zeros_like(want)
-        xi = x.permute(3, 0, 1, 2)[None]
-        xi = torch.cat([xi[:, :, :1]] * 2 + [xi], 2)
-        parts = subpixel.merge_spatial_upsampler(w1, b1, w3, b3)
-        assert [(p[0], p[1]) for p in parts] == list(itertools.product(range(2), range(2)))
-        for py, px, wm, bias, bb in parts:
-            wm, bias, bb = wm.double(), bias.double(), bb.double()       # (the merge works in fp32: compare at that precision)
-            o = F.conv3d(F.pad(xi, (1 - px, px, 1 - py, py)), wm)[0].permute(1, 2, 3, 0)
-            b = bias.expand(T, H, W, Cout).clone()
-            rb, cb = (H - 1 if py else 0), (W - 1 if px else 0)
-            b[:, rb] = bb[0]
-            b[:, :, cb] = bb[1]
-            b[:, rb, cb] = bb[2]
-            got[:, py::2, px::2] = o + b
-        assert rel_err(got, want) < 2e-6
+        x, w1, b1, w3, b3 = rnd(T, H, W, C), rnd(4 * rz * C, C), rnd(4 * rz * C), rnd(Cout, C, 3, 3, 3), rnd(Cout)
+        want = _two_step_upsampler(x, w1, b1, w3, b3, rz)
+        got = torch.full_like(want, float("nan"))
+        sets = {}
+        t0 = 0
+        for n in slices:
+            for t in range(t0, t0 + n):
+                for i in subpixel.output_frames(t, rz):
+                    sig = subpixel.signature(i, rz)
+                    if sig not in sets:
+                        sets[sig] = subpixel.merge_upsampler(w1, b1, w3, b3, rz, sig)
+                    srcs, parts = sets[sig]
+                    frames = torch.stack([x[max(t + s, 0)] for s in srcs], 0)            # (the clamp = the replicated head)
+                    xin = frames.permute(3, 0, 1, 2)[None]
+                    for py, px, wm, bias, bb in parts:
+                        o = F.conv3d(F.pad(xin, (1 - px, px, 1 - py, py)), wm.double())[0].permute(1, 2, 3, 0)
+                        b = bias.double().expand(1, H, W, Cout).clone()
+                        rb, cb = (H - 1 if py else 0), (W - 1 if px else 0)
+                        b[:, rb] = bb[0].double()
+                        b[:, :, cb] = bb[1].double()
+                        b[:, rb, cb] = bb[2].double()
+                        got[i:i + 1, py::2, px::2] = o + b
+            t0 += n
+        assert not torch.isnan(got).any()
+        assert rel_err(got, want) < 2e-6                        # (the merge itself works in fp32)
+        assert len(sets) <= (5 if rz == 2 else 3)
 
 
 def test_vae_subpixel_upsampler_in_the_engine(vae_setup):
@@ -61,12 +80,15 @@ def test_vae_subpixel_upsampler_in_the_engine(vae_setup):
     tiled."""
     cfg, sd, two_step = vae_setup
     merged = sub("vae").VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=torch.float32))
-    assert any(up is not None and up.merged is not None for _, up in merged.dec_up)
+    assert all(up is None or up.merged is not None for _, up in merged.dec_up)
     assert all(up is None or up.merged is None for _, up in two_step.dec_up)
-    z = torch.randn(3, 6, 5, cfg.latent_channels, generator=torch.Generator().manual_seed(3)) * 0.5
+    assert sorted(len(up.merged) for _, up in merged.dec_up if up is not None) == [1, 5, 5]
+    z = torch.randn(4, 6, 5, cfg.latent_channels, generator=torch.Generator().manual_seed(3)) * 0.5
     a, b = two_step.decode(z), merged.decode(z)
-    assert a.shape == b.shape and 1e-5 < rel_err(b, a) < 4e-3
-    assert rel_err(merged.decode(z, latents_per_slice=1), b) < 1e-5      # (fp32 torch convs: not bit-stable across shapes)
+    assert a.shape == b.shape and 1e-5 < rel_err(b, a) < 6e-3
+    for per_slice in (1, 2, 3):                                  # (fp32 torch convs: not bit-stable across shapes)
+        assert rel_err(merged.decode(z, latents_per_slice=per_slice), b) < 1e-5
+    assert rel_err(merged.decode(z[:1]), two_step.decode(z[:1])) < 6e-3          # a single latent frame: the head pattern only
     tile = dict(tiled=True, tile_size=(32, 32), tile_overlap=(8, 8))
     assert rel_err(merged.decode(z, **tile), two_step.decode(z, **tile)) < 4e-3
 
