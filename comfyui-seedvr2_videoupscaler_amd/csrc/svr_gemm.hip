@@ -160,13 +160,16 @@ SVR_DEVICE void epilogue_store8(const svr_gemm_args& a, const float (&acc8)[8], 
     }
     int border = 0;
     const int64_t poff = a.phase.enabled ? phase_offset(a, m, n, border) : 0;
-    if (border && a.phase.bias_border) {            // (rare: one-voxel frame of the image)
-        const float* bb = a.phase.bias_border + (int64_t)(border - 1) * a.N + n;
+    {
+        // (border voxels -- a one-voxel frame of the image -- take their bias from the table; element-wise selects keep v[] in registers)
+        const bool tab = border && a.phase.bias_border;
+        const float* bb = tab ? a.phase.bias_border + (int64_t)(border - 1) * a.N + n : nullptr;
+        float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+        if (tab) { t0 = *(const float4*)bb; t1 = *(const float4*)(bb + 4); }
+        const float bsel[8] = {tab ? t0.x : bias8[0], tab ? t0.y : bias8[1], tab ? t0.z : bias8[2], tab ? t0.w : bias8[3],
+                               tab ? t1.x : bias8[4], tab ? t1.y : bias8[5], tab ? t1.z : bias8[6], tab ? t1.w : bias8[7]};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc8[e] + bb[e];
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc8[e] + bias8[e];
+        for (int e = 0; e < 8; ++e) v[e] = acc8[e] + bsel[e];
     }
     if (epi == SVR_EPI_BIAS_SILU) {
 #pragma unroll
