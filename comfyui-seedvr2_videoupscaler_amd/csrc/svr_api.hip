@@ -8,6 +8,7 @@
 #include "svr_gemm.hip"
 #include "svr_conv_halo.hip"
 #include "svr_conv_halo2.hip"
+#include "svr_conv_sub.hip"
 #include "svr_attn_win.hip"
 #include "svr_attn.hip"
 #include "svr_elementwise.hip"
@@ -39,6 +40,7 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "gemm_epi")) { g_gemm_epi = value; return 0; }
     if (!strcmp(key, "conv_rows")) { g_conv_rows = value; return 0; }
     if (!strcmp(key, "conv_band")) { g_conv_band = value; return 0; }
+    if (!strcmp(key, "conv_sub")) { g_conv_sub = value; return 0; }
     if (!strcmp(key, "conv_lds")) { g_conv_lds_dbg = value; return 0; }
     if (!strcmp(key, "attn_impl")) { g_attn_impl = value; return 0; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return 0; }
@@ -130,6 +132,15 @@ extern "C" int svr_debug_conv_epilogue(void* dst_host, int64_t bytes) {
     return check(hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_conv_ep), (size_t)bytes), "svr_debug_conv_epilogue");
 }
 #endif
+
+int svr_conv_pack_frag_taps(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t kh, int32_t kw, int32_t Cin, void* stream) {
+    if (N <= 0 || N % 32 || Cin <= 0 || Cin % 32 || kt < 1 || kt > 3 || kh < 1 || kh > 3 || kw < 1 || kw > 3 || K != kt * kh * kw * Cin)
+        return fail("svr_conv_pack_frag_taps: need N % 32 == 0, Cin % 32 == 0, kt, kh, kw in 1..3, K == kt * kh * kw * Cin");
+    const int64_t chunks = (int64_t)N * K / 8;
+    hipLaunchKernelGGL(conv_pack_frag_taps_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)W, (uint4*)out, N, K, kt, kh, kw, Cin);
+    return check(hipGetLastError(), "svr_conv_pack_frag_taps");
+}
 
 int svr_conv_pack_frag(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t Cin, void* stream) {
     if (N <= 0 || N % 32 || Cin <= 0 || Cin % 32 || kt < 1 || kt > 3 || K != kt * 9 * Cin)

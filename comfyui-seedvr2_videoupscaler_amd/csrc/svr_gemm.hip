@@ -459,6 +459,9 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s);
 static bool conv_halo2_eligible(const svr_gemm_args& a);
 static bool conv_thin_eligible(const svr_gemm_args& a);
 static int launch_conv_thin(const svr_gemm_args& a, hipStream_t s);
+// sub-pixel upsampler conv kernel (svr_conv_sub.hip)
+static bool conv_sub_eligible(const svr_gemm_args& a);
+static int launch_conv_sub(const svr_gemm_args& a, hipStream_t s);
 int g_conv_impl = 0;   // 0 auto, 1 generic, 2 first halo kernel, 3 second halo kernel without W_frag
 
 // measurement-only ablation selector of the conv kernels in -DSVR_ABLATIONS builds (svr_set_option("pipe_abl"))
@@ -510,6 +513,7 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     }
     if (a.gn_partial && conv_gn_blocks(a) == 0) { *why = "svr_gemm_bf16: gn_partial set but this launch cannot produce fused GroupNorm statistics"; return -1; }
     if (conv_thin_eligible(a)) return launch_conv_thin(a, s);
+    if (conv_sub_eligible(a)) return launch_conv_sub(a, s);
     if ((g_conv_impl == 0 || g_conv_impl == 3) && conv_halo2_eligible(a)) return launch_conv_halo2(a, s);
     if (g_conv_impl != 1 && conv_halo_eligible(a))
         return a.N <= 32 ? launch_conv_halo<32>(a, s) : launch_conv_halo<128>(a, s);

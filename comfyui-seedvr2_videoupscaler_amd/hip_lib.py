@@ -60,6 +60,7 @@ _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
     "svr_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "svr_conv_pack_frag": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "svr_conv_pack_frag_taps": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "svr_gemm_gn_blocks": (C.c_int32, [C.POINTER(GemmArgs)]),
     "svr_groupnorm_reduce": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "svr_rmsnorm_mod": (C.c_int, [_vp, _vp, _i64, _i32, _f, _vp, _vp, _vp, _vp]),

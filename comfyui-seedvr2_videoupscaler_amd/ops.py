@@ -95,15 +95,17 @@ class HipOps:
         return torch.empty(*shape, dtype=dtype or BF16, device=self.device)
 
     # ------------------------------------------------------------------ GEMM / conv
-    def pack_conv_frag(self, W, kt: int, Cin: int, N: int):
-        """Fragment-ordered copy of packed conv weights W [Npad, kt*9*Cin] for gemm(..., W_frag=) (3x3 spatial taps,
-        stride 1, Cin % 32 == 0, N % 128 == 0); None when the geometry is not served by that kernel."""
-        if Cin % 64 or N % 128 or W.shape[1] != kt * 9 * Cin:
+    def pack_conv_frag(self, W, kt: int, Cin: int, N: int, taps=(3, 3)):
+        """Fragment-ordered copy of packed conv weights W [Npad, kt*kh*kw*Cin] for gemm(..., W_frag=) (3x3 spatial taps for
+        the LDS-halo kernel, 2x2 for the sub-pixel upsampler kernel; stride 1, Cin % 32 == 0, N % 128 == 0); None when the
+        geometry is not served by those kernels."""
+        kh, kw = taps
+        if Cin % 64 or N % 128 or W.shape[1] != kt * kh * kw * Cin or (kh, kw) not in ((3, 3), (2, 2)):
             return None
         self._chk(W, BF16, "W")
         out = torch.empty(N * W.shape[1], dtype=BF16, device=self.device)
-        hip_lib.check(self.lib.svr_conv_pack_frag(_ptr(W), _ptr(out), N, W.shape[1], kt, Cin, self._stream()),
-                      "svr_conv_pack_frag")
+        hip_lib.check(self.lib.svr_conv_pack_frag_taps(_ptr(W), _ptr(out), N, W.shape[1], kt, kh, kw, Cin, self._stream()),
+                      "svr_conv_pack_frag_taps")
         return out
 
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,

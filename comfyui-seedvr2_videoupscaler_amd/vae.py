@@ -78,7 +78,8 @@ class _Up:
     temporal: bool
     C: int
     # sub-pixel form (subpixel.py): signature -> (temporal window length, [(py, px, packed weight [Cout, kt'*2*2*C], bias [Cout],
-    # bias_border [3, Cout])]) for the tap patterns this upsampler meets (1 if spatial-only, 5 if temporal)
+    # bias_border [3, Cout], fragment-ordered weight copy or None)]) for the tap patterns this upsampler meets (1 if
+    # spatial-only, 5 if temporal)
     merged: Optional[dict] = None
 
 
@@ -200,8 +201,14 @@ class VideoVAEEngine:
                         sig = subpixel.signature(i, rz, w3.shape[2])
                         if sig not in up.merged:
                             srcs, parts = subpixel.merge_upsampler(w1, b1, w3, b3, rz, sig)
-                            up.merged[sig] = (len(srcs), [(py, px, pack_conv3d(wm, dev), b.contiguous(), bb.contiguous())
-                                                          for py, px, wm, b, bb in parts])
+                            packed = []
+                            for py, px, wm, b, bb in parts:
+                                wp = pack_conv3d(wm, dev)
+                                # fragment-ordered copy for the sub-pixel conv kernel (weights streamed to registers)
+                                frag = ops.pack_conv_frag(wp, len(srcs), w.shape[1], w3.shape[0], taps=(2, 2)) \
+                                    if hasattr(ops, "pack_conv_frag") else None
+                                packed.append((py, px, wp, b.contiguous(), bb.contiguous(), frag))
+                            up.merged[sig] = (len(srcs), packed)
             self.dec_up.append((res, up))
         self.dec_norm_out = norm("decoder.conv_norm_out")
         self.dec_conv_out = conv("decoder.conv_out")
@@ -405,10 +412,10 @@ class VideoVAEEngine:
             else:
                 halo = mem[mem.shape[0] - pt:] if a == 0 else torch.cat([mem[mem.shape[0] - (pt - a):], x[:a]], 0).contiguous()
             geom_in = x[a:b]
-            for py, px, w, bias, bb in parts:
+            for py, px, w, bias, bb, frag in parts:
                 geom = Conv3dGeom(b - a, H, W, Cc, b - a, H, W, (n_src, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
                 ops.gemm(geom_in, w, y[base:], N=cw.cout, K=w.shape[1], bias=bias, conv=geom,
-                         phase=PhaseScatter(py, px, bb, t_stride))
+                         phase=PhaseScatter(py, px, bb, t_stride), W_frag=frag)
 
         if rz == 1:
             launch(subpixel.signature(kt - 1, 1, kt), 0, T, 0, 1)

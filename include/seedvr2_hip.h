@@ -100,6 +100,12 @@ typedef struct svr_gemm_args {
  * fragment order svr_gemm_args.W_frag expects.  N % 32 == 0, Cin % 32 == 0.  Done once per checkpoint.     */
 int svr_conv_pack_frag(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t Cin, void* stream);
 
+/* Same for any spatial tap grid (K = kt * kh * kw * Cin, K order (dt, dy, dx, c)): kh = kw = 3 is svr_conv_pack_frag; kh = kw = 2
+ * feeds the sub-pixel upsampler conv kernel (stride 1, pads 0 | 1, same-size output, N % 128 == 0, plain bias epilogue,
+ * with or without svr_gemm_args.phase).                                                                        */
+int svr_conv_pack_frag_taps(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t kh, int32_t kw, int32_t Cin,
+                            void* stream);
+
 /* Number of per-frame partial blocks the launch described by `args` will write to args->gn_partial
  * (0: the kernel that serves this problem does not produce fused statistics -- use svr_groupnorm_stats). */
 int32_t svr_gemm_gn_blocks(const svr_gemm_args* args);
@@ -194,6 +200,7 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * "conv_rows" patch rows per wave of the register-streamed conv kernel: 8 (default: 256 accumulators, one wave per SIMD) | 4
  * (two workgroups per CU),
  * "conv_band" tile rows per band of the conv kernel's frame-inner tile order (default 1; 0: frame outermost),
+ * "conv_sub" 1 (default) (kt, 2, 2)-tap convs with W_frag run on the sub-pixel conv kernel | 0 on the generic kernel,
  * "conv_lds" dynamic LDS bytes to request for the halo kernel (> 80 KiB forces one workgroup per CU),
  * "gemm_epi" epilogue of the GEMM kernel: 0 auto | 1 stores straight from the accumulators | 2 through LDS wherever possible,
  * "attn_impl" 0 auto (second-generation window kernel for head_dim 128 / windows <= 2048 rows) | 1 first kernel everywhere,

@@ -399,7 +399,8 @@ def test_gemm_epilogue_paths_bit_identical(hip):
 
 @pytest.mark.parametrize("T,H,W,Cin,Cout,hf,kt,ts", [(3, 9, 11, 128, 128, 0, 3, 1), (2, 16, 20, 256, 256, 2, 3, 1), (4, 1, 5, 64, 128, 0, 3, 1),
                                                      (3, 7, 9, 128, 128, 1, 2, 2), (1, 4, 4, 64, 128, 0, 1, 1)])
-def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, T, H, W, Cin, Cout, hf, kt, ts):
+@pytest.mark.parametrize("frag", [False, True], ids=["generic_kernel", "subpixel_kernel"])
+def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, frag, T, H, W, Cin, Cout, hf, kt, ts):
     """Sub-pixel convolution launches (svr_gemm_args.phase): (kt, 2, 2)-tap convs over the low-resolution input, each
     scattering into its spatial phase of the 2x grid -- and, with t_stride 2, into every other frame from its first one on --
     with its own border bias == the torch restatement; together they write every voxel of the output exactly once (NaN canary)."""
@@ -418,7 +419,10 @@ def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, T, H, W, Cin, Cout, hf,
             bb = rnd(3, Cout, dtype=torch.float32, seed=40 + ph)
             geom = opsmod.Conv3dGeom(T, H, W, Cin, To, H, W, (kt, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
             kw = dict(N=Cout, K=Wp.shape[1], bias=bias, conv=geom, phase=opsmod.PhaseScatter(py, px, bb, ts))
-            hip.gemm(x, Wp, out[tz:], **kw)
+            # frag: the fragment-ordered weight copy selects the sub-pixel conv kernel (svr_conv_sub.hip; Cin % 64 == 0)
+            Wf = hip.pack_conv_frag(Wp, kt, Cin, Cout, taps=(2, 2)) if frag else None
+            assert Wf is not None or not frag
+            hip.gemm(x, Wp, out[tz:], W_frag=Wf, **kw)
             ref.gemm(x, Wp, want[tz:], **kw)
             # independent check of the restatement on this phase: F.conv3d of the padded input + per-voxel bias
             head = halo.float() if hf else x[:1].float().expand(pt, H, W, Cin)
@@ -432,6 +436,50 @@ def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, T, H, W, Cin, Cout, hf,
             assert rel_err(want[tz::ts, py::2, px::2], y + b) < 1e-5
     assert not torch.isnan(out.float()).any() and not torch.isnan(want).any()
     assert rel_err(out.float(), want) < TOL_BF16
+
+
+@pytest.mark.parametrize("kt,ts,H,W", [(2, 2, 40, 70), (3, 1, 33, 64), (1, 1, 16, 32)])
+def test_conv_subpixel_kernel_race_screen_and_generic_agreement(hip, kt, ts, H, W):
+    """The sub-pixel conv kernel keeps LDS-DMA, weight loads and fragment reads in flight across barriers with hand-counted
+    waits: repeated launches over many tiles and A steps must be bit-identical, and must agree with the generic
+    implicit-GEMM kernel on the same launch (conv_sub 0) up to the rounding of differently shaped MFMA sums."""
+    packing, opsmod = sub("packing"), sub("ops")
+    T, Cin, Cout = 3, 256, 256
+    x = rnd(T, H, W, Cin)
+    halo = rnd(kt - 1, H, W, Cin, seed=9) if kt > 1 else None
+    w5 = rnd(Cout, Cin, kt, 2, 2, scale=1.0 / math.sqrt(Cin * 4 * kt), seed=2)
+    Wp = packing.pack_conv3d(w5, "cuda")
+    Wf = hip.pack_conv_frag(Wp, kt, Cin, Cout, taps=(2, 2))
+    bias, bb = rnd(Cout, dtype=torch.float32, seed=3), rnd(3, Cout, dtype=torch.float32, seed=4)
+    geom = opsmod.Conv3dGeom(T, H, W, Cin, T, H, W, (kt, 2, 2), (1, 1, 1), (kt - 1, 1, 0), halo)
+    kw = dict(N=Cout, K=Wp.shape[1], bias=bias, conv=geom, phase=opsmod.PhaseScatter(0, 1, bb, ts), W_frag=Wf)
+    outs = []
+    for _ in range(4):
+        out = torch.zeros(T * ts, 2 * H, 2 * W, Cout, device="cuda", dtype=BF16)
+        hip.gemm(x, Wp, out, **kw)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    hip.set_option("conv_sub", 0)
+    try:
+        gen = torch.zeros_like(outs[0])
+        hip.gemm(x, Wp, gen, **kw)
+    finally:
+        hip.set_option("conv_sub", 1)
+    assert torch.equal(gen[:, 1::2], outs[0][:, 1::2]) and torch.equal(gen[:, :, 0::2], outs[0][:, :, 0::2])     # untouched phases stay zero
+    assert rel_err(outs[0].float(), gen.float()) < 2e-3
+    # and without the phase scatter: a plain (kt, 2, 2) conv into a dense tensor
+    kw2 = dict(N=Cout, K=Wp.shape[1], bias=bias, conv=geom, W_frag=Wf, ldc=Cout)
+    d1 = torch.full((T, H, W, Cout), float("nan"), device="cuda", dtype=BF16)
+    hip.gemm(x, Wp, d1, **kw2)
+    hip.set_option("conv_sub", 0)
+    try:
+        d0 = torch.full((T, H, W, Cout), float("nan"), device="cuda", dtype=BF16)
+        hip.gemm(x, Wp, d0, **kw2)
+    finally:
+        hip.set_option("conv_sub", 1)
+    assert not torch.isnan(d1.float()).any() and rel_err(d1.float(), d0.float()) < 2e-3
 
 
 def test_vae_subpixel_upsampler_matches_two_step_on_gpu(hip):

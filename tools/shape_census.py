@@ -24,7 +24,7 @@ class MetaOps:
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or torch.bfloat16, device="meta")
 
-    def pack_conv_frag(self, W, kt, Cin, N):
+    def pack_conv_frag(self, W, kt, Cin, N, taps=(3, 3)):
         return torch.empty(1, device="meta")
 
     def gemm(self, A, W, out, *, N, K, M=None, conv=None, ps=None, resid=None, out_f32=False, gn_groups=0, **kw):
