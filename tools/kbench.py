@@ -138,6 +138,23 @@ def main():
             sec = timeit(lambda: ops.gemm(x, w, y, N=Co, K=k3[0] * 9 * Ci, bias=b, conv=geom, ldc=Co), args.reps)
             report(name, sec, flops=2.0 * To * Ho * Wo * Co * k3[0] * 9 * Ci)
             del x, w, y
+    if "subpixel" in only:
+        # the sub-pixel upsampler convs: one phase launch each, low-resolution input -> 2x grid
+        for name, T, H, W, C, kt, ts in (("sub-pixel conv (3,2,2) 256->256 @5x512^2 -> 1024^2 (spatial upsampler)", 5, 512, 512, 256, 3, 1),
+                                         ("sub-pixel conv (2,2,2) 512->512 @5x256^2 -> 512^2 (temporal upsampler)", 5, 256, 256, 512, 2, 2),
+                                         ("sub-pixel conv (2,2,2) 512->512 @5x128^2 -> 256^2 (temporal upsampler)", 5, 128, 128, 512, 2, 2)):
+            x = rnd(T, H, W, C)
+            halo = rnd(kt - 1, H, W, C)
+            w = packing.pack_conv3d(torch.randn(C, C, kt, 2, 2, generator=g, device=dev) / math.sqrt(4 * kt * C), dev)
+            wf = None if args.no_frag else ops.pack_conv_frag(w, kt, C, C, taps=(2, 2))
+            b = torch.zeros(C, dtype=torch.float32, device=dev)
+            bb = torch.zeros(3, C, dtype=torch.float32, device=dev)
+            y = ops.empty(T * ts, 2 * H, 2 * W, C)
+            geom = ops_mod.Conv3dGeom(T, H, W, C, T, H, W, (kt, 2, 2), (1, 1, 1), (kt - 1, 1, 1), halo)
+            sec = timeit(lambda: ops.gemm(x, w, y, N=C, K=4 * kt * C, bias=b, conv=geom, W_frag=wf,
+                                          phase=ops_mod.PhaseScatter(0, 0, bb, ts)), args.reps)
+            report(name, sec, flops=2.0 * T * H * W * C * C * 4 * kt)
+            del x, w, y
     if "attn" in only:
         windows, config = sub("windows"), sub("config")
         for method in ("720pwin_by_size_bysize", "720pswin_by_size_bysize"):
