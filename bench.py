@@ -78,7 +78,9 @@ def make_profiled_ops(device):
                 halo = (conv.k[1] == 3 and conv.k[2] == 3 and tuple(conv.stride) == (1, 1, 1) and conv.pad[1] == 1
                         and conv.pad[2] == 1 and conv.Ho == conv.H and conv.Wo == conv.W and conv.Cin % 64 == 0
                         and (kw["N"] % 128 == 0 or kw["N"] <= 32))
-                kind = "conv_halo" if halo else "conv_generic"
+                # (kt, 2, 2)-tap phase convs of the sub-pixel upsamplers: svr_conv_sub.hip when the fragment-ordered weights are given
+                sub = conv.k[1] == 2 and conv.k[2] == 2 and kw.get("phase") is not None
+                kind = "conv_halo" if halo else ("conv_subpixel" if sub else "conv_generic")
                 flops = 2.0 * M * kw["N"] * conv.k[0] * conv.k[1] * conv.k[2] * conv.Cin
             else:
                 M = kw.get("M") or A.shape[0]
