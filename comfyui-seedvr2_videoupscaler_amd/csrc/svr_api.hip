@@ -9,6 +9,7 @@
 #include "svr_conv_halo.hip"
 #include "svr_conv_halo2.hip"
 #include "svr_conv_sub.hip"
+#include "svr_conv_thinout.hip"
 #include "svr_attn_win.hip"
 #include "svr_attn.hip"
 #include "svr_elementwise.hip"
@@ -41,6 +42,7 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "conv_rows")) { g_conv_rows = value; return 0; }
     if (!strcmp(key, "conv_band")) { g_conv_band = value; return 0; }
     if (!strcmp(key, "conv_sub")) { g_conv_sub = value; return 0; }
+    if (!strcmp(key, "conv_thinout")) { g_conv_thinout = value; return 0; }
     if (!strcmp(key, "conv_lds")) { g_conv_lds_dbg = value; return 0; }
     if (!strcmp(key, "attn_impl")) { g_attn_impl = value; return 0; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return 0; }

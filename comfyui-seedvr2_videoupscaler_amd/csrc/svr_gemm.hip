@@ -459,6 +459,9 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s);
 static bool conv_halo2_eligible(const svr_gemm_args& a);
 static bool conv_thin_eligible(const svr_gemm_args& a);
 static int launch_conv_thin(const svr_gemm_args& a, hipStream_t s);
+// thin-output conv kernel (svr_conv_thinout.hip)
+static int launch_conv_thinout(const svr_gemm_args& a, hipStream_t s);
+extern int g_conv_thinout;
 // sub-pixel upsampler conv kernel (svr_conv_sub.hip)
 static bool conv_sub_eligible(const svr_gemm_args& a);
 static int launch_conv_sub(const svr_gemm_args& a, hipStream_t s);
@@ -516,7 +519,7 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     if (conv_sub_eligible(a)) return launch_conv_sub(a, s);
     if ((g_conv_impl == 0 || g_conv_impl == 3) && conv_halo2_eligible(a)) return launch_conv_halo2(a, s);
     if (g_conv_impl != 1 && conv_halo_eligible(a))
-        return a.N <= 32 ? launch_conv_halo<32>(a, s) : launch_conv_halo<128>(a, s);
+        return a.N <= 32 ? (g_conv_thinout ? launch_conv_thinout(a, s) : launch_conv_halo<32>(a, s)) : launch_conv_halo<128>(a, s);
     // 256-wide tiles when N allows it (otherwise W is padded to a multiple of 128 rows) -- unless they would leave CUs idle:
     // the VAE attention's P V product (16384 x 512 x 16384) has only 128 such tiles for 256 CUs
     const bool wide = (a.N % 256) == 0 &&

@@ -200,6 +200,7 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * "conv_rows" patch rows per wave of the register-streamed conv kernel: 8 (default: 256 accumulators, one wave per SIMD) | 4
  * (two workgroups per CU),
  * "conv_band" tile rows per band of the conv kernel's frame-inner tile order (default 1; 0: frame outermost),
+ * "conv_thinout" 1 (default) N <= 32 convs on the step-interval thin-output kernel | 0 on the first halo kernel's 32-cout variant,
  * "conv_sub" 1 (default) (kt, 2, 2)-tap convs with W_frag run on the sub-pixel conv kernel | 0 on the generic kernel,
  * "conv_lds" dynamic LDS bytes to request for the halo kernel (> 80 KiB forces one workgroup per CU),
  * "gemm_epi" epilogue of the GEMM kernel: 0 auto | 1 stores straight from the accumulators | 2 through LDS wherever possible,

@@ -438,6 +438,41 @@ def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, frag, T, H, W, Cin, Cou
     assert rel_err(out.float(), want) < TOL_BF16
 
 
+@pytest.mark.parametrize("Cin,Cout,kt,T,H,W,hf", [(128, 3, 3, 3, 40, 70, 0), (512, 32, 3, 2, 19, 45, 2), (128, 3, 1, 2, 9, 33, 0), (192, 16, 3, 4, 8, 32, 0)])
+def test_conv_thin_output_kernel(hip, ref, Cin, Cout, kt, T, H, W, hf):
+    """Thin-output convs (N <= 32: decoder conv_out 128 -> 3, encoder conv_out 512 -> 32) on the step-interval kernel
+    (svr_conv_thinout.hip) == the torch restatement, == the first halo kernel's 32-cout variant up to MFMA-order rounding,
+    plain bias epilogue (production) and residual epilogue; repeated launches bit-identical (double-buffered LDS-DMA)."""
+    packing, opsmod = sub("packing"), sub("ops")
+    x = rnd(T, H, W, Cin)
+    halo = rnd(hf, H, W, Cin, seed=9) if hf else None
+    w5 = rnd(Cout, Cin, kt, 3, 3, scale=1.0 / math.sqrt(Cin * 9 * kt), seed=2)
+    Wp = packing.pack_conv3d(w5, "cuda")
+    bias = rnd(Cout, dtype=torch.float32, seed=3)
+    pt = hf if hf else kt - 1
+    To = T + pt - kt + 1
+    geom = opsmod.Conv3dGeom(T, H, W, Cin, To, H, W, (kt, 3, 3), (1, 1, 1), (pt, 1, 1), halo)
+    resid = rnd(To, H, W, Cout, seed=11)
+    for kw in (dict(), dict(epilogue=EPI_RESID_GATE, resid=resid, ldr=Cout)):
+        kw = dict(N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, **kw)
+        outs = []
+        for _ in range(3):
+            out = torch.full((To, H, W, Cout), float("nan"), device="cuda", dtype=BF16)
+            hip.gemm(x, Wp, out, **kw)
+            outs.append(out)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        want = ref.gemm(x, Wp, torch.empty(To, H, W, Cout, device="cuda"), **kw)
+        assert not torch.isnan(outs[0].float()).any() and rel_err(outs[0].float(), want) < TOL_BF16
+        hip.set_option("conv_thinout", 0)
+        try:
+            old = torch.empty(To, H, W, Cout, device="cuda", dtype=BF16)
+            hip.gemm(x, Wp, old, **kw)
+        finally:
+            hip.set_option("conv_thinout", 1)
+        assert rel_err(outs[0].float(), old.float()) < 2e-3
+
+
 @pytest.mark.parametrize("kt,ts,H,W", [(2, 2, 40, 70), (3, 1, 33, 64), (1, 1, 16, 32)])
 def test_conv_subpixel_kernel_race_screen_and_generic_agreement(hip, kt, ts, H, W):
     """The sub-pixel conv kernel keeps LDS-DMA, weight loads and fragment reads in flight across barriers with hand-counted
