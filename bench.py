@@ -177,6 +177,9 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print per-phase timings to stderr")
     ap.add_argument("--two-step-upsampler", action="store_true",
                     help="A/B: run the VAE's spatial upsampler as the reference's upscale_conv + pixel shuffle + conv instead of its sub-pixel form")
+    ap.add_argument("--three-tap-head", action="store_true",
+                    help="A/B: keep three temporal taps on the first frame of every clip instead of the two-term sum of the taps "
+                         "that fall on the replicated frame (VideoVAEEngine(merge_causal_head=False))")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -200,7 +203,7 @@ def main():
     # random-init weights of the exact architecture, generated on the GPU (no checkpoints available offline)
     dit = sub("dit").NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, device=device), ops)
     vae = sub("vae").VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, device=device), ops,
-                                    merge_upsamplers=not args.two_step_upsampler)
+                                    merge_upsamplers=not args.two_step_upsampler, merge_causal_head=not args.three_tap_head)
     runner_mod = sub("runner")
     runner = runner_mod.VideoDiffusionInfer(
         runner_mod.default_config(), encode_tiled=tiled, encode_tile_size=(1024, 1024), encode_tile_overlap=(128, 128),
@@ -277,13 +280,13 @@ def main():
             f_dit = flops.dit_flops(dcfg, ((bf - 1) // 4 + 1, hl // 2, wl // 2))
             f_vae = flops.vae_flops_tiled(vcfg, bf, H, W, tiled)
             f_step = len(plans) * (f_dit["total"] + f_vae["encode"] + f_vae["decode"])
-            f_exec = len(plans) * (f_dit["total"] + sum(flops.vae_flops_tiled(vcfg, bf, H, W, tiled, merged_upsamplers=not args.two_step_upsampler).values()))
+            f_exec = len(plans) * (f_dit["total"] + sum(flops.vae_flops_tiled(vcfg, bf, H, W, tiled, merged_upsamplers=not args.two_step_upsampler, causal_head=not args.three_tap_head).values()))
             frames_per_step, useful_per_step = frames, frames
         else:
             f_dit = flops.dit_flops(dcfg, (Tl, hl // 2, wl // 2))
             f_vae = flops.vae_flops_tiled(vcfg, frames, H, W, tiled)
             f_step = f_dit["total"] + f_vae["encode"] + f_vae["decode"]
-            f_exec = f_dit["total"] + sum(flops.vae_flops_tiled(vcfg, frames, H, W, tiled, merged_upsamplers=not args.two_step_upsampler).values())
+            f_exec = f_dit["total"] + sum(flops.vae_flops_tiled(vcfg, frames, H, W, tiled, merged_upsamplers=not args.two_step_upsampler, causal_head=not args.three_tap_head).values())
             frames_per_step = world * frames
             # the 4n+1 rule pads a 32-frame clip with one reversed frame (generation_phases.py:398-404): it is computed but
             # trimmed from the output, so the useful rate is (frames - 1) / frames of `value` for the padded workloads

@@ -43,6 +43,9 @@ class _Conv:
     pad_hi: int = 1     # spatial zero pad, high side
     thin: bool = False  # Cin < 64: im2col + plain GEMM
     w_frag: Optional[torch.Tensor] = None   # MFMA-fragment-ordered copy of w for the LDS-halo conv kernel (ops.pack_conv_frag)
+    # causal head (kt = 3, stride 1): the same conv for output frame 0 of a clip, whose three temporal taps all fall on the
+    # replicated first frame (causal_inflation_lib.py:422-437) -> kt = 2 conv with (hi, lo) = W0+W1+W2 split into two bf16 terms
+    head: Optional["_Conv"] = None
 
 
 @dataclass
@@ -115,10 +118,15 @@ def _cos_ramp(n: int) -> Optional[torch.Tensor]:
 
 class VideoVAEEngine:
     def __init__(self, cfg: VAEConfig, state_dict: Dict[str, torch.Tensor], ops,
-                 act_budget_bytes: int = 12 << 30, merge_upsamplers: bool = True):
+                 act_budget_bytes: int = 12 << 30, merge_upsamplers: bool = True, merge_causal_head: bool = True):
         """``merge_upsamplers``: run the spatial-only upsampler (upscale_conv + pixel shuffle + 3x3x3 conv) as four sub-pixel
         convs over its low-resolution input (subpixel.py) -- same function, 12 instead of 28 MACs per output voxel and channel
-        pair, no upsampled intermediate; False keeps the reference's two steps."""
+        pair, no upsampled intermediate; False keeps the reference's two steps.
+        ``merge_causal_head``: output frame 0 of a clip sees the replicated first frame under all three temporal taps
+        (extend_head, causal_inflation_lib.py:422-437), so it is computed as (W0+W1+W2) * x[0] with the sum held as two bf16
+        terms (hi + lo, exact to 2^-17): 18 instead of 27 MACs per voxel and channel pair, same result.  (Rounding the sum
+        to ONE bf16 term -- and merging frame 1's two replicated taps the same way -- would save three times as much but costs
+        0.4-0.8 dB against the fp32 reference: measured, not shipped.)  False keeps three taps on every frame."""
         self.cfg, self.ops = cfg, ops
         self.device = ops.device
         self.act_budget_bytes = act_budget_bytes
@@ -126,8 +134,8 @@ class VideoVAEEngine:
         ch = cfg.block_out_channels
         n = len(ch)
 
-        def conv(name, stride=(1, 1, 1), pad=(1, 1), cin_pad=None):
-            w = sd[name + ".weight"]
+        def conv(name, stride=(1, 1, 1), pad=(1, 1), cin_pad=None, w=None):
+            w = sd[name + ".weight"] if w is None else w
             co, ci, kt, kh, kw = w.shape
             thin = ci < 64
             if thin:
@@ -137,8 +145,15 @@ class VideoVAEEngine:
             if (kh, kw) == (3, 3) and tuple(stride) == (1, 1, 1) and tuple(pad) == (1, 1) and not thin \
                     and hasattr(ops, "pack_conv_frag"):
                 frag = ops.pack_conv_frag(wp, kt, ci, co)
+            head = None
+            if merge_causal_head and kt == 3 and tuple(stride) == (1, 1, 1) and not thin:
+                # (weights as the reference holds them: cast to bf16 at load, model_loader.py:583-584; summed in fp32)
+                wsum = w.to(device=dev, dtype=BF16).float().sum(2)
+                hi = wsum.to(BF16).float()
+                head = conv(name, stride, pad, w=torch.stack([hi, wsum - hi], 2))
             return _Conv(name, wp, pack_vec(sd[name + ".bias"], dev),
-                         cin_pad or ci, co, (kt, kh, kw), stride, pad[0] if kh > 1 else 0, pad[1] if kh > 1 else 0, thin, frag)
+                         cin_pad or ci, co, (kt, kh, kw), stride, pad[0] if kh > 1 else 0, pad[1] if kh > 1 else 0, thin, frag,
+                         head)
 
         def norm(name):
             return _Norm(pack_vec(sd[name + ".weight"], dev), pack_vec(sd[name + ".bias"], dev))
@@ -264,6 +279,8 @@ class VideoVAEEngine:
         ops = self.ops
         T, H, W, Cin = x.shape
         assert Cin == cw.cin, (cw.name, Cin, cw.cin)
+        if first and cw.head is not None:
+            return self._conv_causal_head(cw, x, st, resid, gn)
         kt, kh, kw = cw.k
         sT, sH, sW = cw.stride
         carry = kt - sT                                     # frames handed to the next temporal slice
@@ -303,6 +320,33 @@ class VideoVAEEngine:
                 prev = halo if halo is not None else x[:1].expand(pt, H, W, Cin)
                 st[cw.name] = torch.cat([prev, x], dim=0)[-carry:].contiguous()
         return (out, stats) if gn else out
+
+    def _conv_causal_head(self, cw: _Conv, x, st, resid, gn):
+        """First slice of a clip through a kt = 3 stride-1 conv: output frame 0 = (hi + lo) * x[0] with hi + lo = W0+W1+W2
+        (two taps on the replicated frame instead of three), frames 1.. = the plain conv over x with one replicated frame.
+        Same outputs, per-frame statistics and carried state as one launch with two replicated frames."""
+        T, H, W, _ = x.shape
+        if resid is not None and tuple(resid.shape) != (T, H, W, cw.cout):
+            raise ValueError(f"{cw.name}: residual {tuple(resid.shape)} does not match the output {(T, H, W, cw.cout)}")
+        out = self.ops.empty(T, H, W, cw.cout)
+        stats = []
+        for sub, n_in, o in ((cw.head, 1, 0), (cw, T, 1)):       # (weights, input frames 0..n_in-1, first output frame)
+            To = n_in + 1 - sub.k[0] + 1
+            if To <= 0:
+                continue
+            geom = Conv3dGeom(n_in, H, W, cw.cin, To, H, W, sub.k, (1, 1, 1), (1, cw.pad_lo, cw.pad_lo), None)
+            r = resid[o:o + To] if resid is not None else None
+            res = self.ops.gemm(x[:n_in], sub.w, out[o:o + To], N=cw.cout, K=sub.w.shape[1], bias=cw.b,
+                                epilogue=EPI_RESID_GATE if r is not None else EPI_BIAS, resid=r, conv=geom,
+                                ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups if gn else 0, W_frag=sub.w_frag)
+            if gn:
+                stats.append(res[1])
+        if not st.get("__last_slice__", False):
+            carry = cw.k[0] - 1
+            st[cw.name] = x[T - carry:].clone() if T >= carry else torch.cat([x[:1].expand(carry - T, H, W, cw.cin), x], 0).contiguous()
+        if not gn:
+            return out
+        return out, (None if any(s is None for s in stats) else torch.cat(stats, 0))
 
     def _gn(self, nm: _Norm, x: torch.Tensor, silu: bool, stats: Optional[torch.Tensor] = None):
         """GroupNorm (+SiLU); ``stats`` = statistics of ``x`` already produced by the conv that wrote it."""

@@ -19,7 +19,7 @@ def vae_setup():
     sd = weights.synth_vae_state_dict(cfg)
     # (the reference's two-step upsampler: with fp32 storage the engine then reproduces the goldens to ~1e-6; the sub-pixel
     # form rounds MERGED weights to bf16 and has its own tests below)
-    return cfg, sd, vae.VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=torch.float32), merge_upsamplers=False)
+    return cfg, sd, vae.VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=torch.float32), merge_upsamplers=False, merge_causal_head=False)
 
 
 def _two_step_upsampler(x, w1, b1, w3, b3, rz):
@@ -79,7 +79,7 @@ def test_vae_subpixel_upsampler_in_the_engine(vae_setup):
     weights (fp32 activations on CPU): untiled, temporally sliced (the causal memory is the low-resolution input's tail) and
     tiled."""
     cfg, sd, two_step = vae_setup
-    merged = sub("vae").VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=torch.float32))
+    merged = sub("vae").VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=torch.float32), merge_causal_head=False)
     assert all(up is None or up.merged is not None for _, up in merged.dec_up)
     assert all(up is None or up.merged is None for _, up in two_step.dec_up)
     assert sorted(len(up.merged) for _, up in merged.dec_up if up is not None) == [1, 5, 5]
@@ -91,6 +91,81 @@ def test_vae_subpixel_upsampler_in_the_engine(vae_setup):
     assert rel_err(merged.decode(z[:1]), two_step.decode(z[:1])) < 6e-3          # a single latent frame: the head pattern only
     tile = dict(tiled=True, tile_size=(32, 32), tile_overlap=(8, 8))
     assert rel_err(merged.decode(z, **tile), two_step.decode(z, **tile)) < 4e-3
+
+
+def test_vae_causal_head_merge_in_the_engine(vae_setup):
+    """Output frame 0 of a clip computed as (W0+W1+W2) * x[0] with the sum held as two bf16 terms (the three temporal taps
+    all fall on the replicated first frame: extend_head, causal_inflation_lib.py:422-437): the same function to 2^-17 per
+    weight -- for encode and decode, any temporal slicing, single images, tiles, and together with the sub-pixel upsamplers."""
+    cfg, sd, plain = vae_setup
+    vae = sub("vae")
+    ops = TorchOps("cpu", act_dtype=torch.float32)
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn(3, 6, 5, cfg.latent_channels, generator=gen) * 0.5
+    x = torch.randn(3, 9, 16, 24, generator=gen).clamp(-1, 1)
+    m = vae.VideoVAEEngine(cfg, sd, ops, merge_upsamplers=False, merge_causal_head=True)
+    c1 = m.dec_up[0][0][0].conv1
+    assert c1.head is not None and c1.head.k == (2, 3, 3) and c1.head.head is None and plain.dec_up[0][0][0].conv1.head is None
+    assert m.enc_conv_in.head is None and m.dec_conv_in.head is None and m.enc_down[0][1].head is None   # thin / strided: untouched
+    w = sd["decoder.up_blocks.0.resnets.0.conv1.weight"].bfloat16().double()
+    hl = c1.head.w[:w.shape[0]].double().reshape(w.shape[0], 2, 3, 3, w.shape[1]).sum(1).permute(0, 3, 1, 2)
+    assert float((hl - w.sum(2)).abs().max()) <= 2.0 ** -16 * float(w.sum(2).abs().max())
+    want = plain.decode(z)
+    got = m.decode(z)
+    assert rel_err(got, want) < 2e-5
+    for per_slice in (1, 2):
+        assert rel_err(m.decode(z, latents_per_slice=per_slice), got) < 1e-5
+    assert rel_err(m.decode(z[:1]), plain.decode(z[:1])) < 2e-5                       # one latent frame: the head launch only
+    assert rel_err(m.encode(x), plain.encode(x)) < 2e-5
+    assert rel_err(m.encode(x, frames_per_slice=4), plain.encode(x)) < 2e-5
+    assert rel_err(m.encode(x[:, :1]), plain.encode(x[:, :1])) < 2e-5
+    tile = dict(tiled=True, tile_size=(32, 32), tile_overlap=(8, 8))
+    assert rel_err(m.decode(z, **tile), plain.decode(z, **tile)) < 2e-5
+    both = vae.VideoVAEEngine(cfg, sd, ops)                                           # the shipped default
+    only_up = vae.VideoVAEEngine(cfg, sd, ops, merge_causal_head=False)
+    assert rel_err(both.decode(z), only_up.decode(z)) < 2e-5 and rel_err(both.decode(z, latents_per_slice=1), both.decode(z)) < 1e-5
+
+
+def test_flop_model_counts_what_the_engine_launches():
+    """flops.py (bench.py's executed_tflop_per_step and the FLOPs behind roofline.achieved) against the multiply-adds of the
+    GEMM / implicit-GEMM launches the engine really issues, for the reference's form and for both algebraic reductions
+    (sub-pixel upsamplers, two-term causal head).  The only slack: the thin inputs are padded (encoder conv_in 3 -> 4
+    channels, decoder conv_in K = 432 -> 448); what each reduction saves is compared exactly."""
+    config, weights, vae, flops = sub("config"), sub("weights"), sub("vae"), sub("flops")
+    cfg = config.VAE_V3
+    sd = weights.synth_vae_state_dict(cfg)
+
+    class Counting(TorchOps):
+        macs, depth = 0.0, 0
+
+        def gemm(self, A, W, out, *, N, K, M=None, conv=None, **kw):
+            m = conv.To * conv.Ho * conv.Wo if conv is not None else (M if M is not None else A.shape[0])
+            if self.depth == 0:                                   # (the torch restatement of a conv launch calls gemm again)
+                self.macs += 2.0 * m * N * K
+            self.depth += 1
+            try:
+                return super().gemm(A, W, out, N=N, K=K, M=M, conv=conv, **kw)
+            finally:
+                self.depth -= 1
+
+    T, H, W = 9, 64, 64                                       # (64 latent voxels per frame: the mid attention runs as GEMMs)
+    x = torch.rand(3, T, H, W) * 2 - 1
+    z = torch.randn(3, H // 8, W // 8, cfg.latent_channels) * 0.5
+    got, model = {}, {}
+    for mu, mh in ((False, False), (True, False), (True, True)):
+        ops = Counting("cpu", act_dtype=torch.float32)
+        eng = vae.VideoVAEEngine(cfg, sd, ops, merge_upsamplers=mu, merge_causal_head=mh)
+        eng.encode(x, frames_per_slice=4)
+        enc = ops.macs
+        eng.decode(z, latents_per_slice=1)
+        got[mu, mh] = (enc, ops.macs - enc)
+        f = flops.vae_flops_tiled(cfg, T, H, W, False, merged_upsamplers=mu, causal_head=mh)
+        model[mu, mh] = (f["encode"], f["decode"])
+        assert abs(got[mu, mh][0] / f["encode"] - 1) < 2e-3 and abs(got[mu, mh][1] / f["decode"] - 1) < 1e-5, (mu, mh, got[mu, mh], f)
+    for a, b in (((False, False), (True, False)), ((True, False), (True, True))):      # what each reduction saves: exact
+        for ph in (0, 1):
+            assert abs((got[a][ph] - got[b][ph]) - (model[a][ph] - model[b][ph])) <= 1e-9 * model[a][ph]
+    assert got[True, True][0] < got[True, False][0] and got[True, True][1] < got[True, False][1] < got[False, False][1]
 
 
 def test_dit_engine_host_logic_matches_reference_golden():

@@ -28,7 +28,7 @@ def test_product_pipeline_fp32_double_equals_reference_chain():
     r.dit = dit.NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, seed=g["seed_dit"]), ops)
     # (the reference's two-step upsamplers: this test pins the GLUE exactly; the sub-pixel form rounds merged weights to bf16 and
     # is pinned by tests/test_host_logic.py and, against this same golden on the device, by tests/test_gpu_parity.py)
-    r.vae = vae.VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, seed=g["seed_vae"]), ops, merge_upsamplers=False)
+    r.vae = vae.VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, seed=g["seed_vae"]), ops, merge_upsamplers=False, merge_causal_head=False)
     out = pipeline.upscale(images, r, weights.synth_text_embedding().float(), resolution=g["resolution"],
                            batch_size=g["batch_size"], uniform_batch_size=g["uniform_batch_size"],
                            temporal_overlap=g["temporal_overlap"], color_correction="lab", noise_provider=noise)
