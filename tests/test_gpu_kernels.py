@@ -539,24 +539,37 @@ def test_vae_subpixel_upsampler_matches_two_step_on_gpu(hip):
 
 def test_vae_causal_head_two_term_sum_matches_three_taps_on_gpu(hip):
     """Frame 0 of every clip with the three temporal taps on the replicated first frame folded into a (hi, lo) pair of bf16
-    weights (vae.py:_conv_causal_head): same function to 2^-17 per weight, so the device outputs differ from the three-tap
-    launches by isolated bf16 roundings only; slicing stays bit-exact; a single image takes the head launch alone."""
+    weights (vae.py:_conv_causal_head): same function to 2^-17 per weight.  One layer: frame 0 differs from the three-tap
+    launch by isolated bf16 roundings only, frames 1.. and their statistics are bit-identical; whole network: the two bf16
+    paths sit at the usual bf16 noise floor of a random-weight VAE from each other (tests/test_gpu_parity.py holds the real
+    bound against the reference); slicing stays bit-exact; a single image takes the head launch alone."""
     config, weights, vae_mod = sub("config"), sub("weights"), sub("vae")
     cfg = config.VAE_V3
     sd = weights.synth_vae_state_dict(cfg, device="cuda")
     gen = torch.Generator(device="cuda").manual_seed(2)
-    z = (torch.randn(3, 12, 10, cfg.latent_channels, device="cuda", generator=gen) * 0.5).to(BF16)
-    x = (torch.rand(3, 9, 64, 96, device="cuda", generator=gen) * 2 - 1).to(BF16)
     three = vae_mod.VideoVAEEngine(cfg, sd, hip, merge_causal_head=False)
     two = vae_mod.VideoVAEEngine(cfg, sd, hip)
-    assert two.dec_up[0][0][0].conv1.head is not None and two.dec_up[0][0][0].conv1.head.w_frag is not None
+    for pick in (lambda e: e.dec_up[0][0][0].conv1, lambda e: e.dec_up[3][0][0].conv1, lambda e: e.dec_conv_out):
+        c2, c3 = pick(two), pick(three)
+        assert c2.head is not None and c3.head is None and (c2.head.w_frag is not None) == (c2.w_frag is not None)
+        for T in (1, 2, 5):
+            x = torch.randn(T, 40, 64, c2.cin, device="cuda", generator=gen).to(BF16)
+            gn = c2.cout % 128 == 0
+            r2, r3 = (e._conv(c, x, {"__last_slice__": True}, True, gn=gn) for e, c in ((two, c2), (three, c3)))
+            o2, o3 = (r2[0], r3[0]) if gn else (r2, r3)
+            assert torch.equal(o2[1:], o3[1:]), (c2.name, T)
+            assert rel_err(o2[:1].float(), o3[:1].float()) < 1e-3, (c2.name, T)
+            if gn and r2[1] is not None and r3[1] is not None:
+                assert torch.equal(r2[1][1:], r3[1][1:]) and rel_err(r2[1][:1], r3[1][:1]) < 1e-4
+    z = (torch.randn(3, 12, 10, cfg.latent_channels, device="cuda", generator=gen) * 0.5).to(BF16)
+    x = (torch.rand(3, 9, 64, 96, device="cuda", generator=gen) * 2 - 1).to(BF16)
     d3, d2 = three.decode(z).float(), two.decode(z).float()
     e3, e2 = three.encode(x).float(), two.encode(x).float()
     print(f"two-term head vs three taps: decode rel-err {rel_err(d2, d3):.3e}, encode rel-err {rel_err(e2, e3):.3e}")
-    assert d2.shape == d3.shape and rel_err(d2, d3) < 3e-3 and rel_err(e2, e3) < 3e-3
+    assert d2.shape == d3.shape and rel_err(d2, d3) < 2e-2 and rel_err(e2, e3) < 2e-2
     assert torch.equal(two.decode(z, latents_per_slice=1).float(), d2) and torch.equal(two.encode(x, frames_per_slice=4).float(), e2)
-    assert rel_err(two.decode(z[:1]).float(), three.decode(z[:1]).float()) < 3e-3
-    assert rel_err(two.encode(x[:, :1]).float(), three.encode(x[:, :1]).float()) < 3e-3
+    assert rel_err(two.decode(z[:1]).float(), three.decode(z[:1]).float()) < 2e-2
+    assert rel_err(two.encode(x[:, :1]).float(), three.encode(x[:, :1]).float()) < 2e-2
 
 
 @pytest.fixture(params=[0, 4, 8], ids=["lds_weights", "wreg_4rows", "wreg_8rows"])
