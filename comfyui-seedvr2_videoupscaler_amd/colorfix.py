@@ -39,12 +39,21 @@ def adaptive_instance_normalization(content: torch.Tensor, style: torch.Tensor, 
 
 
 def wavelet_blur(image: torch.Tensor, radius: int) -> torch.Tensor:
+    """The reference's dilated depthwise 3x3 conv over the replicate-padded image (color_fix.py:122-157).  The binomial
+    kernel is separable ([1, 2, 1] / 4 down the rows, then along them) and its weights are powers of two, so it is evaluated
+    as two three-tap passes of shifted adds in fp32 with ONE rounding to the image dtype at the end -- the arithmetic of a
+    conv with fp32 accumulation, without handing a [B, 3, H, W] depthwise conv with dilation up to 16 to a convolution
+    library (on MI355X MIOpen serves it with its naive fallback kernel: 75 ms per 17-frame 4K batch and level, against a
+    few HBM passes here)."""
     radius = min(radius, max(1, min(image.shape[-2:]) // 8))
-    c = image.shape[1]
-    k = torch.tensor([[0.0625, 0.125, 0.0625], [0.125, 0.25, 0.125], [0.0625, 0.125, 0.0625]],
-                     dtype=image.dtype, device=image.device)[None, None].repeat(c, 1, 1, 1)
-    padded = F.pad(image, (radius, radius, radius, radius), mode="replicate")
-    return F.conv2d(padded, k, groups=c, dilation=radius)
+    h, w = image.shape[-2:]
+    x = image if image.dtype in (torch.float32, torch.float64) else image.float()
+    rows = torch.arange(h, device=image.device)
+    v = x.index_select(-2, (rows - radius).clamp_(min=0)) + x.index_select(-2, (rows + radius).clamp_(max=h - 1))
+    v = v.mul_(0.25).add_(x, alpha=0.5)                                   # rows y - r, y, y + r (clamped = replicate padding)
+    p = F.pad(v, (radius, radius, 0, 0), mode="replicate")
+    out = (p[..., :w] + p[..., 2 * radius:2 * radius + w]).mul_(0.25).add_(v, alpha=0.5)
+    return out.to(image.dtype)
 
 
 def wavelet_decomposition(image: torch.Tensor, levels: int = 5):
@@ -69,12 +78,19 @@ _XYZ2RGB = [[3.2404542, -1.5371385, -0.4985314], [-0.9692660, 1.8760108, 0.04155
 _EPS, _KAPPA = 6.0 / 29.0, (29.0 / 3.0) ** 3
 
 
+def _mix3(x: torch.Tensor, m) -> torch.Tensor:
+    """[B, 3, H, W] -> per-pixel 3x3 colour matrix as the reference applies it: ``x.permute(0, 2, 3, 1) @ m.T`` on [N, 3] rows
+    (color_fix.py:368-431).  Kept as the same fp32 matmul on purpose: the histogram matching that follows is rank based, so a
+    1-ulp change here would swap the matched values of near-tied pixels."""
+    b, _, h, w = x.shape
+    mt = torch.tensor(m, dtype=torch.float32, device=x.device)
+    return torch.matmul(x.permute(0, 2, 3, 1).reshape(-1, 3), mt.T).reshape(b, h, w, 3).permute(0, 3, 1, 2).clone()
+
+
 def rgb_to_lab(rgb: torch.Tensor) -> torch.Tensor:
     """[B, 3, H, W] sRGB in [0, 1] (fp32) -> CIELAB, D65."""
-    m = torch.tensor(_RGB2XYZ, dtype=torch.float32, device=rgb.device)
     lin = torch.where(rgb > 0.04045, torch.pow((rgb + 0.055) / 1.055, 2.4), rgb / 12.92)
-    b, _, h, w = lin.shape
-    xyz = torch.matmul(lin.permute(0, 2, 3, 1).reshape(-1, 3), m.T).reshape(b, h, w, 3).permute(0, 3, 1, 2).clone()
+    xyz = _mix3(lin, _RGB2XYZ)
     xyz[:, 0] = xyz[:, 0] / 0.95047
     xyz[:, 2] = xyz[:, 2] / 1.08883
     f = torch.where(xyz > _EPS ** 3, torch.pow(xyz, 1.0 / 3.0), (xyz * _KAPPA + 16.0) / 116.0)
@@ -82,7 +98,6 @@ def rgb_to_lab(rgb: torch.Tensor) -> torch.Tensor:
 
 
 def lab_to_rgb(lab: torch.Tensor) -> torch.Tensor:
-    m = torch.tensor(_XYZ2RGB, dtype=torch.float32, device=lab.device)
     fy = (lab[:, 0] + 16.0) / 116.0
     fx = lab[:, 1] / 500.0 + fy
     fz = fy - lab[:, 2] / 200.0
@@ -91,8 +106,7 @@ def lab_to_rgb(lab: torch.Tensor) -> torch.Tensor:
         return torch.where(f > _EPS, torch.pow(f, 3.0), (f * 116.0 - 16.0) / _KAPPA)
 
     xyz = torch.stack([inv(fx) * 0.95047, inv(fy), inv(fz) * 1.08883], dim=1)
-    b, _, h, w = xyz.shape
-    lin = torch.matmul(xyz.permute(0, 2, 3, 1).reshape(-1, 3), m.T).reshape(b, h, w, 3).permute(0, 3, 1, 2)
+    lin = _mix3(xyz, _XYZ2RGB)
     rgb = torch.where(lin > 0.0031308, torch.pow(torch.clamp(lin, min=0.0), 1.0 / 2.4) * 1.055 - 0.055, lin * 12.92)
     return torch.clamp(rgb, 0.0, 1.0)
 

@@ -108,7 +108,23 @@ def test_colorfix_equals_reference(ref, method):
                 pass
         want = ref["lab_color_transfer"](content.clone(), style.clone(), _Dbg(), luminance_weight=0.8)
     got = cf.METHODS[method](content, style)
-    assert got.shape == want.shape and float((got - want).abs().max()) < 2e-6
+    assert got.shape == want.shape
+    if method != "lab":
+        assert float((got - want).abs().max()) < 2e-6
+        return
+    # LAB: the histogram matching is RANK based, and its input is the wavelet base.  The blur here is the reference's dilated
+    # 3x3 conv evaluated as two three-tap passes (same weights, another order of fp32 additions: <= 2e-6, the "wavelet"
+    # case above), so a few near-tied pixels swap ranks and exchange their matched values.  Hence: (a) everything after
+    # the blur is exact when it is given the reference's wavelet base, (b) composed, all but a handful of values agree.
+    monkey = pytest.MonkeyPatch()
+    try:
+        monkey.setattr(cf, "wavelet_reconstruction", lambda c, s: ref["wavelet_reconstruction"](c.clone(), s.clone(), _Dbg()))
+        staged = cf.lab_color_transfer(content, style, luminance_weight=0.8)
+    finally:
+        monkey.undo()
+    assert float((staged - want).abs().max()) < 2e-6
+    d = (got - want).abs()
+    assert float((d > 2e-6).float().mean()) < 5e-3 and float(d.max()) < 1e-3
 
 
 def test_colorfix_properties():
@@ -118,6 +134,22 @@ def test_colorfix_properties():
     hi, lo = cf.wavelet_decomposition(x)
     assert torch.allclose(hi + lo, x, atol=1e-5)                       # the pyramid is a partition of the signal
     assert torch.allclose(cf.wavelet_reconstruction(x, x), x.clamp(-1, 1), atol=1e-5)
+    # the blur = the reference's conv: depthwise 3x3 binomial kernel, dilation r, replicate padding (color_fix.py:122-157),
+    # for every dilation of the pyramid, odd sizes, images smaller than the dilation cap, and bf16 storage (one rounding of
+    # the fp32 sum, as a conv with fp32 accumulation gives)
+    F = torch.nn.functional
+    k = torch.tensor([[0.0625, 0.125, 0.0625], [0.125, 0.25, 0.125], [0.0625, 0.125, 0.0625]])[None, None].repeat(3, 1, 1, 1)
+    for hh, ww in ((40, 40), (37, 131), (5, 9), (136, 129)):
+        img = torch.rand(2, 3, hh, ww, generator=g) * 2 - 1
+        for r in (1, 2, 4, 8, 16):
+            rr = min(r, max(1, min(hh, ww) // 8))
+            want = F.conv2d(F.pad(img, (rr, rr, rr, rr), mode="replicate"), k, groups=3, dilation=rr)
+            got = cf.wavelet_blur(img, r)
+            assert got.shape == img.shape and got.dtype == img.dtype and float((got - want).abs().max()) < 5e-7
+            got16 = cf.wavelet_blur(img.bfloat16(), r)
+            want16 = F.conv2d(F.pad(img.bfloat16().float(), (rr, rr, rr, rr), mode="replicate"), k, groups=3, dilation=rr).bfloat16()
+            assert got16.dtype == torch.bfloat16 and float((got16 != want16).float().mean()) < 2e-3
+            assert float((got16.float() - want16.float()).abs().max()) <= 2.0 ** -8
     rgb = torch.rand(2, 3, 16, 16, generator=g)
     assert torch.allclose(cf.lab_to_rgb(cf.rgb_to_lab(rgb)), rgb, atol=2e-4)             # LAB round trip
     a, b = torch.randn(1000, generator=g), torch.randn(1000, generator=g) * 3 + 1
