@@ -146,8 +146,12 @@ def lib():
         key, sep, val = item.partition("=")
         if not sep or handle.svr_set_option(key.strip().encode(), int(val)) != 0:
             raise HipLibraryError(f"SVR_OPTIONS: bad item {item!r}")
+        OPTIONS[key.strip()] = int(val)
     _lib = handle
     return _lib
+
+
+OPTIONS = {}      # knobs set so far through SVR_OPTIONS / HipOps.set_option (the library has no getter)
 
 
 def check(rc: int, what: str):

@@ -90,6 +90,7 @@ class HipOps:
     def set_option(self, key: str, value: int):
         """Tuning / measurement knob of the library (see svr_set_option in include/seedvr2_hip.h)."""
         hip_lib.check(self.lib.svr_set_option(key.encode(), int(value)), "svr_set_option")
+        hip_lib.OPTIONS[key] = int(value)
 
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or BF16, device=self.device)
@@ -106,6 +107,17 @@ class HipOps:
         out = torch.empty(N * W.shape[1], dtype=BF16, device=self.device)
         hip_lib.check(self.lib.svr_conv_pack_frag_taps(_ptr(W), _ptr(out), N, W.shape[1], kt, kh, kw, Cin, self._stream()),
                       "svr_conv_pack_frag_taps")
+        return out
+
+    def pack_gemm_frag(self, W, N: int, K: int):
+        """Fragment-ordered copy of a packed nn.Linear weight W [Npad, K] for gemm(..., W_frag=) on plain GEMMs: the kernel with
+        register-streamed weights (svr_gemm8.hip; N % 256 == 0, K % 128 == 0, K >= 256).  None when that kernel is switched off
+        (svr_set_option("gemm_impl", 0), the default) or cannot serve the shape -- the copy doubles the weight's memory."""
+        if not hip_lib.OPTIONS.get("gemm_impl", 0) or N % 256 or K % 128 or K < 256 or W.shape[1] != K or W.shape[0] < N:
+            return None
+        self._chk(W, BF16, "W")
+        out = torch.empty(N * K, dtype=BF16, device=self.device)
+        hip_lib.check(self.lib.svr_conv_pack_frag_taps(_ptr(W), _ptr(out), N, K, 1, 1, 1, K, self._stream()), "svr_conv_pack_frag_taps")
         return out
 
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
@@ -171,7 +183,9 @@ class HipOps:
             a.resid = resid.data_ptr()
             a.ldr = ldr if ldr is not None else (resid.stride(0) if resid.dim() == 2 else N)
         a.epilogue, a.out_f32 = epilogue, int(out_f32)
-        if W_frag is not None and conv is not None:
+        if W_frag is not None:
+            if W_frag.numel() < N * K:
+                raise ValueError(f"W_frag holds {W_frag.numel()} elements, the problem needs N * K = {N * K}")
             a.W_frag = self._chk(W_frag, BF16, "W_frag").data_ptr()
         stats = None
         if gn_groups > 0 and conv is not None:

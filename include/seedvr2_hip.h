@@ -91,7 +91,10 @@ typedef struct svr_gemm_args {
     int32_t gn_groups;
     /* Optional (conv mode, 3x3 spatial taps, stride 1, Cin % 32 == 0, N % 128 == 0): the same weights in
      * MFMA-fragment order as written by svr_conv_pack_frag().  When set, the LDS-halo conv kernel streams the
-     * weights from this copy straight into registers instead of staging W through LDS.  NULL: off.        */
+     * weights from this copy straight into registers instead of staging W through LDS.  NULL: off.
+     * Plain GEMMs (no conv): the copy written by svr_conv_pack_frag_taps(W, out, N, K, 1, 1, 1, K) lets the GEMM
+     * kernel with register-streamed weights serve the problem when svr_set_option("gemm_impl", 1 | 2) is on
+     * (N % 256 == 0, K % 128 == 0, K >= 256, bf16 output, no pixel shuffle); ignored otherwise.           */
     const void* W_frag;
     svr_phase_scatter phase;            /* conv mode only; not together with ps / SWIGLU / gn_partial / resid           */
 } svr_gemm_args;
@@ -204,6 +207,8 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * "conv_sub" 1 (default) (kt, 2, 2)-tap convs with W_frag run on the sub-pixel conv kernel | 0 on the generic kernel,
  * "conv_lds" dynamic LDS bytes to request for the halo kernel (> 80 KiB forces one workgroup per CU),
  * "gemm_epi" epilogue of the GEMM kernel: 0 auto | 1 stores straight from the accumulators | 2 through LDS wherever possible,
+ * "gemm_impl" 0 (default) every plain GEMM on the LDS-staged kernel | 1 plain GEMMs that bring W_frag and fit it on the kernel
+ * with register-streamed weights (svr_gemm8.hip) | 2 as 1, and a plain GEMM with W_frag that does not fit is an error,
  * "attn_impl" 0 auto (second-generation window kernel for head_dim 128 / windows <= 2048 rows) | 1 first kernel everywhere,
  * "attn_variant" build variant of the second-generation window kernel (0 default = 8 waves; 1 / 3 / 4: see svr_attn_win.hip),
  * "pipe_abl" measurement-only ablations in -DSVR_ABLATIONS builds (non-zero values give garbage). */

@@ -145,6 +145,93 @@ def test_gemm_swiglu(hip, ref, gemm_epi):
     assert rel_err(w2, want) < 1e-5
 
 
+@pytest.fixture
+def gemm8(hip):
+    """svr_set_option("gemm_impl", 2): plain GEMMs that bring a fragment-ordered weight copy MUST run on the kernel with
+    register-streamed weights (svr_gemm8.hip) -- a shape it cannot serve is an error, not a silent fallback."""
+    hip.set_option("gemm_impl", 2)
+    yield hip
+    hip.set_option("gemm_impl", 0)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 768, 384), (1, 2560, 256), (255, 512, 1280), (58, 2560, 5120),
+                                   (2048, 1536, 2560), (4100, 4096, 256), (513, 256, 6912)])
+def test_gemm8_bias(gemm8, ref, M, N, K):
+    """Register-streamed-weights GEMM: ragged M (one row .. many tiles), 4 .. 108 K stages, 1 .. 16 column tiles; against the
+    fp32 reference and against the LDS-staged kernel on the same problem."""
+    hip = gemm8
+    A = rnd(M, K)
+    w, W = packed(N, K)
+    Wf = hip.pack_gemm_frag(W, N, K)
+    assert Wf is not None
+    bias = rnd(N, dtype=torch.float32, seed=3)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=BF16)
+    hip.gemm(A, W, out, N=N, K=K, bias=bias, W_frag=Wf)
+    want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias)
+    assert not torch.isnan(out.float()).any() and rel_err(out.float(), want) < TOL_BF16
+    old = torch.empty(M, N, device="cuda", dtype=BF16)
+    hip.gemm(A, W, old, N=N, K=K, bias=bias)                      # (no W_frag: gemm_kernel)
+    assert rel_err(out.float(), old.float()) < 2e-3
+
+
+def test_gemm8_epilogues_views_and_race_screen(gemm8, ref):
+    hip = gemm8
+    packing = sub("packing")
+    M, N, K = 777, 512, 384
+    A = rnd(M, K)
+    w, W = packed(N, K)
+    Wf = hip.pack_gemm_frag(W, N, K)
+    bias = rnd(N, dtype=torch.float32, seed=3)
+    gate = rnd(N, dtype=torch.float32, seed=4)
+    resid = rnd(M, N, seed=5)
+    for epi, kw in ((EPI_BIAS_SILU, {}), (EPI_BIAS_GELU, {}), (EPI_RESID_GATE, dict(gate=gate, resid=resid)),
+                    (EPI_RESID_GATE, dict(resid=resid)), (EPI_RESID_GATE, dict(gate=gate))):
+        out = torch.empty(M, N, device="cuda", dtype=BF16)
+        hip.gemm(A, W, out, N=N, K=K, bias=bias, epilogue=epi, W_frag=Wf, **kw)
+        want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias, epilogue=epi, **kw)
+        assert rel_err(out.float(), want) < TOL_BF16, epi
+    # in-place residual on row-sliced views (C aliases resid), as the DiT calls it; rows outside the view untouched
+    buf = rnd(M + 58, N, seed=6)
+    want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE,
+                    gate=gate, resid=buf[:M].clone())
+    tail = buf[M:].clone()
+    hip.gemm(A, W, buf[:M], N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE, gate=gate, resid=buf[:M], W_frag=Wf)
+    assert rel_err(buf[:M].float(), want) < TOL_BF16 and torch.equal(buf[M:], tail)
+    # SwiGLU (interleaved gate | in blocks), ragged M
+    M2, K2, Hd = 515, 256, 768
+    A2 = rnd(M2, K2)
+    wg, wi = rnd(Hd, K2, scale=1 / 16, seed=7), rnd(Hd, K2, scale=1 / 16, seed=8)
+    W2 = packing.pack_swiglu(wg, wi, "cuda")
+    out = torch.empty(M2, Hd, device="cuda", dtype=BF16)
+    hip.gemm(A2, W2, out, N=2 * Hd, K=K2, epilogue=EPI_SWIGLU, W_frag=hip.pack_gemm_frag(W2, 2 * Hd, K2))
+    want = torch.nn.functional.silu(A2.float() @ wg.float().t()) * (A2.float() @ wi.float().t())
+    assert rel_err(out.float(), want) < TOL_BF16
+    # a transposed / swapped layout cannot hide behind a tolerance: identity against an asymmetric W returns W^T exactly
+    Kt = Nt = 256
+    wt = (torch.arange(Nt * Kt, device="cuda").reshape(Nt, Kt) % 251).to(BF16)
+    Wt = packing.pack_matrix(wt, "cuda")
+    o = torch.empty(Kt, Nt, device="cuda", dtype=BF16)
+    hip.gemm(torch.eye(Kt, device="cuda", dtype=BF16), Wt, o, N=Nt, K=Kt, W_frag=hip.pack_gemm_frag(Wt, Nt, Kt))
+    assert torch.equal(o, wt.t().contiguous())
+    # race screen: look-ahead loads, LDS-DMA ring and counted waits -- repeated launches of a 108-stage problem are bit-identical
+    M3, N3, K3 = 3000, 2560, 6912
+    A3 = rnd(M3, K3)
+    w3, W3 = packed(N3, K3)
+    Wf3 = hip.pack_gemm_frag(W3, N3, K3)
+    outs = []
+    for _ in range(4):
+        o3 = torch.empty(M3, N3, device="cuda", dtype=BF16)
+        hip.gemm(A3, W3, o3, N=N3, K=K3, W_frag=Wf3)
+        outs.append(o3)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o3, outs[0]) for o3 in outs[1:])
+    assert rel_err(outs[0].float(), ref.gemm(A3, W3, torch.empty(M3, N3, device="cuda"), N=N3, K=K3)) < TOL_BF16
+    # and a shape the kernel cannot serve is refused under gemm_impl = 2 (K = 192: not a multiple of 128)
+    w4, W4 = packed(256, 192)
+    with pytest.raises(Exception):
+        hip.gemm(rnd(64, 192), W4, torch.empty(64, 256, device="cuda", dtype=BF16), N=256, K=192, W_frag=W4.reshape(-1)[:256 * 192])
+
+
 # ------------------------------------------------------------------ implicit-GEMM causal conv
 CONV_ROWS_DEFAULT = 8        # the library's default for svr_set_option("conv_rows", ...)
 CONV_CASES = [

@@ -95,9 +95,10 @@ def main():
             kw = {}
             if epi == ops_mod.EPI_RESID_GATE:
                 kw = dict(gate=torch.ones(N, dtype=torch.float32, device=dev), resid=rnd(M, N))
-            sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, epilogue=epi, **kw), args.reps)
-            report(name, sec, flops=2.0 * M * N * K)
-            del a, w, c, kw
+            wf = ops.pack_gemm_frag(w, N, K)          # None unless SVR_OPTIONS=gemm_impl=1|2 (register-streamed weights)
+            sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, epilogue=epi, W_frag=wf, **kw), args.reps)
+            report(name + (" [gemm8]" if wf is not None else ""), sec, flops=2.0 * M * N * K)
+            del a, w, c, kw, wf
     if "shortk" in only:
         # short-K problems of the VAE (tools/shape_census.py): pixel-shuffle upsamplers, 1x1 shortcut convs, attention scores
         for name, F_, H, W, Cc, rz in (("upsample gemm+pixel-shuffle 256->1024 @5x512^2", 5, 512, 512, 256, 1),
