@@ -17,6 +17,7 @@ round-trips every latent through host RAM by default) and with 28
 whole output clip in HBM.  Temporal batches are independent units, which is what ``dist.py`` shards over ranks.
 """
 from dataclasses import dataclass
+import inspect
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -78,6 +79,14 @@ def transformed_shape(images_thwc: torch.Tensor, plan: BatchPlan, resolution: in
     return (3, t, (h + 15) // 16 * 16, (w + 15) // 16 * 16)
 
 
+def _takes_keep_frames(runner) -> bool:
+    """Only this repo's runner knows ``vae_decode(..., keep_frames=)``; any object with the reference's three calls still works."""
+    try:
+        return "keep_frames" in inspect.signature(runner.vae_decode).parameters
+    except (TypeError, ValueError):
+        return False
+
+
 @torch.no_grad()
 def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolution: int = 1080,
             max_resolution: int = 0, batch_size: int = 5, uniform_batch_size: bool = False,
@@ -87,7 +96,7 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
             progress: Optional[Callable[[str, int, int], None]] = None,
             noise_provider: Optional[Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None,
             exchange_heads: Optional[Callable[[dict, list, tuple], dict]] = None,
-            return_spans: bool = False):
+            return_spans: bool = False, skip_trimmed_frames: bool = False):
     """images [T, H, W, 3] in [0, 1] (any float dtype, on the runner's device) -> upscaled [T, H', W', 3] in [0, 1].
 
     ``batch_filter(i)`` restricts phases 1-3 to the temporal batches a rank owns (data parallelism over
@@ -166,7 +175,10 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
         ori = plan.end - plan.start
         n_new = ori if (i == 0 or overlap == 0) else max(ori - overlap, 0)
         if i in upscaled:
-            sample = runner.vae_decode([upscaled.pop(i)])[0]
+            # (skip_trimmed_frames: the decoder is causal in time, so our runner can leave out the padding frames that are
+            # trimmed two lines down -- same result; off by default until it has run on the GPU path: DESIGN.md 7)
+            sample = (runner.vae_decode([upscaled.pop(i)], keep_frames=[ori])[0]
+                      if skip_trimmed_frames and _takes_keep_frames(runner) else runner.vae_decode([upscaled.pop(i)])[0])
             if sample.dim() == 3:
                 sample = sample.unsqueeze(1)
             sample = sample.permute(1, 2, 3, 0)[:ori, :true_h, :true_w]                   # T H W C, padding trimmed

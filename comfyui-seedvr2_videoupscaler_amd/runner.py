@@ -142,9 +142,14 @@ class VideoDiffusionInfer:
 
     # ---- infer.py:203-278
     @torch.no_grad()
-    def vae_decode(self, latents: List[torch.Tensor]) -> List[torch.Tensor]:
+    def vae_decode(self, latents: List[torch.Tensor], keep_frames: Optional[Sequence[Optional[int]]] = None) -> List[torch.Tensor]:
+        """``keep_frames`` (not in the reference's signature; optional): per latent, the number of leading output frames the
+        caller will keep -- the temporal padding it is going to trim is then not decoded (VideoVAEEngine.decode)."""
+        keep = list(keep_frames) if keep_frames is not None else [None] * len(latents)
+        if len(keep) != len(latents):
+            raise ValueError("keep_frames must have one entry per latent")
         return [self.vae.decode(l, tiled=self.decode_tiled, tile_size=self.decode_tile_size,
-                                tile_overlap=self.decode_tile_overlap) for l in latents]
+                                tile_overlap=self.decode_tile_overlap, keep_frames=k) for l, k in zip(latents, keep)]
 
     # ---- infer.py:315-395
     @torch.no_grad()

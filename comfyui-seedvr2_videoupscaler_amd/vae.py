@@ -504,11 +504,20 @@ class VideoVAEEngine:
     def _decoder_slice(self, z, st, first):
         h, hs = self._conv(self.dec_conv_in, z, st, first, gn=True)
         h, hs = self._mid(self.dec_mid, h, st, first, hs)
-        for res, up in self.dec_up:
+        for i, (res, up) in enumerate(self.dec_up):
             for rb in res:
                 h, hs = self._resnet(rb, h, st, first, hs)
             if up is not None:
                 h, hs = self._upsample(up, h, st, first)
+                if i == self.cfg.temporal_scale_num - 1 and st.get("__keep__") is not None:
+                    # full frame rate from here on, every layer causal in time: frames the caller will trim are not computed
+                    # (only the clip's last slice can be cut: decode() already dropped the latent frames nobody needs)
+                    done = st["__produced__"]
+                    st["__produced__"] = done + h.shape[0]
+                    n = max(1, min(h.shape[0], st["__keep__"] - done))
+                    if n < h.shape[0]:
+                        assert st.get("__last_slice__", False)
+                        h, hs = h[:n], (hs[:n] if hs is not None else None)
         h = self._gn(self.dec_norm_out, h, True, hs)
         return self._conv(self.dec_conv_out, h, st, first)
 
@@ -539,14 +548,15 @@ class VideoVAEEngine:
             outs.append(self._encoder_slice(x_thwc[a:b], st, i == 0))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
-    def decode_clip(self, z_thwc: torch.Tensor, latents_per_slice: Optional[int] = None) -> torch.Tensor:
-        """[T', h, w, 16] -> [T, 8h, 8w, 3]."""
+    def decode_clip(self, z_thwc: torch.Tensor, latents_per_slice: Optional[int] = None,
+                    keep_frames: Optional[int] = None) -> torch.Tensor:
+        """[T', h, w, 16] -> [T, 8h, 8w, 3] (the first ``keep_frames`` frames of it: see decode)."""
         Tl, h, w, _ = z_thwc.shape
         if latents_per_slice is None:
             s = self.cfg.spatial_downsample_factor
             per_latent = (h * s) * (w * s) * 2 * self.cfg.block_out_channels[0] * 2 * self.cfg.temporal_downsample_factor
             latents_per_slice = max(1, int(self.act_budget_bytes // per_latent))
-        st, outs = {}, []
+        st, outs = {"__keep__": keep_frames, "__produced__": 0}, []
         slices = self._slices(Tl, 1, latents_per_slice)
         for i, (a, b) in enumerate(slices):
             st["__last_slice__"] = i == len(slices) - 1
@@ -599,12 +609,24 @@ class VideoVAEEngine:
 
     @torch.no_grad()
     def decode(self, latent_thwc: torch.Tensor, tiled: bool = False, tile_size=(512, 512), tile_overlap=(64, 64),
-               latents_per_slice: Optional[int] = None) -> torch.Tensor:
-        """scaled latent [T', h, w, 16] -> sample [3, T, 8h, 8w] (or [3, 8h, 8w] for a single frame)."""
+               latents_per_slice: Optional[int] = None, keep_frames: Optional[int] = None) -> torch.Tensor:
+        """scaled latent [T', h, w, 16] -> sample [3, T, 8h, 8w] (or [3, 8h, 8w] for a single frame).
+        ``keep_frames``: the caller keeps only the first n output frames (the pipeline trims the 4n+1 / uniform-batch padding
+        after decode, generation_phases.py:953-958): the decoder is causal in time, so the latent frames that only feed
+        trimmed output and, at full frame rate, the trimmed frames themselves are not computed -> [3, n, 8h, 8w], equal to
+        the first n frames of the full decode."""
         cfg, ops = self.cfg, self.ops
         lat = latent_thwc.to(device=self.device, dtype=self.ops.act_dtype).contiguous()
         if lat.dim() == 3:
             lat = lat.unsqueeze(0)
+        tf = cfg.temporal_downsample_factor
+        if keep_frames is not None:
+            if keep_frames < 1:
+                raise ValueError("keep_frames must be >= 1")
+            if keep_frames >= 1 + (lat.shape[0] - 1) * tf:
+                keep_frames = None
+            else:
+                lat = lat[:(keep_frames - 1 + tf - 1) // tf + 1].contiguous()     # latent j > 0 first shows in output frame tf (j - 1) + 1
         Tl, H, W, lc = lat.shape
         z = ops.empty(Tl, H, W, lc)
         # latent / scale + shift  ==  (latent - (-shift*scale)) * (1/scale)
@@ -612,7 +634,7 @@ class VideoVAEEngine:
         s = cfg.spatial_downsample_factor
         lth, ltw = max(1, tile_size[0] // s), max(1, tile_size[1] // s)
         if not tiled or (H <= lth and W <= ltw):
-            y = self.decode_clip(z, latents_per_slice)
+            y = self.decode_clip(z, latents_per_slice, keep_frames)
         else:
             oh, ow = tile_overlap
             loh = max(0, min(oh // s, lth - 1))
@@ -621,7 +643,7 @@ class VideoVAEEngine:
             acc = cnt = None
             for (y0, y1) in _tile_ranges(H, lth, loh):
                 for (x0, x1) in _tile_ranges(W, ltw, low):
-                    dec = self.decode_clip(z[:, y0:y1, x0:x1].contiguous(), latents_per_slice)
+                    dec = self.decode_clip(z[:, y0:y1, x0:x1].contiguous(), latents_per_slice, keep_frames)
                     if acc is None:
                         acc = torch.zeros(dec.shape[0], H * s, W * s, dec.shape[3], dtype=torch.float32, device=self.device)
                         cnt = torch.zeros(H * s, W * s, dtype=torch.float32, device=self.device)

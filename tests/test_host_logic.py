@@ -126,6 +126,46 @@ def test_vae_causal_head_merge_in_the_engine(vae_setup):
     assert rel_err(both.decode(z), only_up.decode(z)) < 2e-5 and rel_err(both.decode(z, latents_per_slice=1), both.decode(z)) < 1e-5
 
 
+def test_vae_decode_skips_the_frames_the_caller_trims(vae_setup):
+    """decode(z, keep_frames=n) == decode(z)[:, :n] for every n (the decoder is causal in time): untiled, one latent per slice,
+    tiled; the latent frames that only feed trimmed output never enter the decoder, and at full frame rate the trimmed frames
+    are not computed (fewer multiply-adds, counted through the ops)."""
+    cfg, sd, eng = vae_setup
+    z = torch.randn(4, 6, 5, cfg.latent_channels, generator=torch.Generator().manual_seed(9)) * 0.5
+    variants = ({}, dict(latents_per_slice=1), dict(tiled=True, tile_size=(32, 32), tile_overlap=(8, 8)))
+    full = [eng.decode(z, **kw) for kw in variants]
+    assert full[0].shape[1] == 13
+    for k in (1, 2, 5, 6, 9, 12, 13, 20):
+        for kw, f in zip(variants, full):
+            y = eng.decode(z, keep_frames=k, **kw)
+            y = y.unsqueeze(1) if y.dim() == 3 else y
+            assert y.shape[1] == min(k, 13) and rel_err(y, f[:, :k]) < 1e-5, (k, kw)
+    with pytest.raises(ValueError):
+        eng.decode(z, keep_frames=0)
+
+    class Counting(TorchOps):
+        macs, depth = 0.0, 0
+
+        def gemm(self, A, W, out, *, N, K, M=None, conv=None, **kw):
+            if self.depth == 0:
+                self.macs += 2.0 * (conv.To * conv.Ho * conv.Wo if conv is not None else (M if M is not None else A.shape[0])) * N * K
+            self.depth += 1
+            try:
+                return super().gemm(A, W, out, N=N, K=K, M=M, conv=conv, **kw)
+            finally:
+                self.depth -= 1
+
+    ops = Counting("cpu", act_dtype=torch.float32)
+    e2 = sub("vae").VideoVAEEngine(cfg, sd, ops)
+    e2.decode(z)
+    all13 = ops.macs
+    e2.decode(z, keep_frames=12)
+    cut12 = ops.macs - all13
+    e2.decode(z, keep_frames=9)                       # the fourth latent frame is not needed at all
+    cut9 = ops.macs - all13 - cut12
+    assert cut9 < cut12 < all13 and cut12 > 0.9 * all13 and cut9 < 0.8 * all13
+
+
 def test_flop_model_counts_what_the_engine_launches():
     """flops.py (bench.py's executed_tflop_per_step and the FLOPs behind roofline.achieved) against the multiply-adds of the
     GEMM / implicit-GEMM launches the engine really issues, for the reference's form and for both algebraic reductions

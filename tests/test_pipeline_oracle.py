@@ -38,6 +38,19 @@ def test_product_pipeline_fp32_double_equals_reference_chain():
     # may move by a few per cent -- bound the bulk tightly and the outliers loosely
     assert rel_err(out.float(), g["out"]) < 5e-4 and float(d.flatten().kthvalue(int(d.numel() * 0.999)).values) < 2e-3
     assert float(d.max()) < 6e-2
+    # skip_trimmed_frames: the padding frames the pipeline trims after decode are not decoded at all -- same clip (the golden's
+    # batches carry uniform-batch and 4n+1 padding), fewer frames through the decoder
+    decoded = []
+    real = r.vae.decode
+    r.vae.decode = lambda *a, **k: decoded.append(k.get("keep_frames")) or real(*a, **k)
+    out2 = pipeline.upscale(images, r, weights.synth_text_embedding().float(), resolution=g["resolution"],
+                            batch_size=g["batch_size"], uniform_batch_size=g["uniform_batch_size"],
+                            temporal_overlap=g["temporal_overlap"], color_correction="lab", noise_provider=noise,
+                            skip_trimmed_frames=True)
+    r.vae.decode = real
+    assert any(k is not None for k in decoded)
+    d2 = (out2.float() - out.float()).abs()
+    assert float(d2.flatten().kthvalue(int(d2.numel() * 0.999)).values) < 1e-4 and float(d2.max()) < 6e-2
 
 
 def test_oracle_pipeline_over_in_repo_oracles_equals_reference_chain():
