@@ -135,7 +135,7 @@ def test_vae_decode_skips_the_frames_the_caller_trims(vae_setup):
     variants = ({}, dict(latents_per_slice=1), dict(tiled=True, tile_size=(32, 32), tile_overlap=(8, 8)))
     full = [eng.decode(z, **kw) for kw in variants]
     assert full[0].shape[1] == 13
-    for k in (1, 2, 5, 6, 9, 12, 13, 20):
+    for k in (1, 6, 9, 12, 20):                      # one frame; mid-clip cuts (whole latent frames dropped); the 4n+1 trim; no-op
         for kw, f in zip(variants, full):
             y = eng.decode(z, keep_frames=k, **kw)
             y = y.unsqueeze(1) if y.dim() == 3 else y
