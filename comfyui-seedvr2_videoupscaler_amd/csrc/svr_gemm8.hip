@@ -54,7 +54,7 @@ SVR_DEVICE const char* g8_uniform(const char* p) {
     return (const char*)(((uint64_t)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(G8_NT, 1) void gemm8_kernel(const svr_gemm_args a, const int abl_arg) {
+__global__ __launch_bounds__(G8_NT, 1) void gemm8_kernel(const svr_gemm_args a, const int abl_arg, const int stagger) {
 #ifdef SVR_ABLATIONS   // measurement build (results invalid): 1 no weight loads | 2 no LDS-DMA pieces | 4 no fragment reads | 8 no stores
     const int abl = abl_arg;
 #else
@@ -65,6 +65,11 @@ __global__ __launch_bounds__(G8_NT, 1) void gemm8_kernel(const svr_gemm_args a, 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // experiment (svr_set_option("gemm_stagger", n)): the workgroups of the FIRST wave on the chip start n * (XCD index) sleeps of
+    // 8128 cycles late, so that the equal-length tiles that follow reach their store phases out of step instead of all at once
+    if (stagger > 0 && blockIdx.x < 512u) {
+        for (int i = 0; i < stagger * (int)(blockIdx.x & 7); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int wm = wave >> 1, wn = wave & 1;              // rows 128 wm .. + 127, columns 128 wn .. + 127 of the tile
 
     // ---- tile id: XCD-contiguous bands, then groups of 4 row panels x all column panels (gemm_kernel's order)
@@ -346,12 +351,17 @@ template <int N> SVR_DEVICE void g4_wait_vm(g4_frag2& x) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ __launch_bounds__(G4_NT, 2) void gemm4_kernel(const svr_gemm_args a) {
+__global__ __launch_bounds__(G4_NT, 2) void gemm4_kernel(const svr_gemm_args a, const int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((ext_vector_type(16))) float f32x16_t;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // experiment (svr_set_option("gemm_stagger", n)): the workgroups of the FIRST wave on the chip start n * (XCD index) sleeps of
+    // 8128 cycles late, so that the equal-length tiles that follow reach their store phases out of step instead of all at once
+    if (stagger > 0 && blockIdx.x < 512u) {
+        for (int i = 0; i < stagger * (int)(blockIdx.x & 7); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int wm = wave >> 1, wn = wave & 1;              // rows 128 wm .. + 127, columns 64 wn .. + 63 of the tile
 
     const int tiles_m = (a.M + G4_BM - 1) / G4_BM;
@@ -571,6 +581,7 @@ __global__ __launch_bounds__(G4_NT, 2) void gemm4_kernel(const svr_gemm_args a) 
 // fragment-ordered weight copy and fit it; 2 = as 1, but such a GEMM that does NOT fit is an error (tests: no silent fallback);
 // 3 / 4 = the same two meanings for gemm4_kernel (two workgroups per CU)
 int g_gemm_impl = 0;
+int g_gemm_stagger = 0;   // experiment knob, see gemm8_kernel
 
 // what gemm8_kernel serves (everything else: gemm_kernel)
 static bool gemm8_eligible(const svr_gemm_args& a) {
@@ -598,7 +609,7 @@ static int launch_gemm4(const svr_gemm_args& a, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ((a.M + G4_BM - 1) / G4_BM) * (a.N / G4_BN);
-    hipLaunchKernelGGL(gemm4_kernel, dim3(tiles), dim3(G4_NT), G4_LDS, s, a);
+    hipLaunchKernelGGL(gemm4_kernel, dim3(tiles), dim3(G4_NT), G4_LDS, s, a, g_gemm_stagger);
     return (int)hipGetLastError();
 }
 
@@ -610,7 +621,7 @@ static int launch_gemm8(const svr_gemm_args& a, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ((a.M + G8_BM - 1) / G8_BM) * (a.N / G8_BN);
-    hipLaunchKernelGGL(gemm8_kernel, dim3(tiles), dim3(G8_NT), G8_LDS, s, a, g_pipe_abl);
+    hipLaunchKernelGGL(gemm8_kernel, dim3(tiles), dim3(G8_NT), G8_LDS, s, a, g_pipe_abl, g_gemm_stagger);
     return (int)hipGetLastError();
 }
 
