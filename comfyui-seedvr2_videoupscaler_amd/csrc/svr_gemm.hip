@@ -468,6 +468,8 @@ static int launch_conv_sub(const svr_gemm_args& a, hipStream_t s);
 // plain GEMM with register-streamed weights (svr_gemm8.hip)
 static bool gemm8_eligible(const svr_gemm_args& a);
 static int launch_gemm8(const svr_gemm_args& a, hipStream_t s);
+static bool gemm4_eligible(const svr_gemm_args& a);
+static int launch_gemm4(const svr_gemm_args& a, hipStream_t s);
 extern int g_gemm_impl;
 int g_conv_impl = 0;   // 0 auto, 1 generic, 2 first halo kernel, 3 second halo kernel without W_frag
 
@@ -525,8 +527,8 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     if (g_conv_impl != 1 && conv_halo_eligible(a))
         return a.N <= 32 ? (g_conv_thinout ? launch_conv_thinout(a, s) : launch_conv_halo<32>(a, s)) : launch_conv_halo<128>(a, s);
     if (g_gemm_impl != 0 && !a.conv.enabled && a.W_frag != nullptr) {
-        if (gemm8_eligible(a)) return launch_gemm8(a, s);
-        if (g_gemm_impl == 2) { *why = "svr_gemm_bf16: gemm_impl = 2 and this GEMM with W_frag does not fit the register-streamed kernel"; return -1; }
+        if (g_gemm_impl <= 2 ? gemm8_eligible(a) : gemm4_eligible(a)) return g_gemm_impl <= 2 ? launch_gemm8(a, s) : launch_gemm4(a, s);
+        if (g_gemm_impl == 2 || g_gemm_impl == 4) { *why = "svr_gemm_bf16: gemm_impl = 2 | 4 and this GEMM with W_frag does not fit the register-streamed kernel"; return -1; }
     }
     // 256-wide tiles when N allows it (otherwise W is padded to a multiple of 128 rows) -- unless they would leave CUs idle:
     // the VAE attention's P V product (16384 x 512 x 16384) has only 128 such tiles for 256 CUs

@@ -111,9 +111,11 @@ class HipOps:
 
     def pack_gemm_frag(self, W, N: int, K: int):
         """Fragment-ordered copy of a packed nn.Linear weight W [Npad, K] for gemm(..., W_frag=) on plain GEMMs: the kernel with
-        register-streamed weights (svr_gemm8.hip; N % 256 == 0, K % 128 == 0, K >= 256).  None when that kernel is switched off
+        register-streamed weights (svr_gemm8.hip; N % 256 == 0 -- N % 128 == 0 for its two-workgroups-per-CU form, gemm_impl 3 | 4 --,
+        K % 128 == 0, K >= 256).  None when that kernel is switched off
         (svr_set_option("gemm_impl", 0), the default) or cannot serve the shape -- the copy doubles the weight's memory."""
-        if not hip_lib.OPTIONS.get("gemm_impl", 0) or N % 256 or K % 128 or K < 256 or W.shape[1] != K or W.shape[0] < N:
+        impl = hip_lib.OPTIONS.get("gemm_impl", 0)
+        if not impl or N % (256 if impl <= 2 else 128) or K % 128 or K < 256 or W.shape[1] != K or W.shape[0] < N:
             return None
         self._chk(W, BF16, "W")
         out = torch.empty(N * K, dtype=BF16, device=self.device)

@@ -145,11 +145,12 @@ def test_gemm_swiglu(hip, ref, gemm_epi):
     assert rel_err(w2, want) < 1e-5
 
 
-@pytest.fixture
-def gemm8(hip):
-    """svr_set_option("gemm_impl", 2): plain GEMMs that bring a fragment-ordered weight copy MUST run on the kernel with
-    register-streamed weights (svr_gemm8.hip) -- a shape it cannot serve is an error, not a silent fallback."""
-    hip.set_option("gemm_impl", 2)
+@pytest.fixture(params=[2, 4], ids=["one_wg_256acc", "two_wg_128acc"])
+def gemm8(request, hip):
+    """svr_set_option("gemm_impl", 2 | 4): plain GEMMs that bring a fragment-ordered weight copy MUST run on the kernel with
+    register-streamed weights (svr_gemm8.hip: gemm8_kernel / gemm4_kernel) -- a shape it cannot serve is an error, not a
+    silent fallback."""
+    hip.set_option("gemm_impl", request.param)
     yield hip
     hip.set_option("gemm_impl", 0)
 
