@@ -917,6 +917,7 @@ static bool conv_thin_eligible(const svr_gemm_args& a) {
 static int launch_conv_thin(const svr_gemm_args& a, hipStream_t s) { return launch_conv_halo2_t<8, 2>(a, s); }
 
 static int conv_gn_blocks(const svr_gemm_args& a) {
+    if (a.gn_groups > 0 && conv_sub_eligible(a)) return conv_sub_gn_blocks(a);
     if (conv_thin_eligible(a) && !a.out_f32 && a.gn_groups > 0) {
         const int cpg = a.N / a.gn_groups;
         if (cpg < 4 || (cpg & 3) || a.N % a.gn_groups || 128 % cpg) return 0;

@@ -297,6 +297,7 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
     const int up = a.phase.enabled ? 2 : 1, ts = a.phase.enabled ? a.phase.t_stride : 1;
     const int yb = a.phase.py ? g.H - 1 : 0, xb = a.phase.px ? g.W - 1 : 0;
     const float* btab = a.phase.enabled ? a.phase.bias_border : nullptr;
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;      // fused GroupNorm statistics of the stored values (columns n .. n + 3, n + 4 .. n + 7)
 #pragma unroll
     for (int pass = 0; pass < MTW / 2; ++pass) {
         __builtin_amdgcn_sched_barrier(0);
@@ -344,23 +345,73 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
                                     hi_[it][0] + bh[0], hi_[it][1] + bh[1], hi_[it][2] + bh[2], hi_[it][3] + bh[3]};
                 const uint4 pk = pack8(f);
                 if (ok[it]) *(uint4*)((bf16_t*)a.C + off[it]) = pk;
+                if (a.gn_partial != nullptr && ok[it]) {
+                    float r[8];
+                    unpack8(pk, r);
+                    gs0 += r[0] + r[1] + r[2] + r[3];
+                    gq0 += r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+                    gs1 += r[4] + r[5] + r[6] + r[7];
+                    gq1 += r[4] * r[4] + r[5] * r[5] + r[6] * r[6] + r[7] * r[7];
+                }
             }
         }
         if (pass + 1 < MTW / 2) __syncthreads();
+    }
+    if (a.gn_partial) {
+        // fixed-order reduction thread -> quad -> group (svr_conv_halo2.hip's); the (sum, sum of squares) of this patch go to
+        // gn_partial[output frame][phase (py, px)][block][group]: the four phase launches of an upsampled frame fill one row of
+        // 4 x blocks entries, which svr_groupnorm_reduce() adds up (a dense launch: [frame][block][group])
+        __syncthreads();
+        float4* red = (float4*)smem;                      // [NT]
+        double2* qsum = (double2*)(smem + 8192);          // [32 quads]
+        red[tid] = make_float4(gs0, gq0, gs1, gq1);
+        __syncthreads();
+        if (tid < 32) {                                   // quad = 2 * chunk + half; rows tid' with tid' & 15 == chunk
+            const int c = tid >> 1, h = tid & 1;
+            double s_ = 0.0, q_ = 0.0;
+            for (int j = 0; j < NT / 16; ++j) {
+                const float4 v = red[(j << 4) | c];
+                s_ += (double)(h ? v.z : v.x);
+                q_ += (double)(h ? v.w : v.y);
+            }
+            qsum[tid] = make_double2(s_, q_);
+        }
+        __syncthreads();
+        const int qpg = (a.N / a.gn_groups) >> 2;         // quads per group (channels per group / 4)
+        if (tid < 32 / qpg) {
+            double s_ = 0.0, q_ = 0.0;
+            for (int i = 0; i < qpg; ++i) { s_ += qsum[tid * qpg + i].x; q_ += qsum[tid * qpg + i].y; }
+            const int nblk = tiles_y * tiles_x;
+            const int per_frame = a.phase.enabled ? 4 * nblk : nblk;
+            const int slot = (a.phase.enabled ? (py * 2 + px) * nblk : 0) + ty * tiles_x + tx;
+            ((double2*)a.gn_partial)[((int64_t)to * ts * per_frame + slot) * a.gn_groups + (n0 >> 2) / qpg + tid] = make_double2(s_, q_);
+        }
     }
 }
 
 int g_conv_sub = 1;        // 0: the sub-pixel convs run on the generic implicit-GEMM kernel (svr_set_option("conv_sub"))
 
 // what conv_sub_kernel serves: (kt, 2, 2) taps, stride 1, same-size output, pads 0 | 1, fragment-ordered weights, plain bias epilogue
+static bool conv_sub_gn_ok(const svr_gemm_args& a) {         // fused statistics: 4, 8 or 16 channels per group inside a 128-cout tile
+    const int cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 0;
+    return cpg >= 4 && !(cpg & 3) && a.N % a.gn_groups == 0 && 128 % cpg == 0;
+}
+
 static bool conv_sub_eligible(const svr_gemm_args& a) {
     const svr_conv_geom& g = a.conv;
     return g_conv_sub && g.enabled && a.W_frag != nullptr && g.kh == 2 && g.kw == 2 && g.sh == 1 && g.sw == 1 && g.st == 1 &&
            (unsigned)g.ph <= 1u && (unsigned)g.pw <= 1u && g.Ho == g.H && g.Wo == g.W && g.Cin % 32 == 0 && g.kt >= 1 && g.kt <= 3 &&
            g.To == g.T + g.pt - g.kt + 1 && !a.ps.enabled && a.epilogue == SVR_EPI_BIAS && !a.out_f32 && !a.resid && !a.gate &&
-           !a.gn_partial && (a.N % 128) == 0 && (a.phase.enabled || (a.ldc == a.N)) &&
+           (!a.gn_partial || conv_sub_gn_ok(a)) && (a.N % 128) == 0 && (a.phase.enabled || (a.ldc == a.N)) &&
            (int64_t)g.H * g.W * g.Cin * 2 < (int64_t)1 << 32 && ((uintptr_t)a.C % 16) == 0 &&
            (!a.bias || ((uintptr_t)a.bias % 16) == 0) && (!a.phase.bias_border || ((uintptr_t)a.phase.bias_border % 16) == 0);
+}
+
+// partial blocks per OUTPUT frame of the fused statistics (0: not produced); a phase launch fills a quarter of them
+static int conv_sub_gn_blocks(const svr_gemm_args& a) {
+    if (!conv_sub_eligible(a) || !conv_sub_gn_ok(a)) return 0;
+    const int nblk = ((a.conv.H + CS_TY - 1) / CS_TY) * ((a.conv.W + CS_TX - 1) / CS_TX);
+    return a.phase.enabled ? 4 * nblk : nblk;
 }
 
 static int launch_conv_sub(const svr_gemm_args& a, hipStream_t s) {

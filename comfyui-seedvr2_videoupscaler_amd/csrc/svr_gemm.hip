@@ -465,6 +465,7 @@ extern int g_conv_thinout;
 // sub-pixel upsampler conv kernel (svr_conv_sub.hip)
 static bool conv_sub_eligible(const svr_gemm_args& a);
 static int launch_conv_sub(const svr_gemm_args& a, hipStream_t s);
+static int conv_sub_gn_blocks(const svr_gemm_args& a);
 // plain GEMM with register-streamed weights (svr_gemm8.hip)
 static bool gemm8_eligible(const svr_gemm_args& a);
 static int launch_gemm8(const svr_gemm_args& a, hipStream_t s);
@@ -514,10 +515,11 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     }
     if (a.phase.enabled) {
         const svr_conv_geom& g = a.conv;
-        if (!g.enabled || g.st != 1 || g.sh != 1 || g.sw != 1 || g.Ho != g.H || g.Wo != g.W || a.ps.enabled || a.resid || a.gn_partial ||
+        if (!g.enabled || g.st != 1 || g.sh != 1 || g.sw != 1 || g.Ho != g.H || g.Wo != g.W || a.ps.enabled || a.resid ||
+            (a.gn_partial && conv_sub_gn_blocks(a) == 0) ||
             a.epilogue == SVR_EPI_SWIGLU || (unsigned)a.phase.py > 1u || (unsigned)a.phase.px > 1u ||
             (a.phase.t_stride != 1 && a.phase.t_stride != 2)) {
-            *why = "svr_gemm_bf16: phase scatter needs a stride-1 same-size conv without ps / residual / SwiGLU / fused statistics"; return -1;
+            *why = "svr_gemm_bf16: phase scatter needs a stride-1 same-size conv without ps / residual / SwiGLU (fused statistics: sub-pixel conv kernel only)"; return -1;
         }
     }
     if (a.gn_partial && conv_gn_blocks(a) == 0) { *why = "svr_gemm_bf16: gn_partial set but this launch cannot produce fused GroupNorm statistics"; return -1; }

@@ -124,11 +124,15 @@ class HipOps:
 
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
              out_f32=False, conv: Optional[Conv3dGeom] = None, ps: Optional[PixelShuffleGeom] = None,
-             lda=None, ldc=None, ldr=None, gn_groups: int = 0, W_frag=None, phase: Optional[PhaseScatter] = None):
+             lda=None, ldc=None, ldr=None, gn_groups: int = 0, W_frag=None, phase: Optional[PhaseScatter] = None,
+             gn_shared: Optional[dict] = None):
         """out[M, N] = A[M, K] @ W[:N, :K]^T with fused epilogue.  W is [Npad, K] bf16 (Npad % 128 == 0).
         With ``gn_groups`` > 0 (conv mode) returns ``(out, stats)``: per-frame GroupNorm (sum, sumsq) of the stored
         output [To, groups, 2] fp64 fused into the conv epilogue, or ``None`` when the kernel serving this
-        geometry does not produce them (the caller then runs groupnorm_stats)."""
+        geometry does not produce them (the caller then runs groupnorm_stats).
+        ``gn_shared`` (with ``gn_groups``): several launches write ONE output tensor (the phases of a sub-pixel upsampler); the
+        caller passes the same dict {"frames": output frames, "frame0": first output frame of this launch} to each of them and
+        calls gn_shared_stats() after the last -- the launches then return ``out`` only."""
         self._chk(A, BF16, "A"); self._chk(W, BF16, "W")
         self._chk(out, torch.float32 if out_f32 else BF16, "out")
         if W.shape[1] != K or W.shape[0] < N or W.shape[0] % 128:
@@ -157,8 +161,8 @@ class HipOps:
             if lda is None:
                 lda = A.stride(0) if A.dim() == 2 else K
         if phase is not None:
-            if conv is None or ps is not None or resid is not None or gn_groups:
-                raise ValueError("phase scatter: conv mode only, without pixel shuffle / residual / fused statistics")
+            if conv is None or ps is not None or resid is not None or (gn_groups and gn_shared is None):
+                raise ValueError("phase scatter: conv mode only, without pixel shuffle / residual; fused statistics through gn_shared")
             if out.numel() < ((conv.To - 1) * phase.t_stride + 1) * 4 * conv.Ho * conv.Wo * N or not out.is_contiguous():
                 raise ValueError("phase scatter: out must be the dense [frames, 2*Ho, 2*Wo, N] tensor from the launch's first frame on")
             a.phase.enabled, a.phase.py, a.phase.px, a.phase.t_stride = 1, int(phase.py), int(phase.px), int(phase.t_stride)
@@ -193,19 +197,40 @@ class HipOps:
         if gn_groups > 0 and conv is not None:
             a.gn_groups = gn_groups
             nblk = int(self.lib.svr_gemm_gn_blocks(C.byref(a)))
-            if nblk > 0:
+            if gn_shared is not None:
+                # one partial buffer [frames][nblk][groups] for all launches of the output tensor; a launch that cannot fuse
+                # (nblk == 0, or a different block count than its siblings) switches the whole tensor back to the separate pass
+                if nblk > 0 and gn_shared.get("ok", True) and gn_shared.get("nblk", nblk) == nblk:
+                    if "partial" not in gn_shared:
+                        gn_shared.update(nblk=nblk, groups=gn_groups, ok=True, partial=torch.empty(
+                            gn_shared["frames"] * nblk * gn_groups * 2, dtype=torch.float64, device=self.device))
+                    a.gn_partial = gn_shared["partial"].data_ptr() + int(gn_shared["frame0"]) * nblk * gn_groups * 16
+                else:
+                    gn_shared["ok"] = False
+                    a.gn_groups = 0
+            elif nblk > 0:
                 partial = torch.empty(conv.To * nblk * gn_groups * 2, dtype=torch.float64, device=self.device)
                 a.gn_partial = partial.data_ptr()
                 stats = torch.empty(conv.To, gn_groups, 2, dtype=torch.float64, device=self.device)
             else:
                 a.gn_groups = 0
         hip_lib.check(self.lib.svr_gemm_bf16(C.byref(a), self._stream()), "svr_gemm_bf16")
-        if gn_groups > 0:
+        if gn_groups > 0 and gn_shared is None:
             if stats is not None:
                 hip_lib.check(self.lib.svr_groupnorm_reduce(_ptr(partial), _ptr(stats), conv.To, nblk, gn_groups,
                                                             self._stream()), "svr_groupnorm_reduce")
             return out, stats
         return out
+
+    def gn_shared_stats(self, gn_shared: dict):
+        """Statistics [frames, groups, 2] of a tensor whose launches shared ``gn_shared`` (gemm), or None when one of them could
+        not fuse them (the caller then runs groupnorm_stats)."""
+        if not gn_shared.get("ok", False) or "partial" not in gn_shared:
+            return None
+        stats = torch.empty(gn_shared["frames"], gn_shared["groups"], 2, dtype=torch.float64, device=self.device)
+        hip_lib.check(self.lib.svr_groupnorm_reduce(_ptr(gn_shared["partial"]), _ptr(stats), gn_shared["frames"], gn_shared["nblk"],
+                                                    gn_shared["groups"], self._stream()), "svr_groupnorm_reduce")
+        return stats
 
     # ------------------------------------------------------------------ DiT side kernels
     def rmsnorm_mod(self, x, out, eps, w=None, scale=None, shift=None):

@@ -442,6 +442,8 @@ class VideoVAEEngine:
         carry = kt - 1 if rz == 1 else 1                   # low-resolution frames the next slice needs
         outs = [subpixel.output_frames(t0 + tl, rz) for tl in range(T)]
         y = ops.empty(sum(len(o) for o in outs), 2 * H, 2 * W, cw.cout)
+        # GroupNorm statistics of y fused into the launches' epilogues where the ops offer it (one partial buffer for all of them)
+        shared = {"frames": y.shape[0]} if hasattr(ops, "gn_shared_stats") else None
 
         def launch(sig, a, b, base, t_stride):
             """frames a..b-1 of this slice -> y[base + j * t_stride] with the merged weights of `sig`."""
@@ -458,8 +460,12 @@ class VideoVAEEngine:
             geom_in = x[a:b]
             for py, px, w, bias, bb, frag in parts:
                 geom = Conv3dGeom(b - a, H, W, Cc, b - a, H, W, (n_src, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
+                kw = {}
+                if shared is not None:
+                    shared["frame0"] = base
+                    kw = dict(gn_groups=self.cfg.norm_num_groups, gn_shared=shared)
                 ops.gemm(geom_in, w, y[base:], N=cw.cout, K=w.shape[1], bias=bias, conv=geom,
-                         phase=PhaseScatter(py, px, bb, t_stride), W_frag=frag)
+                         phase=PhaseScatter(py, px, bb, t_stride), W_frag=frag, **kw)
 
         if rz == 1:
             launch(subpixel.signature(kt - 1, 1, kt), 0, T, 0, 1)
@@ -486,7 +492,7 @@ class VideoVAEEngine:
                 else:
                     prev = mem if mem is not None else x[:1].expand(carry, H, W, Cc)
                     st[key] = torch.cat([prev, x], dim=0)[-carry:].contiguous()
-        return y, None
+        return y, (ops.gn_shared_stats(shared) if shared is not None else None)
 
     # ------------------------------------------------------------------ one temporal slice through a network
     # (hs = GroupNorm statistics of h when the conv that produced h fused them into its epilogue, else None)

@@ -526,6 +526,45 @@ def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, frag, T, H, W, Cin, Cou
     assert rel_err(out.float(), want) < TOL_BF16
 
 
+@pytest.mark.parametrize("T,H,W,Cin,Cout,hf,kt,ts", [(3, 9, 11, 128, 128, 0, 3, 1), (2, 40, 70, 256, 256, 2, 3, 1), (3, 17, 33, 128, 256, 1, 2, 2),
+                                                     (1, 4, 4, 64, 128, 0, 1, 1)])
+def test_conv_subpixel_fused_groupnorm_statistics(hip, T, H, W, Cin, Cout, hf, kt, ts):
+    """The sub-pixel conv kernel's fused GroupNorm statistics: the phase launches of an upsampled tensor share one partial
+    buffer [frame][phase][block][group] (ops.gemm(gn_shared=...)); reduced, it equals svr_groupnorm_stats of the stored tensor
+    (both sum the bf16 values that were written; fixed orders, so repeated runs are bit-identical), frames offset by frame0."""
+    packing, opsmod = sub("packing"), sub("ops")
+    G = 32
+    x = rnd(T, H, W, Cin)
+    halo = rnd(hf, H, W, Cin, seed=9) if hf else None
+    pt = hf if hf else kt - 1
+    To = T + pt - kt + 1
+    lead = 2                                                                       # frames in front of the launches' first frame
+    runs = []
+    for _ in range(2):
+        out = torch.zeros((lead + To * ts, 2 * H, 2 * W, Cout), device="cuda", dtype=BF16)
+        shared = {"frames": out.shape[0]}
+        # the lead frames get their four phases from a launch of their own (as a head launch of the engine would); then one
+        # launch group per temporal phase: (first output frame, input, halo, causal pad, frames, frame stride)
+        groups = [(0, x[:1].expand(lead, H, W, Cin).contiguous(), None, kt - 1, lead, 1)]
+        groups += [(lead + tz, x, halo, pt, To, ts) for tz in range(ts)]
+        for base, xin, hl, p_t, to_n, stride in groups:
+            for ph, (py, px) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+                w5 = rnd(Cout, Cin, kt, 2, 2, scale=1.0 / math.sqrt(Cin * 4 * kt), seed=20 + ph + base)
+                Wp = packing.pack_conv3d(w5, "cuda")
+                geom = opsmod.Conv3dGeom(xin.shape[0], H, W, Cin, to_n, H, W, (kt, 2, 2), (1, 1, 1), (p_t, 1 - py, 1 - px), hl)
+                shared["frame0"] = base
+                hip.gemm(xin, Wp, out[base:], N=Cout, K=Wp.shape[1], bias=rnd(Cout, dtype=torch.float32, seed=30 + ph), conv=geom,
+                         phase=opsmod.PhaseScatter(py, px, rnd(3, Cout, dtype=torch.float32, seed=40 + ph), stride),
+                         W_frag=hip.pack_conv_frag(Wp, kt, Cin, Cout, taps=(2, 2)), gn_groups=G, gn_shared=shared)
+        stats = hip.gn_shared_stats(shared)
+        assert stats is not None and tuple(stats.shape) == (out.shape[0], G, 2)
+        want = torch.empty(out.shape[0], G, 2, dtype=torch.float64, device="cuda")
+        hip.groupnorm_stats(out, want, G)
+        assert rel_err(stats[..., 0], want[..., 0]) < 1e-5 and rel_err(stats[..., 1], want[..., 1]) < 1e-6
+        runs.append(stats)
+    assert torch.equal(runs[0], runs[1])
+
+
 @pytest.mark.parametrize("Cin,Cout,kt,T,H,W,hf", [(128, 3, 3, 3, 40, 70, 0), (512, 32, 3, 2, 19, 45, 2), (128, 3, 1, 2, 9, 33, 0), (192, 16, 3, 4, 8, 32, 0)])
 def test_conv_thin_output_kernel(hip, ref, Cin, Cout, kt, T, H, W, hf):
     """Thin-output convs (N <= 32: decoder conv_out 128 -> 3, encoder conv_out 512 -> 32) on the step-interval kernel
