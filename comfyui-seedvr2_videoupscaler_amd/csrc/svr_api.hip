@@ -6,8 +6,6 @@
 
 // single translation unit: the kernel sources are included here so one hipcc call builds the library
 #include "svr_gemm.hip"
-#include "svr_gemm8.hip"
-#include "svr_conv_halo.hip"
 #include "svr_conv_halo2.hip"
 #include "svr_conv_sub.hip"
 #include "svr_conv_thinout.hip"
@@ -40,12 +38,9 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "pipe_abl")) { g_pipe_abl = value; return 0; }
     if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
     if (!strcmp(key, "gemm_epi")) { g_gemm_epi = value; return 0; }
-    if (!strcmp(key, "gemm_impl")) { g_gemm_impl = value; return 0; }
-    if (!strcmp(key, "gemm_stagger")) { g_gemm_stagger = value; return 0; }
     if (!strcmp(key, "conv_rows")) { g_conv_rows = value; return 0; }
     if (!strcmp(key, "conv_band")) { g_conv_band = value; return 0; }
     if (!strcmp(key, "conv_sub")) { g_conv_sub = value; return 0; }
-    if (!strcmp(key, "conv_thinout")) { g_conv_thinout = value; return 0; }
     if (!strcmp(key, "conv_lds")) { g_conv_lds_dbg = value; return 0; }
     if (!strcmp(key, "attn_impl")) { g_attn_impl = value; return 0; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return 0; }
@@ -85,13 +80,15 @@ int svr_groupnorm_reduce(const void* partial, double* stats, int32_t T, int32_t 
 }
 
 int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps, const float* w, const float* scale,
-                    const float* shift, void* stream) {
+                    const float* shift, int32_t x_f32, void* stream) {
     if (rows <= 0) return 0;
     if (dim % 8 || dim > 64 * 8 * 8) return fail("svr_rmsnorm_mod: dim must be a multiple of 8 and <= 4096");
     const unsigned grid = (unsigned)(rows < 4 * 2048 ? blocks_for(rows, 4) : 2048);      // 8 blocks per CU, rows strided
     const int nc = (dim + 511) / 512;
-#define SVR_RMS_LAUNCH(NC) hipLaunchKernelGGL(rmsnorm_mod_kernel<NC>, dim3(grid), dim3(256), 0, (hipStream_t)stream, \
-                                              (const bf16_t*)x, (bf16_t*)y, rows, dim, eps, w, scale, shift)
+#define SVR_RMS_LAUNCH(NC) do { if (x_f32) hipLaunchKernelGGL((rmsnorm_mod_kernel<NC, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
+                                              x, (bf16_t*)y, rows, dim, eps, w, scale, shift); \
+                           else hipLaunchKernelGGL((rmsnorm_mod_kernel<NC, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
+                                              x, (bf16_t*)y, rows, dim, eps, w, scale, shift); } while (0)
     switch (nc) {
         case 1: SVR_RMS_LAUNCH(1); break; case 2: SVR_RMS_LAUNCH(2); break; case 3: SVR_RMS_LAUNCH(3); break;
         case 4: SVR_RMS_LAUNCH(4); break; case 5: SVR_RMS_LAUNCH(5); break; case 6: SVR_RMS_LAUNCH(6); break;
@@ -198,28 +195,30 @@ int64_t svr_groupnorm_workspace_bytes(int32_t T, int64_t HW, int32_t groups) {
 }
 
 int svr_groupnorm_stats(const void* x, double* stats, void* workspace, int32_t T, int64_t HW, int32_t C, int32_t groups,
-                        void* stream) {
+                        int32_t x_f32, void* stream) {
     if (T <= 0 || HW <= 0) return 0;
     if (C % 8 || C > 512 || groups > 32 || (C / groups) % 4 || (256 % (C / 8)))
         return fail("svr_groupnorm_stats: need C in {128,256,512}-like (C%8==0, C<=512, groups<=32, (C/groups)%4==0)");
     if (!workspace) return fail("svr_groupnorm_stats: workspace missing (svr_groupnorm_workspace_bytes)");
     const unsigned nblk = blocks_for(HW, GN_ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (double2*)workspace, HW, C, groups);
+    if (x_f32) hipLaunchKernelGGL(groupnorm_stats_kernel<true>, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream, x, (double2*)workspace, HW, C, groups);
+    else hipLaunchKernelGGL(groupnorm_stats_kernel<false>, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream, x, (double2*)workspace, HW, C, groups);
     hipLaunchKernelGGL(groupnorm_reduce_kernel, dim3(T, groups), dim3(256), 0, (hipStream_t)stream,
                        (const double2*)workspace, stats, (int)nblk, groups);
     return check(hipGetLastError(), "svr_groupnorm_stats");
 }
 
 int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float* gamma, const float* beta, int32_t T,
-                        int64_t HW, int32_t C, int32_t groups, float eps, int32_t apply_silu, void* stream) {
+                        int64_t HW, int32_t C, int32_t groups, float eps, int32_t apply_silu, int32_t x_f32, void* stream) {
     if (T <= 0 || HW <= 0) return 0;
     if (C % 8 || C > 512) return fail("svr_groupnorm_apply: C must be a multiple of 8 and <= 512");
     const int64_t nchunks = HW * (C / 8);
     unsigned gx = blocks_for(nchunks, 256 * 4);
     if (gx > 8192) gx = 8192;
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                       (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
+    if (x_f32) hipLaunchKernelGGL(groupnorm_apply_kernel<true>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,
+                                  (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
+    else hipLaunchKernelGGL(groupnorm_apply_kernel<false>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,
+                            (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
     return check(hipGetLastError(), "svr_groupnorm_apply");
 }
 

@@ -43,6 +43,16 @@ SVR_DEVICE void unpack8(const uint4& v, float* o) {
     o[6] = __builtin_bit_cast(float, v.w << 16); o[7] = __builtin_bit_cast(float, v.w & 0xffff0000u);
 }
 
+// 8 consecutive activations starting at element index e8 (a multiple of 8) of a bf16 or -- XF32: the wide residual trunk -- fp32 tensor
+template <bool XF32> SVR_DEVICE void load8(const void* base, int64_t e8, float* o) {
+    if constexpr (XF32) {
+        const float4 a = *(const float4*)((const float*)base + e8), b = *(const float4*)((const float*)base + e8 + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    } else {
+        unpack8(*(const uint4*)((const bf16_t*)base + e8), o);
+    }
+}
+
 SVR_DEVICE uint4 pack8(const float* o) {
     uint4 v;
     v.x = pack2bf(o[0], o[1]); v.y = pack2bf(o[2], o[3]);

@@ -711,7 +711,7 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
 #endif
     SVR_EP_STAMP(0)
     const bool resid_gate = a.epilogue == SVR_EPI_RESID_GATE;
-    // fused GroupNorm statistics of the stored (bf16-rounded) output: this thread always stores the same
+    // fused GroupNorm statistics of the stored (bf16-rounded, or fp32) output: this thread always stores the same
     // 8-cout chunk (tid & 15), so it keeps two quad sums over its 16 voxels
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
     constexpr int EP_ROWS = G::EP_ROWS;                             // patch rows per pass
@@ -725,6 +725,10 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
         constexpr int F = decltype(fc)::value;
         constexpr bool RT = F < 0, F_RESID = !RT && (F & 1), F_GN = !RT && (F & 2);
         const bool with_resid = RT ? (resid_gate && a.resid != nullptr) : F_RESID;
+        // wide residual trunk (ABI v5): fp32 output (F & 4) / fp32 residual (F & 8); the fused statistics are then those of the fp32 values
+        const bool o32 = RT ? (a.out_f32 != 0) : ((F & 4) != 0);
+        const bool r32 = RT ? (a.resid_f32 != 0) : ((F & 8) != 0);
+        const bool with_gn = RT ? a.gn_partial != nullptr : F_GN;
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             // every wave parks two of its MTW rows per pass (all waves write in every pass): LDS slot row wm * 2 + j
@@ -752,6 +756,7 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             for (int half = 0; half < 2; ++half) {
             f32x4 lo[4], hi_[4];
             uint4 rr8[4];
+            f32x4 rf0[4], rf1[4];
             int64_t mrow[4];
             bool ok[4];
 #pragma unroll
@@ -766,8 +771,22 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
                 hi_[it] = *(const f32x4*)(smem + vox * EP_PITCH + (tid & 15) * 32 + 16);
             }
             if (with_resid) {
+                if constexpr (RT) {                       // (run-time option set: tests / rare epilogues -- fp32 residuals are
+                    if (!r32) {                           //  loaded where they are used instead of four iterations ahead)
 #pragma unroll
-                for (int it = 0; it < 4; ++it) rr8[it] = *(const uint4*)((const bf16_t*)a.resid + mrow[it] * a.ldr + n);
+                        for (int it = 0; it < 4; ++it) rr8[it] = *(const uint4*)((const bf16_t*)a.resid + mrow[it] * a.ldr + n);
+                    }
+                } else if (r32) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const float* rp = (const float*)a.resid + mrow[it] * a.ldr + n;
+                        rf0[it] = *(const f32x4*)rp;
+                        rf1[it] = *(const f32x4*)(rp + 4);
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) rr8[it] = *(const uint4*)((const bf16_t*)a.resid + mrow[it] * a.ldr + n);
+                }
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -785,20 +804,36 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
                 }
                 if (with_resid) {
                     float r8[8];
-                    unpack8(rr8[it], r8);
+                    if (r32) {
+                        if constexpr (RT) {
+                            const float* rp = (const float*)a.resid + mrow[it] * a.ldr + n;
+                            rf0[0] = *(const f32x4*)rp;
+                            rf1[0] = *(const f32x4*)(rp + 4);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { r8[e] = rf0[RT ? 0 : it][e]; r8[4 + e] = rf1[RT ? 0 : it][e]; }
+                    } else {
+                        unpack8(rr8[it], r8);
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] += r8[e];
                 }
-                if (RT && a.out_f32) {
+                if (o32) {
                     if (ok[it]) {
                         float* cp = (float*)a.C + mrow[it] * a.ldc + n;
                         *(float4*)cp = make_float4(f[0], f[1], f[2], f[3]);
                         *(float4*)(cp + 4) = make_float4(f[4], f[5], f[6], f[7]);
+                        if (with_gn) {
+                            gs0 += f[0] + f[1] + f[2] + f[3];
+                            gq0 += f[0] * f[0] + f[1] * f[1] + f[2] * f[2] + f[3] * f[3];
+                            gs1 += f[4] + f[5] + f[6] + f[7];
+                            gq1 += f[4] * f[4] + f[5] * f[5] + f[6] * f[6] + f[7] * f[7];
+                        }
                     }
                 } else {
                     const uint4 pk = pack8(f);
                     if (ok[it]) *(uint4*)((bf16_t*)a.C + mrow[it] * a.ldc + n) = pk;
-                    if ((RT ? a.gn_partial != nullptr : F_GN) && ok[it]) {
+                    if (with_gn && ok[it]) {
                         float r[8];
                         unpack8(pk, r);
                         gs0 += r[0] + r[1] + r[2] + r[3];
@@ -813,12 +848,21 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             if (pass + 1 < NPASS) __syncthreads();
         }
     };
-    if (a.epilogue != SVR_EPI_BIAS_SILU && !a.out_f32 && a.gate == nullptr) {
-        const int F = ((resid_gate && a.resid != nullptr) ? 1 : 0) | (a.gn_partial != nullptr ? 2 : 0);
-        if (F == 0) ep_body(std::integral_constant<int, 0>{});
-        else if (F == 1) ep_body(std::integral_constant<int, 1>{});
-        else if (F == 2) ep_body(std::integral_constant<int, 2>{});
-        else ep_body(std::integral_constant<int, 3>{});
+    // (measurement builds' DBG variants: the round-2 option sets only -- they are never launched with a wide trunk)
+    if (a.epilogue != SVR_EPI_BIAS_SILU && a.gate == nullptr && (DBG == 0 || (!a.out_f32 && !a.resid_f32))) {
+        const bool wr = resid_gate && a.resid != nullptr;
+        const int F = (wr ? 1 : 0) | (a.gn_partial != nullptr ? 2 : 0) | (a.out_f32 ? 4 : 0) | (wr && a.resid_f32 ? 8 : 0);
+        switch (F) {
+#define SVR_EP_CASE(v) case v: ep_body(std::integral_constant<int, v>{}); break;
+            SVR_EP_CASE(0) SVR_EP_CASE(1) SVR_EP_CASE(2) SVR_EP_CASE(3)
+            default:
+                if constexpr (DBG == 0) switch (F) {
+                    SVR_EP_CASE(4) SVR_EP_CASE(5) SVR_EP_CASE(6) SVR_EP_CASE(7) SVR_EP_CASE(9) SVR_EP_CASE(11) SVR_EP_CASE(13) SVR_EP_CASE(15)
+                    default: break;
+                }
+                break;
+#undef SVR_EP_CASE
+        }
     } else {
         ep_body(std::integral_constant<int, -1>{});
     }
@@ -918,16 +962,27 @@ static int launch_conv_thin(const svr_gemm_args& a, hipStream_t s) { return laun
 
 static int conv_gn_blocks(const svr_gemm_args& a) {
     if (a.gn_groups > 0 && conv_sub_eligible(a)) return conv_sub_gn_blocks(a);
-    if (conv_thin_eligible(a) && !a.out_f32 && a.gn_groups > 0) {
+    if (conv_thin_eligible(a) && a.gn_groups > 0) {
         const int cpg = a.N / a.gn_groups;
         if (cpg < 4 || (cpg & 3) || a.N % a.gn_groups || 128 % cpg) return 0;
         return ((a.conv.H + 7) / 8) * ((a.conv.W + CG_TX - 1) / CG_TX);
     }
-    if ((g_conv_impl != 0 && g_conv_impl != 3) || !conv_halo_eligible(a) || (a.N % 128) != 0 || a.conv.Cin % 32 != 0 || a.out_f32) return 0;
+    if ((g_conv_impl != 0 && g_conv_impl != 3) || !conv_halo_eligible(a) || (a.N % 128) != 0 || a.conv.Cin % 32 != 0) return 0;
     const int cpg = a.gn_groups > 0 ? a.N / a.gn_groups : 0;          // channels per group: 4, 8 or 16
     if (cpg < 4 || (cpg & 3) || a.N % a.gn_groups || 128 % cpg) return 0;
     const int ty = conv_halo2_wreg(a) && g_conv_rows != 8 ? 8 : 16;
     return ((a.conv.H + ty - 1) / ty) * ((a.conv.W + CG_TX - 1) / CG_TX);
+}
+
+// stride-1 "same" 3x3 spatial kernel (1 or 3 temporal taps), plain bias / residual epilogue: the geometry of the LDS-halo kernels
+// (N <= 32: the thin-output kernel, svr_conv_thinout.hip; N % 128 == 0: conv_halo2_kernel)
+static bool conv_halo_eligible(const svr_gemm_args& a) {
+    const svr_conv_geom& g = a.conv;
+    return g.enabled && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.st == 1 && g.ph == 1 && g.pw == 1 &&
+           g.Ho == g.H && g.Wo == g.W && g.Cin % 64 == 0 && g.kt >= 1 && g.kt <= 3 &&
+           g.To == g.T + g.pt - g.kt + 1 && !a.ps.enabled && !a.phase.enabled && a.epilogue != SVR_EPI_SWIGLU &&
+           (a.N <= 32 || ((a.N % 128) == 0 && (a.ldc % 8) == 0 && (!a.resid || (a.ldr % 8) == 0))) &&
+           (int64_t)g.H * g.W * g.Cin * 2 < (int64_t)1 << 32;
 }
 
 // what conv_halo_eligible() accepts with 128-cout tiles and channels in 32-slices

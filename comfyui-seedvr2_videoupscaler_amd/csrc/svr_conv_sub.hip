@@ -298,6 +298,9 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
     const int yb = a.phase.py ? g.H - 1 : 0, xb = a.phase.px ? g.W - 1 : 0;
     const float* btab = a.phase.enabled ? a.phase.bias_border : nullptr;
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;      // fused GroupNorm statistics of the stored values (columns n .. n + 3, n + 4 .. n + 7)
+    // (the body is instantiated per output type -- bf16 | fp32 for the wide residual trunk -- so its loops carry no option branches)
+    auto ep_body = [&](auto o32c) {
+    constexpr bool O32 = decltype(o32c)::value;
 #pragma unroll
     for (int pass = 0; pass < MTW / 2; ++pass) {
         __builtin_amdgcn_sched_barrier(0);
@@ -343,11 +346,21 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
                 }
                 const float f[8] = {lo[it][0] + bl[0], lo[it][1] + bl[1], lo[it][2] + bl[2], lo[it][3] + bl[3],
                                     hi_[it][0] + bh[0], hi_[it][1] + bh[1], hi_[it][2] + bh[2], hi_[it][3] + bh[3]};
-                const uint4 pk = pack8(f);
-                if (ok[it]) *(uint4*)((bf16_t*)a.C + off[it]) = pk;
-                if (a.gn_partial != nullptr && ok[it]) {
-                    float r[8];
+                float r[8];
+                if constexpr (O32) {
+                    if (ok[it]) {
+                        float* cp = (float*)a.C + off[it];
+                        *(float4*)cp = make_float4(f[0], f[1], f[2], f[3]);
+                        *(float4*)(cp + 4) = make_float4(f[4], f[5], f[6], f[7]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = f[e];
+                } else {
+                    const uint4 pk = pack8(f);
+                    if (ok[it]) *(uint4*)((bf16_t*)a.C + off[it]) = pk;
                     unpack8(pk, r);
+                }
+                if (a.gn_partial != nullptr && ok[it]) {
                     gs0 += r[0] + r[1] + r[2] + r[3];
                     gq0 += r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
                     gs1 += r[4] + r[5] + r[6] + r[7];
@@ -357,6 +370,8 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
         }
         if (pass + 1 < MTW / 2) __syncthreads();
     }
+    };
+    if (a.out_f32) ep_body(std::true_type{}); else ep_body(std::false_type{});
     if (a.gn_partial) {
         // fixed-order reduction thread -> quad -> group (svr_conv_halo2.hip's); the (sum, sum of squares) of this patch go to
         // gn_partial[output frame][phase (py, px)][block][group]: the four phase launches of an upsampled frame fill one row of
@@ -401,7 +416,7 @@ static bool conv_sub_eligible(const svr_gemm_args& a) {
     const svr_conv_geom& g = a.conv;
     return g_conv_sub && g.enabled && a.W_frag != nullptr && g.kh == 2 && g.kw == 2 && g.sh == 1 && g.sw == 1 && g.st == 1 &&
            (unsigned)g.ph <= 1u && (unsigned)g.pw <= 1u && g.Ho == g.H && g.Wo == g.W && g.Cin % 32 == 0 && g.kt >= 1 && g.kt <= 3 &&
-           g.To == g.T + g.pt - g.kt + 1 && !a.ps.enabled && a.epilogue == SVR_EPI_BIAS && !a.out_f32 && !a.resid && !a.gate &&
+           g.To == g.T + g.pt - g.kt + 1 && !a.ps.enabled && a.epilogue == SVR_EPI_BIAS && !a.resid && !a.gate &&
            (!a.gn_partial || conv_sub_gn_ok(a)) && (a.N % 128) == 0 && (a.phase.enabled || (a.ldc == a.N)) &&
            (int64_t)g.H * g.W * g.Cin * 2 < (int64_t)1 << 32 && ((uintptr_t)a.C % 16) == 0 &&
            (!a.bias || ((uintptr_t)a.bias % 16) == 0) && (!a.phase.bias_border || ((uintptr_t)a.phase.bias_border % 16) == 0);

@@ -185,7 +185,6 @@ __global__ __launch_bounds__(CT_NT) void conv_thinout_kernel(const svr_gemm_args
     }
 }
 
-int g_conv_thinout = 1;    // 0: thin outputs on the first LDS-halo kernel's 32-cout variant (svr_set_option("conv_thinout"))
 
 static int launch_conv_thinout(const svr_gemm_args& a, hipStream_t s) {
     const svr_conv_geom& g = a.conv;

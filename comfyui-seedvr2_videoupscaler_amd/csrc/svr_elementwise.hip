@@ -15,8 +15,8 @@ constexpr int RMS_MAXC = 8;   // 16-byte chunks per lane -> dim <= 4096
 // One wave per row, rows strided over the grid so that the per-channel affine (w * scale, shift) is loaded
 // ONCE per wave into registers and reused for all its rows (a per-element reload made the first version
 // load-issue bound at 1.1 TB/s); the next row's chunks are fetched while the current one is reduced.
-template <int NC>             // chunks per lane actually used: ceil(dim / 512)
-__global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+template <int NC, bool XF32>  // chunks per lane actually used: ceil(dim / 512); XF32: x is the fp32 residual stream
+__global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const void* __restrict__ x, bf16_t* __restrict__ y,
                                                           int64_t rows, int dim, float eps,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ scale,
@@ -44,13 +44,17 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const bf16_t* __restri
             }
         }
     }
-    uint4 v[NC], nx[NC];
-    auto fetch = [&](int64_t row, uint4 (&dst)[NC]) {
-        const uint4* xp = (const uint4*)(x + row * dim);
+    struct chunk8 { float f[8]; };
+    chunk8 v[NC], nx[NC];
+    auto fetch = [&](int64_t row, chunk8 (&dst)[NC]) {
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            dst[i] = c < nchunk ? xp[c] : make_uint4(0u, 0u, 0u, 0u);
+            if (c < nchunk) load8<XF32>(x, row * dim + c * 8, dst[i].f);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[i].f[e] = 0.f;
+            }
         }
     };
     if (wave0 < rows) fetch(wave0, nx);
@@ -61,10 +65,8 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const bf16_t* __restri
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            float f[8];
-            unpack8(v[i], f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+            for (int e = 0; e < 8; ++e) ss += v[i].f[e] * v[i].f[e];
         }
         ss = wave_sum(ss);
         const float inv = rsqrtf(ss / (float)dim + eps);
@@ -74,11 +76,10 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const bf16_t* __restri
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 float f[8];
-                unpack8(v[i], f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     // same operation order as the reference: ((x * inv) * w * scale) + shift  (modulation.py:110)
-                    float t = f[e] * inv;
+                    float t = v[i].f[e] * inv;
                     f[e] = affine ? t * mul[i][e] + add[i][e] : t;
                 }
                 yp[c] = pack8(f);
@@ -206,7 +207,8 @@ __global__ void unpatchify_euler_kernel(const bf16_t* __restrict__ pred, int64_t
 constexpr int GN_ROWS_PER_BLOCK = 2048;
 
 // partial[(t * nblk + blockIdx.x) * groups + g] = {sum, sum of squares} of this block's rows
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x, double2* __restrict__ partial,
+template <bool XF32>
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const void* __restrict__ x, double2* __restrict__ partial,
                                                               int64_t HW, int C, int groups) {
     __shared__ float red[256][4];
     __shared__ double qsum[128][2];                 // per 4-channel quad (C/4 <= 128)
@@ -218,11 +220,10 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
     const int64_t r0 = (int64_t)blockIdx.x * GN_ROWS_PER_BLOCK;
     const int64_t r1 = min(r0 + GN_ROWS_PER_BLOCK, HW);
     float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-    const bf16_t* base = x + ((int64_t)t * HW) * C + cc * 8;
+    const int64_t base = ((int64_t)t * HW) * C + cc * 8;
     for (int64_t r = r0 + tid / cchunks; r < r1; r += rstep) {
-        const uint4 v = *(const uint4*)(base + r * C);
         float f[8];
-        unpack8(v, f);
+        load8<XF32>(x, base + r * C, f);
         s0 += f[0] + f[1] + f[2] + f[3];
         q0 += f[0] * f[0] + f[1] * f[1] + f[2] * f[2] + f[3] * f[3];
         s1 += f[4] + f[5] + f[6] + f[7];
@@ -277,7 +278,8 @@ __global__ __launch_bounds__(256) void groupnorm_reduce_kernel(const double2* __
     }
 }
 
-__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+template <bool XF32>
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __restrict__ x, bf16_t* __restrict__ y,
                                                               const double* __restrict__ stats,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int64_t HW, int C,
@@ -299,7 +301,9 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
     __syncthreads();
     const int cchunks = C >> 3;
     const int64_t nchunks = HW * cchunks;
-    const bf16_t* xb = x + (int64_t)t * HW * C;
+    const int64_t xo = (int64_t)t * HW * C;              // element offset of this frame
+    const bf16_t* xb = (const bf16_t*)x + xo;            // (bf16 input)
+    const float* xf = (const float*)x + xo;              // (XF32 input)
     bf16_t* yb = y + (int64_t)t * HW * C;
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
     auto act = [&](float u) { return apply_silu ? silu(u) : u; };
@@ -314,11 +318,18 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
         typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
         int64_t i = i0;
         for (; i + stride < nchunks; i += 2 * stride) {
-            const u32x4 v0 = __builtin_nontemporal_load((const u32x4*)(xb + i * 8));
-            const u32x4 v1 = __builtin_nontemporal_load((const u32x4*)(xb + (i + stride) * 8));
             float f[8], h[8];
-            unpack8(make_uint4(v0.x, v0.y, v0.z, v0.w), f);
-            unpack8(make_uint4(v1.x, v1.y, v1.z, v1.w), h);
+            if constexpr (XF32) {
+                const f32x4 a0 = __builtin_nontemporal_load((const f32x4*)(xf + i * 8)), a1 = __builtin_nontemporal_load((const f32x4*)(xf + i * 8 + 4));
+                const f32x4 b0 = __builtin_nontemporal_load((const f32x4*)(xf + (i + stride) * 8)), b1 = __builtin_nontemporal_load((const f32x4*)(xf + (i + stride) * 8 + 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { f[e] = a0[e]; f[4 + e] = a1[e]; h[e] = b0[e]; h[4 + e] = b1[e]; }
+            } else {
+                const u32x4 v0 = __builtin_nontemporal_load((const u32x4*)(xb + i * 8));
+                const u32x4 v1 = __builtin_nontemporal_load((const u32x4*)(xb + (i + stride) * 8));
+                unpack8(make_uint4(v0.x, v0.y, v0.z, v0.w), f);
+                unpack8(make_uint4(v1.x, v1.y, v1.z, v1.w), h);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { f[e] = act(f[e] * sa[e] + sb[e]); h[e] = act(h[e] * sa[e] + sb[e]); }
             const uint4 o0 = pack8(f), o1 = pack8(h);
@@ -326,9 +337,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
             __builtin_nontemporal_store(u32x4{o1.x, o1.y, o1.z, o1.w}, (u32x4*)(yb + (i + stride) * 8));
         }
         for (; i < nchunks; i += stride) {
-            const uint4 v = *(const uint4*)(xb + i * 8);
             float f[8];
-            unpack8(v, f);
+            load8<XF32>(x, xo + i * 8, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = act(f[e] * sa[e] + sb[e]);
             *(uint4*)(yb + i * 8) = pack8(f);
@@ -336,9 +346,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
     } else {
         for (int64_t i = i0; i < nchunks; i += stride) {
             const int c0 = (int)(i % cchunks) * 8;
-            const uint4 v = *(const uint4*)(xb + i * 8);
             float f[8];
-            unpack8(v, f);
+            load8<XF32>(x, xo + i * 8, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = act(f[e] * a_s[c0 + e] + b_s[c0 + e]);
             *(uint4*)(yb + i * 8) = pack8(f);

@@ -84,7 +84,11 @@ SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] *= a.gate[n + r];
         }
-        if (a.resid) {
+        if (a.resid && a.resid_f32) {
+            const float* rp = (const float*)a.resid + (int64_t)m * a.ldr + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += rp[r];
+        } else if (a.resid) {
             const bf16_t* rp = (const bf16_t*)a.resid + (int64_t)m * a.ldr + n;
             if (full) {
                 const uint2 rr = *(const uint2*)rp;
@@ -184,7 +188,8 @@ SVR_DEVICE void epilogue_store8(const svr_gemm_args& a, const float (&acc8)[8], 
         }
         if (a.resid) {
             float r8[8];
-            unpack8(*(const uint4*)((const bf16_t*)a.resid + (int64_t)m * a.ldr + n), r8);
+            if (a.resid_f32) load8<true>(a.resid, (int64_t)m * a.ldr + n, r8);
+            else load8<false>(a.resid, (int64_t)m * a.ldr + n, r8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += r8[e];
         }
@@ -452,8 +457,7 @@ static int launch(const svr_gemm_args& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-// LDS-halo conv kernel (svr_conv_halo.hip)
-template <int BN> static int launch_conv_halo(const svr_gemm_args& a, hipStream_t s);
+// LDS-halo conv kernel (svr_conv_halo2.hip)
 static bool conv_halo_eligible(const svr_gemm_args& a);
 static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s);
 static bool conv_halo2_eligible(const svr_gemm_args& a);
@@ -461,18 +465,11 @@ static bool conv_thin_eligible(const svr_gemm_args& a);
 static int launch_conv_thin(const svr_gemm_args& a, hipStream_t s);
 // thin-output conv kernel (svr_conv_thinout.hip)
 static int launch_conv_thinout(const svr_gemm_args& a, hipStream_t s);
-extern int g_conv_thinout;
 // sub-pixel upsampler conv kernel (svr_conv_sub.hip)
 static bool conv_sub_eligible(const svr_gemm_args& a);
 static int launch_conv_sub(const svr_gemm_args& a, hipStream_t s);
 static int conv_sub_gn_blocks(const svr_gemm_args& a);
-// plain GEMM with register-streamed weights (svr_gemm8.hip)
-static bool gemm8_eligible(const svr_gemm_args& a);
-static int launch_gemm8(const svr_gemm_args& a, hipStream_t s);
-static bool gemm4_eligible(const svr_gemm_args& a);
-static int launch_gemm4(const svr_gemm_args& a, hipStream_t s);
-extern int g_gemm_impl;
-int g_conv_impl = 0;   // 0 auto, 1 generic, 2 first halo kernel, 3 second halo kernel without W_frag
+int g_conv_impl = 0;   // 0 auto, 1 generic implicit-GEMM kernel everywhere, 3 LDS-halo kernel ignoring W_frag (weights through LDS)
 
 // measurement-only ablation selector of the conv kernels in -DSVR_ABLATIONS builds (svr_set_option("pipe_abl"))
 int g_pipe_abl = 0;
@@ -526,12 +523,7 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     if (conv_thin_eligible(a)) return launch_conv_thin(a, s);
     if (conv_sub_eligible(a)) return launch_conv_sub(a, s);
     if ((g_conv_impl == 0 || g_conv_impl == 3) && conv_halo2_eligible(a)) return launch_conv_halo2(a, s);
-    if (g_conv_impl != 1 && conv_halo_eligible(a))
-        return a.N <= 32 ? (g_conv_thinout ? launch_conv_thinout(a, s) : launch_conv_halo<32>(a, s)) : launch_conv_halo<128>(a, s);
-    if (g_gemm_impl != 0 && !a.conv.enabled && a.W_frag != nullptr) {
-        if (g_gemm_impl <= 2 ? gemm8_eligible(a) : gemm4_eligible(a)) return g_gemm_impl <= 2 ? launch_gemm8(a, s) : launch_gemm4(a, s);
-        if (g_gemm_impl == 2 || g_gemm_impl == 4) { *why = "svr_gemm_bf16: gemm_impl = 2 | 4 and this GEMM with W_frag does not fit the register-streamed kernel"; return -1; }
-    }
+    if (g_conv_impl != 1 && conv_halo_eligible(a) && a.N <= 32) return launch_conv_thinout(a, s);
     // 256-wide tiles when N allows it (otherwise W is padded to a multiple of 128 rows) -- unless they would leave CUs idle:
     // the VAE attention's P V product (16384 x 512 x 16384) has only 128 such tiles for 256 CUs
     const bool wide = (a.N % 256) == 0 &&

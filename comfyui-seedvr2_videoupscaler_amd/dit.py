@@ -49,7 +49,6 @@ class _Lin:
     b: Optional[torch.Tensor]
     n: int
     k: int
-    f: Optional[torch.Tensor] = None    # fragment-ordered copy of w for the GEMM kernel with register-streamed weights (ops.pack_gemm_frag)
 
 
 def timestep_sinusoid(t: float, dim: int = 256) -> torch.Tensor:
@@ -62,8 +61,11 @@ def timestep_sinusoid(t: float, dim: int = 256) -> torch.Tensor:
 
 
 class NaDiTEngine:
-    def __init__(self, cfg: DiTConfig, state_dict: Dict[str, torch.Tensor], ops):
+    def __init__(self, cfg: DiTConfig, state_dict: Dict[str, torch.Tensor], ops, hid_fp32: bool = True):
+        """``hid_fp32``: the residual stream ``hid`` is stored in fp32 (its only readers are RMSNorm and the gate+residual GEMM
+        epilogues; every MFMA operand stays bf16) -- 64 bf16 roundings of the stream per 32-layer pass disappear."""
         self.cfg, self.ops = cfg, ops
+        self.hid_dtype = torch.float32 if hid_fp32 else None        # None: the ops' activation dtype
         dev = ops.device
         self.device = dev
         d, inner = cfg.vid_dim, cfg.heads * cfg.head_dim
@@ -71,13 +73,10 @@ class NaDiTEngine:
             raise ValueError("the window-attention kernel is built for head_dim 128")
         sd = state_dict
 
-        frag = getattr(ops, "pack_gemm_frag", lambda w, n, k: None)
-
-        def lin(name, bias=True, big=False):
+        def lin(name, bias=True):
             w = sd[name + ".weight"]
             wp, kpad = pack_matrix(w, dev), (w.shape[1] + 63) // 64 * 64
-            return _Lin(wp, pack_vec(sd[name + ".bias"], dev) if bias else None, w.shape[0], kpad,
-                        frag(wp, w.shape[0], kpad) if big else None)
+            return _Lin(wp, pack_vec(sd[name + ".bias"], dev) if bias else None, w.shape[0], kpad)
 
         self.vid_in = lin("vid_in.proj")
         self.txt_in = lin("txt_in")
@@ -104,18 +103,18 @@ class NaDiTEngine:
                     blk["txt"] = blk["vid"]
                     continue
                 s = {}
-                s["qkv"] = lin(p + f"attn.proj_qkv.{b}", bias=False, big=True)
-                s["out"] = lin(p + f"attn.proj_out.{b}", big=True)
+                s["qkv"] = lin(p + f"attn.proj_qkv.{b}", bias=False)
+                s["out"] = lin(p + f"attn.proj_out.{b}")
                 s["wq"] = pack_vec(sd[p + f"attn.norm_q.{b}.weight"], dev)
                 s["wk"] = pack_vec(sd[p + f"attn.norm_k.{b}.weight"], dev)
                 if cfg.mlp_type == "normal":
-                    s["mlp_in"] = lin(p + f"mlp.{b}.proj_in", big=True)
-                    s["mlp_out"] = lin(p + f"mlp.{b}.proj_out", big=True)
+                    s["mlp_in"] = lin(p + f"mlp.{b}.proj_in")
+                    s["mlp_out"] = lin(p + f"mlp.{b}.proj_out")
                 else:
                     wg, wi = sd[p + f"mlp.{b}.proj_in_gate.weight"], sd[p + f"mlp.{b}.proj_in.weight"]
                     wsw = pack_swiglu(wg, wi, dev)
-                    s["mlp_in"] = _Lin(wsw, None, 2 * wg.shape[0], wg.shape[1], frag(wsw, 2 * wg.shape[0], wg.shape[1]))
-                    s["mlp_out"] = lin(p + f"mlp.{b}.proj_out", bias=False, big=True)
+                    s["mlp_in"] = _Lin(wsw, None, 2 * wg.shape[0], wg.shape[1])
+                    s["mlp_out"] = lin(p + f"mlp.{b}.proj_out", bias=False)
                 # AdaSingle parameters; slot = l*3 + g with l in (attn, mlp), g in (shift, scale, gate)
                 s["ada"] = {}
                 for l, lname in enumerate(("attn", "mlp")):
@@ -250,12 +249,13 @@ class NaDiTEngine:
         R = N + Lt
         eps = cfg.norm_eps
 
-        hid = ops.empty(R, d)
+        hid = ops.empty(R, d, dtype=self.hid_dtype)
+        hf = hid.dtype == torch.float32
         a0 = ops.empty(N, self.kpad_in)
         ops.patchify(vid.contiguous(), a0)
-        ops.gemm(a0, self.vid_in.w, hid[:N], N=d, K=self.kpad_in, bias=self.vid_in.b)
+        ops.gemm(a0, self.vid_in.w, hid[:N], N=d, K=self.kpad_in, bias=self.vid_in.b, out_f32=hf)
         del a0
-        ops.gemm(txt.contiguous(), self.txt_in.w, hid[N:], N=d, K=self.txt_in.k, bias=self.txt_in.b)
+        ops.gemm(txt.contiguous(), self.txt_in.w, hid[N:], N=d, K=self.txt_in.k, bias=self.txt_in.b, out_f32=hf)
 
         # ---- timestep embedding -> all AdaLN vectors of the step
         e = timestep_sinusoid(timestep).to(device=self.device, dtype=ops.act_dtype)
@@ -298,10 +298,10 @@ class NaDiTEngine:
                 ops.rmsnorm_mod(hid[N:], xn[N:], eps, scale=mod[st["ada"][("attn", "scale")]],
                                 shift=mod[st["ada"][("attn", "shift")]])
             if shared:
-                ops.gemm(xn, sv["qkv"].w, qkv, N=3 * inner, K=d, W_frag=sv["qkv"].f)
+                ops.gemm(xn, sv["qkv"].w, qkv, N=3 * inner, K=d)
             else:
-                ops.gemm(xn[:N], sv["qkv"].w, qkv[:N], N=3 * inner, K=d, W_frag=sv["qkv"].f)
-                ops.gemm(xn[N:], st["qkv"].w, qkv[N:], N=3 * inner, K=d, W_frag=st["qkv"].f)
+                ops.gemm(xn[:N], sv["qkv"].w, qkv[:N], N=3 * inner, K=d)
+                ops.gemm(xn[N:], st["qkv"].w, qkv[N:], N=3 * inner, K=d)
             ops.qknorm_rope(qkv[:N], heads, plan["pos"], 0 if rope3d else Lt, cos_t, sin_t, sv["wq"], sv["wk"], eps)
             ops.qknorm_rope(qkv[N:], heads, pos_t, 0, cos_t, sin_t, st["wq"], st["wk"], eps)
             att = ops.empty(R + n_win * Lt, inner)
@@ -310,13 +310,13 @@ class NaDiTEngine:
             g_v = mod[sv["ada"][("attn", "gate")]]
             if shared and not final:
                 ops.gemm(att[:R], sv["out"].w, hid, N=d, K=inner, bias=sv["out"].b, epilogue=EPI_RESID_GATE,
-                         gate=g_v, resid=hid, W_frag=sv["out"].f)
+                         gate=g_v, resid=hid, out_f32=hf)
             else:
                 ops.gemm(att[:N], sv["out"].w, hid[:N], N=d, K=inner, bias=sv["out"].b, epilogue=EPI_RESID_GATE,
-                         gate=g_v, resid=hid[:N], W_frag=sv["out"].f)
+                         gate=g_v, resid=hid[:N], out_f32=hf)
                 if not final:  # the text stream is dead after the last block's attention
-                    ops.gemm(att[N:R], st["out"].w, hid[N:], N=d, K=inner, bias=st["out"].b,
-                             epilogue=EPI_RESID_GATE, gate=mod[st["ada"][("attn", "gate")]], resid=hid[N:], W_frag=st["out"].f)
+                    ops.gemm(att[N:R], st["out"].w, hid[N:], N=d, K=inner, bias=st["out"].b, out_f32=hf,
+                             epilogue=EPI_RESID_GATE, gate=mod[st["ada"][("attn", "gate")]], resid=hid[N:])
             del att
 
             # ---- MLP branch (3B: SwiGLU, 7B: GELU); video only in the last block (its text output is never read)
@@ -328,19 +328,22 @@ class NaDiTEngine:
                                 shift=mod[st["ada"][("mlp", "shift")]])
             gm_v = mod[sv["ada"][("mlp", "gate")]]
 
-            def mlp(rows, s_, gate):
+            def mlp(rows, s_, gate, dst=None):
+                """``dst``: where the branch's output (residual added) goes instead of back into ``hid``."""
                 if cfg.mlp_type == "normal":
-                    ops.gemm(xn[rows], s_["mlp_in"].w, h1[rows], N=hm, K=d, bias=s_["mlp_in"].b, epilogue=EPI_BIAS_GELU,
-                             W_frag=s_["mlp_in"].f)
+                    ops.gemm(xn[rows], s_["mlp_in"].w, h1[rows], N=hm, K=d, bias=s_["mlp_in"].b, epilogue=EPI_BIAS_GELU)
                 else:
-                    ops.gemm(xn[rows], s_["mlp_in"].w, h1[rows], N=2 * hm, K=d, epilogue=EPI_SWIGLU, W_frag=s_["mlp_in"].f)
-                ops.gemm(h1[rows], s_["mlp_out"].w, hid[rows], N=d, K=hm, bias=s_["mlp_out"].b,
-                         epilogue=EPI_RESID_GATE, gate=gate, resid=hid[rows], W_frag=s_["mlp_out"].f)
+                    ops.gemm(xn[rows], s_["mlp_in"].w, h1[rows], N=2 * hm, K=d, epilogue=EPI_SWIGLU)
+                o = hid[rows] if dst is None else dst
+                ops.gemm(h1[rows], s_["mlp_out"].w, o, N=d, K=hm, bias=s_["mlp_out"].b, out_f32=o.dtype == torch.float32,
+                         epilogue=EPI_RESID_GATE, gate=gate, resid=hid[rows])
 
             if shared and not final:
                 mlp(slice(0, R), sv, gm_v)
             else:
-                mlp(slice(0, N), sv, gm_v)
+                # (no output norm -- the 7B family: vid_out reads the stream as an MFMA operand, so the last block leaves it in
+                # the activation dtype)
+                mlp(slice(0, N), sv, gm_v, dst=xn[:N] if final and not cfg.out_norm and hf else None)
                 if not final:
                     mlp(slice(N, R), st, mod[st["ada"][("mlp", "gate")]])
 
@@ -351,7 +354,7 @@ class NaDiTEngine:
                             shift=mod[self.ada_out_shift])
             ops.gemm(xn[:N], self.vid_out.w, pred, N=cfg.patch_out_dim, K=d, bias=self.vid_out.b)
         else:
-            ops.gemm(hid[:N], self.vid_out.w, pred, N=cfg.patch_out_dim, K=d, bias=self.vid_out.b)
+            ops.gemm(xn[:N] if hf else hid[:N], self.vid_out.w, pred, N=cfg.patch_out_dim, K=d, bias=self.vid_out.b)
         out = ops.empty(T, H, W, cfg.vid_out_channels)
         ops.unpatchify_euler(pred, None if x_t is None else x_t.contiguous(), out)
         return out

@@ -18,6 +18,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                "-mllvm", "-pragma-unroll-threshold=1000000"]
 
 EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU, EPI_BIAS_GELU = 0, 1, 2, 3, 4
+ABI_VERSION = 5
 
 
 class ConvGeom(C.Structure):
@@ -52,7 +53,8 @@ class GemmArgs(C.Structure):
                 ("conv", ConvGeom), ("ps", PixelShuffle),
                 ("gn_partial", C.c_void_p), ("gn_groups", C.c_int32),
                 ("W_frag", C.c_void_p),
-                ("phase", PhaseScatter)]
+                ("phase", PhaseScatter),
+                ("resid_f32", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/seedvr2_hip.h
@@ -63,7 +65,7 @@ SYMBOLS = {
     "svr_conv_pack_frag_taps": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "svr_gemm_gn_blocks": (C.c_int32, [C.POINTER(GemmArgs)]),
     "svr_groupnorm_reduce": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
-    "svr_rmsnorm_mod": (C.c_int, [_vp, _vp, _i64, _i32, _f, _vp, _vp, _vp, _vp]),
+    "svr_rmsnorm_mod": (C.c_int, [_vp, _vp, _i64, _i32, _f, _vp, _vp, _vp, _i32, _vp]),
     "svr_ada_combine": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "svr_qknorm_rope": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _f, _vp]),
     "svr_attn_varlen": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f, _vp]),
@@ -72,8 +74,8 @@ SYMBOLS = {
     "svr_patchify": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "svr_unpatchify_euler": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "svr_groupnorm_workspace_bytes": (C.c_int64, [_i32, _i64, _i32]),
-    "svr_groupnorm_stats": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
-    "svr_groupnorm_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _i32, _vp]),
+    "svr_groupnorm_stats": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "svr_groupnorm_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _i32, _i32, _vp]),
     "svr_im2col_causal": (C.c_int, [_vp, _vp, C.POINTER(ConvGeom), _i32, _vp]),
     "svr_blend_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "svr_blend_finalize": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _f, _vp]),
@@ -138,7 +140,7 @@ def lib():
         except AttributeError as e:
             raise HipLibraryError(f"{LIB_PATH} does not export {name} (stale build?)") from e
         fn.restype, fn.argtypes = res, args
-    if handle.svr_abi_version() != 4:
+    if handle.svr_abi_version() != ABI_VERSION:
         raise HipLibraryError("libseedvr2_hip.so ABI version mismatch; rebuild")
     # measurement knobs from the environment, e.g. SVR_OPTIONS="conv_rows=8,gemm_epi=1" (svr_set_option keys; an unknown key
     # or a malformed item is an error, not a silently ignored setting)

@@ -109,19 +109,6 @@ class HipOps:
                       "svr_conv_pack_frag_taps")
         return out
 
-    def pack_gemm_frag(self, W, N: int, K: int):
-        """Fragment-ordered copy of a packed nn.Linear weight W [Npad, K] for gemm(..., W_frag=) on plain GEMMs: the kernel with
-        register-streamed weights (svr_gemm8.hip; N % 256 == 0 -- N % 128 == 0 for its two-workgroups-per-CU form, gemm_impl 3 | 4 --,
-        K % 128 == 0, K >= 256).  None when that kernel is switched off
-        (svr_set_option("gemm_impl", 0), the default) or cannot serve the shape -- the copy doubles the weight's memory."""
-        impl = hip_lib.OPTIONS.get("gemm_impl", 0)
-        if not impl or N % (256 if impl <= 2 else 128) or K % 128 or K < 256 or W.shape[1] != K or W.shape[0] < N:
-            return None
-        self._chk(W, BF16, "W")
-        out = torch.empty(N * K, dtype=BF16, device=self.device)
-        hip_lib.check(self.lib.svr_conv_pack_frag_taps(_ptr(W), _ptr(out), N, K, 1, 1, 1, K, self._stream()), "svr_conv_pack_frag_taps")
-        return out
-
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
              out_f32=False, conv: Optional[Conv3dGeom] = None, ps: Optional[PixelShuffleGeom] = None,
              lda=None, ldc=None, ldr=None, gn_groups: int = 0, W_frag=None, phase: Optional[PhaseScatter] = None,
@@ -185,8 +172,11 @@ class HipOps:
         if gate is not None:
             a.gate = self._chk(gate, torch.float32, "gate").data_ptr()
         if resid is not None:
-            self._chk(resid, BF16, "resid")
+            if resid.dtype not in (BF16, torch.float32):
+                raise ValueError(f"resid must be bf16 or fp32, got {resid.dtype}")
+            self._chk(resid, None, "resid")
             a.resid = resid.data_ptr()
+            a.resid_f32 = int(resid.dtype == torch.float32)
             a.ldr = ldr if ldr is not None else (resid.stride(0) if resid.dim() == 2 else N)
         a.epilogue, a.out_f32 = epilogue, int(out_f32)
         if W_frag is not None:
@@ -233,10 +223,17 @@ class HipOps:
         return stats
 
     # ------------------------------------------------------------------ DiT side kernels
+    def _xf32(self, x, name="x"):
+        """activation inputs that may come from the wide (fp32) residual trunk: -> 1 if fp32, 0 if bf16"""
+        if x.dtype not in (BF16, torch.float32):
+            raise ValueError(f"{name} must be bf16 or fp32, got {x.dtype}")
+        self._chk(x, None, name)
+        return int(x.dtype == torch.float32)
+
     def rmsnorm_mod(self, x, out, eps, w=None, scale=None, shift=None):
-        self._chk(x, BF16, "x"); self._chk(out, BF16, "out")
+        xf = self._xf32(x); self._chk(out, BF16, "out")
         rows, dim = x.shape
-        hip_lib.check(self.lib.svr_rmsnorm_mod(_ptr(x), _ptr(out), rows, dim, eps, _ptr(w), _ptr(scale), _ptr(shift),
+        hip_lib.check(self.lib.svr_rmsnorm_mod(_ptr(x), _ptr(out), rows, dim, eps, _ptr(w), _ptr(scale), _ptr(shift), xf,
                                                self._stream()), "svr_rmsnorm_mod")
         return out
 
@@ -301,19 +298,19 @@ class HipOps:
 
     # ------------------------------------------------------------------ VAE side kernels
     def groupnorm_stats(self, x, stats, groups):
-        self._chk(x, BF16, "x"); self._chk(stats, torch.float64, "stats")
+        xf = self._xf32(x); self._chk(stats, torch.float64, "stats")
         T, H, W, Cc = x.shape
         ws = torch.empty(int(self.lib.svr_groupnorm_workspace_bytes(T, H * W, groups)), dtype=torch.uint8,
                          device=self.device)
-        hip_lib.check(self.lib.svr_groupnorm_stats(_ptr(x), _ptr(stats), _ptr(ws), T, H * W, Cc, groups,
+        hip_lib.check(self.lib.svr_groupnorm_stats(_ptr(x), _ptr(stats), _ptr(ws), T, H * W, Cc, groups, xf,
                                                    self._stream()), "svr_groupnorm_stats")
         return stats
 
     def groupnorm_apply(self, x, out, stats, gamma, beta, groups, eps, silu):
-        self._chk(x, BF16, "x"); self._chk(out, BF16, "out")
+        xf = self._xf32(x); self._chk(out, BF16, "out")
         T, H, W, Cc = x.shape
         hip_lib.check(self.lib.svr_groupnorm_apply(_ptr(x), _ptr(out), _ptr(stats), _ptr(gamma), _ptr(beta), T, H * W,
-                                                   Cc, groups, eps, int(silu), self._stream()), "svr_groupnorm_apply")
+                                                   Cc, groups, eps, int(silu), xf, self._stream()), "svr_groupnorm_apply")
         return out
 
     def im2col_causal(self, x, out, conv: Conv3dGeom):

@@ -118,7 +118,8 @@ def _cos_ramp(n: int) -> Optional[torch.Tensor]:
 
 class VideoVAEEngine:
     def __init__(self, cfg: VAEConfig, state_dict: Dict[str, torch.Tensor], ops,
-                 act_budget_bytes: int = 12 << 30, merge_upsamplers: bool = True, merge_causal_head: bool = True):
+                 act_budget_bytes: int = 12 << 30, merge_upsamplers: bool = True, merge_causal_head: bool = True,
+                 trunk_fp32: bool = True, branch_fp32: bool = True):
         """``merge_upsamplers``: run the spatial-only upsampler (upscale_conv + pixel shuffle + 3x3x3 conv) as four sub-pixel
         convs over its low-resolution input (subpixel.py) -- same function, 12 instead of 28 MACs per output voxel and channel
         pair, no upsampled intermediate; False keeps the reference's two steps.
@@ -126,8 +127,17 @@ class VideoVAEEngine:
         (extend_head, causal_inflation_lib.py:422-437), so it is computed as (W0+W1+W2) * x[0] with the sum held as two bf16
         terms (hi + lo, exact to 2^-17): 18 instead of 27 MACs per voxel and channel pair, same result.  (Rounding the sum
         to ONE bf16 term -- and merging frame 1's two replicated taps the same way -- would save three times as much but costs
-        0.4-0.8 dB against the fp32 reference: measured, not shipped.)  False keeps three taps on every frame."""
+        0.4-0.8 dB against the fp32 reference: measured, not shipped.)  False keeps three taps on every frame.
+        ``trunk_fp32``: the residual trunk (ResnetBlock3D / attention outputs, attn_video_vae.py:311-362, 615-665) is stored in
+        fp32 wherever its only readers are GroupNorm and the next residual add; it is stored bf16 only where a conv reads it
+        directly as an MFMA operand (in front of a down/upsampler or a shortcut conv): 5 instead of 17 bf16 roundings on the
+        decoder's skip path, +2.6 dB against the fp32 reference (tools/error_budget.py) for ~1.5 x the bytes of the
+        GroupNorm-apply reads and the conv2 epilogue stores.  False keeps every activation in the ops' storage dtype.
+        ``branch_fp32`` (with ``trunk_fp32``): conv1's output inside a block -- read only by norm2 -- is stored fp32 as well, so a
+        block rounds to bf16 exactly where an MFMA consumes the value (the two GroupNorm-apply outputs): +1.3 dB more."""
         self.cfg, self.ops = cfg, ops
+        self.trunk_dtype = torch.float32 if trunk_fp32 else None      # None: the ops' activation dtype
+        self.branch_wide = bool(trunk_fp32 and branch_fp32)
         self.device = ops.device
         self.act_budget_bytes = act_budget_bytes
         sd, dev = state_dict, ops.device
@@ -273,14 +283,16 @@ class VideoVAEEngine:
 
     # ------------------------------------------------------------------ layer primitives
     def _conv(self, cw: _Conv, x: torch.Tensor, st: dict, first: bool, resid: Optional[torch.Tensor] = None,
-              gn: bool = False):
+              gn: bool = False, wide: bool = False):
         """Causal conv of one temporal slice.  ``gn=True``: also return the per-frame GroupNorm statistics of the
-        output when the conv kernel can fuse them into its epilogue (else None) -> ``(out, stats)``."""
+        output when the conv kernel can fuse them into its epilogue (else None) -> ``(out, stats)``.
+        ``wide``: store the output in the trunk dtype (fp32 under ``trunk_fp32``) instead of the activation dtype."""
         ops = self.ops
+        odt = self.trunk_dtype if wide else None
         T, H, W, Cin = x.shape
         assert Cin == cw.cin, (cw.name, Cin, cw.cin)
         if first and cw.head is not None:
-            return self._conv_causal_head(cw, x, st, resid, gn)
+            return self._conv_causal_head(cw, x, st, resid, gn, odt)
         kt, kh, kw = cw.k
         sT, sH, sW = cw.stride
         carry = kt - sT                                     # frames handed to the next temporal slice
@@ -295,7 +307,8 @@ class VideoVAEEngine:
         geom = Conv3dGeom(T, H, W, Cin, To, Ho, Wo, cw.k, cw.stride, (pt, cw.pad_lo, cw.pad_lo), halo)
         if resid is not None and tuple(resid.shape) != (To, Ho, Wo, cw.cout):
             raise ValueError(f"{cw.name}: residual {tuple(resid.shape)} does not match the output {(To, Ho, Wo, cw.cout)}")
-        out = ops.empty(To, Ho, Wo, cw.cout)
+        out = ops.empty(To, Ho, Wo, cw.cout, dtype=odt)
+        f32 = out.dtype == torch.float32
         K = cw.w.shape[1]
         epi = EPI_RESID_GATE if resid is not None else EPI_BIAS
         stats = None
@@ -305,13 +318,13 @@ class VideoVAEEngine:
             cols = ops.empty(To * Ho * Wo, K)
             ops.im2col_causal(x, cols, geom)
             ops.gemm(cols, cw.w, out, N=cw.cout, K=K, M=To * Ho * Wo, bias=cw.b, epilogue=epi, resid=resid,
-                     lda=K, ldc=cw.cout, ldr=cw.cout)
+                     lda=K, ldc=cw.cout, ldr=cw.cout, out_f32=f32)
         else:
             # implicit-GEMM conv; RGB input (encoder conv_in, Cin 3 -> 4) is served by the thin-input variant of the
             # LDS-halo kernel, which builds the im2col image of each patch in LDS
             r = ops.gemm(x, cw.w, out, N=cw.cout, K=K, bias=cw.b, epilogue=epi, resid=resid, conv=geom,
                          ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups if gn else 0,
-                         W_frag=None if cw.thin else cw.w_frag)
+                         W_frag=None if cw.thin else cw.w_frag, out_f32=f32)
             stats = r[1] if gn else None
         if carry > 0 and not st.get("__last_slice__", False):   # per-conv memory for the next slice (none follows the last one)
             if T >= carry:
@@ -321,14 +334,14 @@ class VideoVAEEngine:
                 st[cw.name] = torch.cat([prev, x], dim=0)[-carry:].contiguous()
         return (out, stats) if gn else out
 
-    def _conv_causal_head(self, cw: _Conv, x, st, resid, gn):
+    def _conv_causal_head(self, cw: _Conv, x, st, resid, gn, odt=None):
         """First slice of a clip through a kt = 3 stride-1 conv: output frame 0 = (hi + lo) * x[0] with hi + lo = W0+W1+W2
         (two taps on the replicated frame instead of three), frames 1.. = the plain conv over x with one replicated frame.
         Same outputs, per-frame statistics and carried state as one launch with two replicated frames."""
         T, H, W, _ = x.shape
         if resid is not None and tuple(resid.shape) != (T, H, W, cw.cout):
             raise ValueError(f"{cw.name}: residual {tuple(resid.shape)} does not match the output {(T, H, W, cw.cout)}")
-        out = self.ops.empty(T, H, W, cw.cout)
+        out = self.ops.empty(T, H, W, cw.cout, dtype=odt)
         stats = []
         for sub, n_in, o in ((cw.head, 1, 0), (cw, T, 1)):       # (weights, input frames 0..n_in-1, first output frame)
             To = n_in + 1 - sub.k[0] + 1
@@ -338,7 +351,8 @@ class VideoVAEEngine:
             r = resid[o:o + To] if resid is not None else None
             res = self.ops.gemm(x[:n_in], sub.w, out[o:o + To], N=cw.cout, K=sub.w.shape[1], bias=cw.b,
                                 epilogue=EPI_RESID_GATE if r is not None else EPI_BIAS, resid=r, conv=geom,
-                                ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups if gn else 0, W_frag=sub.w_frag)
+                                ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups if gn else 0, W_frag=sub.w_frag,
+                                out_f32=out.dtype == torch.float32)
             if gn:
                 stats.append(res[1])
         if not st.get("__last_slice__", False):
@@ -358,13 +372,18 @@ class VideoVAEEngine:
         ops.groupnorm_apply(x, out, stats, nm.gamma, nm.beta, cfg.norm_num_groups, cfg.norm_eps, silu)
         return out
 
-    def _resnet(self, rb: _Resnet, x, st, first, x_stats=None):
-        """-> (out, GroupNorm statistics of out or None).  ``x_stats``: statistics of ``x`` if its producer fused them."""
+    def _resnet(self, rb: _Resnet, x, st, first, x_stats=None, wide=True):
+        """-> (out, GroupNorm statistics of out or None).  ``x_stats``: statistics of ``x`` if its producer fused them.
+        ``wide``: the output stays on the residual trunk (only GroupNorm and the next residual add read it) -> trunk dtype;
+        False: a conv reads it as an MFMA operand -> activation dtype."""
         h = self._gn(rb.norm1, x, True, x_stats)
-        h, hs = self._conv(rb.conv1, h, st, first, gn=True)
+        h, hs = self._conv(rb.conv1, h, st, first, gn=True, wide=self.branch_wide)
         h = self._gn(rb.norm2, h, True, hs)
+        if rb.shortcut is not None and x.dtype != self.ops.act_dtype:
+            raise RuntimeError(f"{rb.shortcut.name}: a shortcut conv reads its block input as an MFMA operand; the producer must store it "
+                               f"in the activation dtype, got {x.dtype}")
         sc = self._conv(rb.shortcut, x, st, first) if rb.shortcut is not None else x
-        return self._conv(rb.conv2, h, st, first, resid=sc, gn=True)
+        return self._conv(rb.conv2, h, st, first, resid=sc, gn=True, wide=wide)
 
     def _attention(self, ab: _Attn, x):
         """Per-frame spatial self-attention of the mid block (1 head x C=512 over n = H*W tokens).
@@ -376,7 +395,7 @@ class VideoVAEEngine:
         T, H, W, Cc = x.shape
         n = H * W
         y = self._gn(ab.norm, x, False)
-        out = ops.empty(T, H, W, Cc)
+        out = ops.empty(T, H, W, Cc, dtype=self.trunk_dtype)
         if self.attn_as_gemm and n <= 16384 and n % 64 == 0:
             npad = (n + 255) // 256 * 256
             q, v = ops.empty(T * n, Cc), ops.empty(T * n, Cc)
@@ -403,28 +422,28 @@ class VideoVAEEngine:
             att = ops.empty(T * n, Cc)
             ops.attn_varlen(qkv, att, rows, rows, cu, n, 1, Cc, 1.0 / math.sqrt(Cc))
         ops.gemm(att, ab.out_w, out, N=Cc, K=Cc, M=T * n, bias=ab.out_b, epilogue=EPI_RESID_GATE,
-                 resid=x, ldc=Cc, ldr=Cc)
+                 resid=x, ldc=Cc, ldr=Cc, out_f32=out.dtype == torch.float32)
         return out
 
-    def _mid(self, m, x, st, first, x_stats=None):
+    def _mid(self, m, x, st, first, x_stats=None, wide=True):
         x, _ = self._resnet(m[0], x, st, first, x_stats)
         x = self._attention(m[1], x)
-        return self._resnet(m[2], x, st, first)
+        return self._resnet(m[2], x, st, first, wide=wide)
 
-    def _upsample(self, up: _Up, x, st, first):
+    def _upsample(self, up: _Up, x, st, first, wide=False):
         ops = self.ops
         T, H, W, Cc = x.shape
         if up.merged is not None:
-            return self._upsample_subpixel(up, x, st, first)
+            return self._upsample_subpixel(up, x, st, first, wide)
         rz = 2 if up.temporal else 1
         drop = up.temporal and first                       # remove_head on the first slice only
         To = T * rz - (1 if drop else 0)
         y = ops.empty(To, 2 * H, 2 * W, Cc)
         ops.gemm(x.reshape(T * H * W, Cc), up.upscale_w, y, N=4 * rz * Cc, K=Cc, M=T * H * W, bias=up.upscale_b,
                  ps=PixelShuffleGeom(T, H, W, rz, Cc, drop))
-        return self._conv(up.conv, y, st, first, gn=True)
+        return self._conv(up.conv, y, st, first, gn=True, wide=wide)
 
-    def _upsample_subpixel(self, up: _Up, x, st, first):
+    def _upsample_subpixel(self, up: _Up, x, st, first, wide=False):
         """Upsampler as (kt', 2, 2)-tap convs over the low-resolution input, one launch per output phase, each scattering
         into its positions of the upsampled tensor (subpixel.py).  The causal memory of the reference's conv (the last frames
         of its upsampled input) becomes the last frame(s) of the LOW-resolution input, and the tap pattern of an output
@@ -441,7 +460,8 @@ class VideoVAEEngine:
             raise RuntimeError(f"{cw.name}: missing temporal state for a non-initial slice")
         carry = kt - 1 if rz == 1 else 1                   # low-resolution frames the next slice needs
         outs = [subpixel.output_frames(t0 + tl, rz) for tl in range(T)]
-        y = ops.empty(sum(len(o) for o in outs), 2 * H, 2 * W, cw.cout)
+        y = ops.empty(sum(len(o) for o in outs), 2 * H, 2 * W, cw.cout, dtype=self.trunk_dtype if wide else None)
+        f32 = y.dtype == torch.float32
         # GroupNorm statistics of y fused into the launches' epilogues where the ops offer it (one partial buffer for all of them)
         shared = {"frames": y.shape[0]} if hasattr(ops, "gn_shared_stats") else None
 
@@ -465,7 +485,7 @@ class VideoVAEEngine:
                     shared["frame0"] = base
                     kw = dict(gn_groups=self.cfg.norm_num_groups, gn_shared=shared)
                 ops.gemm(geom_in, w, y[base:], N=cw.cout, K=w.shape[1], bias=bias, conv=geom,
-                         phase=PhaseScatter(py, px, bb, t_stride), W_frag=frag, **kw)
+                         phase=PhaseScatter(py, px, bb, t_stride), W_frag=frag, out_f32=f32, **kw)
 
         if rz == 1:
             launch(subpixel.signature(kt - 1, 1, kt), 0, T, 0, 1)
@@ -496,25 +516,30 @@ class VideoVAEEngine:
 
     # ------------------------------------------------------------------ one temporal slice through a network
     # (hs = GroupNorm statistics of h when the conv that produced h fused them into its epilogue, else None)
+    # Trunk storage rule (trunk_fp32): a tensor on the skip path is wide (fp32) unless a conv reads it as an MFMA operand -- the
+    # input of a down/upsampler, or of a block with a shortcut conv.
     def _encoder_slice(self, x, st, first):
-        h, hs = self._conv(self.enc_conv_in, x, st, first, gn=True)
-        for res, down in self.enc_down:
-            for rb in res:
-                h, hs = self._resnet(rb, h, st, first, hs)
+        levels = self.enc_down
+        feeds_shortcut = lambda i: i < len(levels) and levels[i][0][0].shortcut is not None
+        h, hs = self._conv(self.enc_conv_in, x, st, first, gn=True, wide=not feeds_shortcut(0))
+        for i, (res, down) in enumerate(levels):
+            for j, rb in enumerate(res):
+                h, hs = self._resnet(rb, h, st, first, hs, wide=not (down is not None and j == len(res) - 1))
             if down is not None:
-                h, hs = self._conv(down, h, st, first, gn=True)
+                h, hs = self._conv(down, h, st, first, gn=True, wide=not feeds_shortcut(i + 1))
         h, hs = self._mid(self.enc_mid, h, st, first, hs)
         h = self._gn(self.enc_norm_out, h, True, hs)
         return self._conv(self.enc_conv_out, h, st, first)
 
     def _decoder_slice(self, z, st, first):
-        h, hs = self._conv(self.dec_conv_in, z, st, first, gn=True)
-        h, hs = self._mid(self.dec_mid, h, st, first, hs)
-        for i, (res, up) in enumerate(self.dec_up):
-            for rb in res:
-                h, hs = self._resnet(rb, h, st, first, hs)
+        h, hs = self._conv(self.dec_conv_in, z, st, first, gn=True, wide=True)
+        levels = self.dec_up
+        h, hs = self._mid(self.dec_mid, h, st, first, hs, wide=levels[0][0][0].shortcut is None)
+        for i, (res, up) in enumerate(levels):
+            for j, rb in enumerate(res):
+                h, hs = self._resnet(rb, h, st, first, hs, wide=not (up is not None and j == len(res) - 1))
             if up is not None:
-                h, hs = self._upsample(up, h, st, first)
+                h, hs = self._upsample(up, h, st, first, wide=levels[i + 1][0][0].shortcut is None)
                 if i == self.cfg.temporal_scale_num - 1 and st.get("__keep__") is not None:
                     # full frame rate from here on, every layer causal in time: frames the caller will trim are not computed
                     # (only the clip's last slice can be cut: decode() already dropped the latent frames nobody needs)

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SVR_ABI_VERSION 4
+#define SVR_ABI_VERSION 5
 
 /* ---- GEMM / implicit-GEMM convolution epilogues ------------------------------------------ */
 #define SVR_EPI_BIAS        0   /* C = acc + bias                                              */
@@ -91,12 +91,12 @@ typedef struct svr_gemm_args {
     int32_t gn_groups;
     /* Optional (conv mode, 3x3 spatial taps, stride 1, Cin % 32 == 0, N % 128 == 0): the same weights in
      * MFMA-fragment order as written by svr_conv_pack_frag().  When set, the LDS-halo conv kernel streams the
-     * weights from this copy straight into registers instead of staging W through LDS.  NULL: off.
-     * Plain GEMMs (no conv): the copy written by svr_conv_pack_frag_taps(W, out, N, K, 1, 1, 1, K) lets the GEMM
-     * kernel with register-streamed weights serve the problem when svr_set_option("gemm_impl", 1 | 2) is on
-     * (N % 256 == 0, K % 128 == 0, K >= 256, bf16 output, no pixel shuffle); ignored otherwise.           */
+     * weights from this copy straight into registers instead of staging W through LDS.  NULL: off; ignored by plain GEMMs. */
     const void* W_frag;
-    svr_phase_scatter phase;            /* conv mode only; not together with ps / SWIGLU / gn_partial / resid           */
+    svr_phase_scatter phase;            /* conv mode only; not together with ps / SWIGLU / resid                        */
+    int32_t resid_f32;                  /* 1: `resid` is fp32 [M, N] (ldr in elements).  Wide residual trunk (ABI v5): with out_f32
+                                           the skip path of ResnetBlock3D (attn_video_vae.py:311-362) / the NaDiT residual stream
+                                           (mmsr_block.py:108-126) is carried in fp32 and only MFMA operands are rounded to bf16 */
 } svr_gemm_args;
 
 /* W [N, K = kt * 9 * Cin] (conv weight rows, K order (dt, dy, dx, c)) -> out (same byte size, N * K bf16) in the
@@ -120,9 +120,9 @@ int svr_gemm_bf16(const svr_gemm_args* args, void* stream);
 
 /* ---- DiT elementwise / normalisation ------------------------------------------------------- */
 /* y = rms_norm(x) [* w] * scale + shift, per row.  normalization.py:88-109 + modulation.py:110.
- * x,y bf16 [rows, dim]; w (affine weight) / scale / shift fp32 [dim] or NULL.                  */
+ * x bf16 (fp32 if x_f32: the wide residual stream) [rows, dim], y bf16; w (affine weight) / scale / shift fp32 [dim] or NULL. */
 int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps,
-                    const float* w, const float* scale, const float* shift, void* stream);
+                    const float* w, const float* scale, const float* shift, int32_t x_f32, void* stream);
 
 /* mod[l][i] = emb[i*stride + off(l)] + param[l][i]: builds the fused AdaSingle vectors
  * (scaleA+scaleB, shiftA+shiftB, gateA+gateB).  modulation.py:76,88-113.
@@ -164,19 +164,19 @@ int svr_unpatchify_euler(const void* pred, int64_t ldp, const void* x_t, void* o
 
 /* ---- VAE elementwise ------------------------------------------------------------------------- */
 /* Per-frame GroupNorm statistics over NDHWC.  causal_inflation_lib.py:366-408.
- * x bf16 [T, HW, C]; stats fp64 [T, groups, 2] (sum, sumsq), fully overwritten.  Reductions run in a
+ * x bf16 (fp32 if x_f32) [T, HW, C]; stats fp64 [T, groups, 2] (sum, sumsq), fully overwritten.  Reductions run in a
  * fixed order (no atomics): bit-reproducible, independent of temporal slicing.  `workspace` is a
  * caller-provided scratch of svr_groupnorm_workspace_bytes(T, HW, groups) bytes.                    */
 int64_t svr_groupnorm_workspace_bytes(int32_t T, int64_t HW, int32_t groups);
 int svr_groupnorm_stats(const void* x, double* stats, void* workspace, int32_t T, int64_t HW, int32_t C,
-                        int32_t groups, void* stream);
+                        int32_t groups, int32_t x_f32, void* stream);
 /* stats[t][g] = fixed-order sum over the `nblk` block partials [T][nblk][groups] (fp64 pairs) written by
  * svr_groupnorm_stats' first stage or by a conv launch with gn_partial set.                           */
 int svr_groupnorm_reduce(const void* partial, double* stats, int32_t T, int32_t nblk, int32_t groups, void* stream);
-/* y = [silu](gamma * (x - mean) * rstd + beta).  attn_video_vae.py:316-323,343-350.               */
+/* y = [silu](gamma * (x - mean) * rstd + beta); x bf16 (fp32 if x_f32), y bf16.  attn_video_vae.py:316-323,343-350. */
 int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float* gamma, const float* beta,
                         int32_t T, int64_t HW, int32_t C, int32_t groups, float eps, int32_t apply_silu,
-                        void* stream);
+                        int32_t x_f32, void* stream);
 /* P[r, :] = softmax(scale * S[r, :]): fp32 scores [rows, cols] (ld_s) -> bf16 probabilities (ld_p); cols <= 16384.
  * The softmax of the VAE mid-block attention (diffusers Attention, 1 head x 512; attn_video_vae.py:659-665) when it is
  * run as two MFMA GEMMs around a materialised score matrix.                                            */
@@ -199,16 +199,13 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
 /* ---- misc ------------------------------------------------------------------------------------ */
 /* Tuning / measurement knobs (no effect on results):
  * "conv_impl" 0 auto (LDS-halo kernels for stride-1 3x3 convs; register-streamed weights when W_frag is given)
- * | 1 generic implicit GEMM everywhere | 2 first (8x32-patch) halo kernel | 3 second halo kernel ignoring W_frag,
+ * | 1 generic implicit GEMM everywhere | 3 LDS-halo kernel ignoring W_frag (weights through LDS),
  * "conv_rows" patch rows per wave of the register-streamed conv kernel: 8 (default: 256 accumulators, one wave per SIMD) | 4
  * (two workgroups per CU),
  * "conv_band" tile rows per band of the conv kernel's frame-inner tile order (default 1; 0: frame outermost),
- * "conv_thinout" 1 (default) N <= 32 convs on the step-interval thin-output kernel | 0 on the first halo kernel's 32-cout variant,
  * "conv_sub" 1 (default) (kt, 2, 2)-tap convs with W_frag run on the sub-pixel conv kernel | 0 on the generic kernel,
  * "conv_lds" dynamic LDS bytes to request for the halo kernel (> 80 KiB forces one workgroup per CU),
  * "gemm_epi" epilogue of the GEMM kernel: 0 auto | 1 stores straight from the accumulators | 2 through LDS wherever possible,
- * "gemm_impl" 0 (default) every plain GEMM on the LDS-staged kernel | 1 plain GEMMs that bring W_frag and fit it on the kernel
- * with register-streamed weights (svr_gemm8.hip) | 2 as 1, and a plain GEMM with W_frag that does not fit is an error,
  * "attn_impl" 0 auto (second-generation window kernel for head_dim 128 / windows <= 2048 rows) | 1 first kernel everywhere,
  * "attn_variant" build variant of the second-generation window kernel (0 default = 8 waves; 1 / 3 / 4: see svr_attn_win.hip),
  * "pipe_abl" measurement-only ablations in -DSVR_ABLATIONS builds (non-zero values give garbage). */

@@ -24,6 +24,14 @@ stored -- tests rebuild them with the seeded helpers below, which use only exact
                       and a 2-frame overlap blend, LAB colour fix; the reference's own NaDiT (DIT_TINY width) and VAE
                       (4 x 128 channels) classes plus the reference's text of pad_video_temporal / SideResize /
                       DivisiblePad / blend_overlapping_frames / lab_color_transfer, driven by oracle/pipeline_oracle.py
+Round-3 fixtures (``--only r3-dit32`` / ``r3-dit7b`` / ``r3-refbf16``):
+  dit3b_32l_crop.pt   the FULL-DEPTH SeedVR2-3B (32 layers, 2560 wide) on the same cropped config-3 grid 9x30x54 tokens
+                      (48 ragged windows per layer pair); fp32 reference output
+  dit7b_w2l_crop.pt   SeedVR2-7B at PRODUCTION WIDTH (3072, 24 heads, 60 rotated dims, biased GELU MLP of 12288), 2 layers,
+                      on a 5x30x54-token crop (regular + shifted windows); fp32 reference output
+  refbf16.pt          what the REFERENCE ITSELF produces in bf16 (model.to(bfloat16), bf16 inputs: its production dtype) on the
+                      inputs of dit3b_w4l_crop / vae_tiled17 / pipeline_small -- the yardstick "engine error <= reference-bf16
+                      error" of tests/test_gpu_parity.py (stored as bf16 tensors)
 """
 import argparse
 import importlib
@@ -74,21 +82,31 @@ def latent_input(T, H, W, seed):
 CROPS_1024 = [(0, 0), (0, 1056), (928, 0), (464, 832), (464, 960), (100, 896), (928, 1056), (512, 300)]   # (y, x) of 96x96 crops; x 896..1024 is the blend seam
 
 
-def run_reference_dit(rl, cfg, sd, vid, txt):
-    ref = rl.build_reference_dit(cfg.as_dict(), {k: v.float() for k, v in sd.items()})
+def run_reference_dit(rl, cfg, sd, vid, txt, dtype=torch.float32):
+    """``dtype`` bfloat16: the reference's production regime (weights, activations and inputs in bf16)."""
+    ref = rl.build_reference_dit(cfg.as_dict(), {k: v.to(dtype) for k, v in sd.items()})
     T, H, W, C = vid.shape
     with torch.no_grad():
-        out = ref(vid=vid.float().reshape(-1, C), txt=txt.float(),
+        out = ref(vid=vid.to(dtype).reshape(-1, C), txt=txt.to(dtype),
                   vid_shape=torch.tensor([[T, H, W]]), txt_shape=torch.tensor([[txt.shape[0]]]),
                   timestep=torch.tensor([1000.0])).vid_sample
     return out.reshape(T, H, W, -1).contiguous()
 
 
+def dit7b_r3_config(config):
+    """7B production width, 2 layers (regular + shifted windows)."""
+    import dataclasses
+    return dataclasses.replace(config.DIT_7B, num_layers=2, mm_layers=2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-3b", action="store_true")
-    ap.add_argument("--only", default="", help="'r2': only the round-2 fixtures; 'r2-dit' / 'r2-vae17' / 'r2-vae1024': one of them")
+    ap.add_argument("--only", default="", help="'r2': only the round-2 fixtures; 'r2-dit' / 'r2-vae17' / 'r2-vae1024': one of them; "
+                                               "'r3-dit32' / 'r3-dit7b' / 'r3-refbf16': the round-3 fixtures")
     args = ap.parse_args()
+    if args.only.startswith("r3"):
+        return main_r3(args.only)
     if args.only:
         return main_r2(args.only)
     from oracle import reference_loader as rl
@@ -165,16 +183,17 @@ def pipeline_noise(lat):
     return torch.randn(lat.shape, generator=gg), torch.randn(lat.shape, generator=gg)
 
 
-def reference_pipeline_components(rl, config, weights, txt):
-    """pipeline_oracle.Components built from the REFERENCE: its NaDiT and VAE classes, and its glue function text."""
+def reference_pipeline_components(rl, config, weights, txt, dtype=torch.float32):
+    """pipeline_oracle.Components built from the REFERENCE: its NaDiT and VAE classes, and its glue function text.
+    ``dtype`` bfloat16: models and the tensors handed to them in bf16 (the reference's production regime)."""
     from oracle import pipeline_oracle as po
     glue = rl.reference_glue()
     dcfg = config.DIT_TINY
     vcfg = config.VAEConfig(block_out_channels=PIPE_CASE["vae_channels"])
     dsd = weights.synth_dit_state_dict(dcfg, seed=PIPE_CASE["seed_dit"])
     vsd = weights.synth_vae_state_dict(vcfg, seed=PIPE_CASE["seed_vae"])
-    dit = rl.build_reference_dit(dcfg.as_dict(), {k: v.float() for k, v in dsd.items()})
-    vae = rl.build_reference_vae({k: v.float() for k, v in vsd.items()}, block_out_channels=vcfg.block_out_channels)
+    dit = rl.build_reference_dit(dcfg.as_dict(), {k: v.to(dtype) for k, v in dsd.items()})
+    vae = rl.build_reference_vae({k: v.to(dtype) for k, v in vsd.items()}, block_out_channels=vcfg.block_out_channels)
     res = PIPE_CASE["resolution"]
     resize, pad16 = glue["SideResize"](size=res, max_size=0), glue["DivisiblePad"]((16, 16))
 
@@ -192,25 +211,26 @@ def reference_pipeline_components(rl, config, weights, txt):
 
     def vae_encode(x_cthw):                            # infer.py:117-199
         with torch.no_grad():
-            lat = vae.encode(x_cthw[None].float()).latent[0]
+            lat = vae.encode(x_cthw[None].to(dtype)).latent[0]
         return (lat.permute(1, 2, 3, 0) - vcfg.shifting_factor) * vcfg.scaling_factor
 
     def vae_decode(lat_thwc):                          # infer.py:203-278
         z = (lat_thwc / vcfg.scaling_factor + vcfg.shifting_factor).permute(3, 0, 1, 2)[None]
         with torch.no_grad():
-            return vae.decode(z.float()).sample[0]
+            return vae.decode(z.to(dtype)).sample[0].float()
 
     def dit_fn(vid, text):
         T, H, W, C = vid.shape
         with torch.no_grad():
-            out = dit(vid=vid.float().reshape(-1, C), txt=text.float(), vid_shape=torch.tensor([[T, H, W]]),
+            out = dit(vid=vid.to(dtype).reshape(-1, C), txt=text.to(dtype), vid_shape=torch.tensor([[T, H, W]]),
                       txt_shape=torch.tensor([[text.shape[0]]]), timestep=torch.tensor([1000.0])).vid_sample
         return out.reshape(T, H, W, -1)
 
     return po.Components(
         pad_video_temporal=glue["pad_video_temporal"], video_transform=video_transform, true_target_dims=true_dims,
         vae_encode=vae_encode, dit=dit_fn, vae_decode=vae_decode, blend_overlapping_frames=glue["blend_overlapping_frames"],
-        color_fix=lambda s_, r_: glue["lab_color_transfer"](s_, r_, _Dbg(), luminance_weight=0.8), noise=pipeline_noise)
+        color_fix=lambda s_, r_: glue["lab_color_transfer"](s_, r_, _Dbg(), luminance_weight=0.8),
+        noise=pipeline_noise if dtype == torch.float32 else (lambda lat: tuple(n.to(lat.dtype) for n in pipeline_noise(lat))))
 
 
 def main_r2(which):
@@ -273,6 +293,62 @@ def main_r2(which):
                     "frames": (5, 1024, 1152), "latent": (2, 128, 144), "seed_x": 47, "seed_z": 48, "cell": 32,
                     "tile_size": (1024, 1024), "tile_overlap": (128, 128), "seed_weights": weights.SEED_WEIGHTS + 1},
                    os.path.join(GOLD, "vae_tile1024.pt"))
+
+
+def main_r3(which):
+    from oracle import reference_loader as rl
+    assert rl.available(), "needs /root/reference"
+    config = importlib.import_module(PKG + ".config")
+    weights = importlib.import_module(PKG + ".weights")
+    txt = torch.load(os.path.join(GOLD, "text_pos_emb.pt"), weights_only=True)
+    if which in ("r3", "r3-dit32"):
+        cfg = config.DIT_3B
+        sd = weights.synth_dit_state_dict(cfg)
+        vid = dit_inputs(9, 60, 108, seed=44)
+        t0 = time.time()
+        out = run_reference_dit(rl, cfg, sd, vid, txt)
+        print("dit3b_32l_crop reference fp32 forward %.0fs" % (time.time() - t0), tuple(out.shape), float(out.std()))
+        torch.save({"out": out, "latent": (9, 60, 108), "seed_input": 44, "seed_weights": weights.SEED_WEIGHTS},
+                   os.path.join(GOLD, "dit3b_32l_crop.pt"))
+        del sd
+    if which in ("r3", "r3-dit7b"):
+        cfg = dit7b_r3_config(config)
+        sd = weights.synth_dit_state_dict(cfg)
+        vid = dit_inputs(5, 60, 108, seed=49)
+        t0 = time.time()
+        out = run_reference_dit(rl, cfg, sd, vid, txt)
+        print("dit7b_w2l_crop reference fp32 forward %.0fs" % (time.time() - t0), tuple(out.shape), float(out.std()))
+        torch.save({"out": out, "latent": (5, 60, 108), "seed_input": 49, "seed_weights": weights.SEED_WEIGHTS},
+                   os.path.join(GOLD, "dit7b_w2l_crop.pt"))
+        del sd
+    if which in ("r3", "r3-refbf16"):
+        bf = torch.bfloat16
+        res = {}
+        # DiT at production width (the inputs of dit3b_w4l_crop)
+        cfg = dit_r2_config(config)
+        out = run_reference_dit(rl, cfg, weights.synth_dit_state_dict(cfg), dit_inputs(9, 60, 108, seed=44), txt, dtype=bf)
+        res["dit3b_w4l_crop"] = out.to(bf)
+        print("refbf16 dit3b_w4l_crop", tuple(out.shape))
+        # VAE (the inputs of vae_tiled17)
+        vcfg = config.VAE_V3
+        ref = rl.build_reference_vae({k: v.to(bf) for k, v in weights.synth_vae_state_dict(vcfg).items()})
+        tile = dict(tiled=True, tile_size=(64, 64), tile_overlap=(32, 32))
+        t0 = time.time()
+        with torch.no_grad():
+            res["vae_tiled17_enc"] = ref.encode(blocky_frames(17, 96, 160, seed=45, cell=8).to(bf), **tile).latent.to(bf)
+            res["vae_tiled17_dec"] = ref.decode(latent_input(5, 12, 20, seed=46).to(bf), **tile).sample.to(bf)
+        print("refbf16 vae_tiled17 %.0fs" % (time.time() - t0))
+        del ref
+        # the whole chain (the inputs of pipeline_small)
+        from oracle import pipeline_oracle as po
+        pc = PIPE_CASE
+        images = torch.rand(pc["frames"], pc["hw"][0], pc["hw"][1], 3, generator=torch.Generator().manual_seed(pc["seed_images"]))
+        text = weights.synth_text_embedding()
+        comps = reference_pipeline_components(rl, config, weights, text, dtype=bf)
+        out = po.upscale(images, text, comps, pc["batch_size"], pc["temporal_overlap"], pc["uniform_batch_size"], compute_dtype=bf)
+        res["pipeline_small"] = out.to(bf)
+        print("refbf16 pipeline_small", tuple(out.shape))
+        torch.save(res, os.path.join(GOLD, "refbf16.pt"))
 
 
 if __name__ == "__main__":

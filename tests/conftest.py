@@ -14,6 +14,20 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: multi-minute CPU test")
+    config.addinivalue_line("markers", "variants: GPU tests of non-default kernel variants (opt-in: -m variants; also carry the gpu marker)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` (the driver's round-end run) spends its seconds on the shipped path: tests marked `variants` (non-default kernel
+    generations / A-B knobs) run only when the -m expression names them (`-m variants`)."""
+    if "variants" in (config.getoption("-m") or ""):
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("variants") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 def sub(name):

@@ -30,8 +30,8 @@ def test_library_builds_loads_and_exports_header_symbols():
         assert hasattr(lib, name), f"{name} declared in seedvr2_hip.h but not exported"
     assert sorted(hip_lib.SYMBOLS) == declared, "ctypes table and header disagree"
     lib.svr_abi_version.restype = ctypes.c_int
-    assert lib.svr_abi_version() == 4
-    assert hip_lib.lib().svr_abi_version() == 4
+    assert lib.svr_abi_version() == hip_lib.ABI_VERSION == 5
+    assert hip_lib.lib().svr_abi_version() == 5
 
 
 def test_struct_layout_matches_header():

@@ -145,94 +145,6 @@ def test_gemm_swiglu(hip, ref, gemm_epi):
     assert rel_err(w2, want) < 1e-5
 
 
-@pytest.fixture(params=[2, 4], ids=["one_wg_256acc", "two_wg_128acc"])
-def gemm8(request, hip):
-    """svr_set_option("gemm_impl", 2 | 4): plain GEMMs that bring a fragment-ordered weight copy MUST run on the kernel with
-    register-streamed weights (svr_gemm8.hip: gemm8_kernel / gemm4_kernel) -- a shape it cannot serve is an error, not a
-    silent fallback."""
-    hip.set_option("gemm_impl", request.param)
-    yield hip
-    hip.set_option("gemm_impl", 0)
-
-
-@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 768, 384), (1, 2560, 256), (255, 512, 1280), (58, 2560, 5120),
-                                   (2048, 1536, 2560), (4100, 4096, 256), (513, 256, 6912)])
-def test_gemm8_bias(gemm8, ref, M, N, K):
-    """Register-streamed-weights GEMM: ragged M (one row .. many tiles), 4 .. 108 K stages, 1 .. 16 column tiles; against the
-    fp32 reference and against the LDS-staged kernel on the same problem."""
-    hip = gemm8
-    A = rnd(M, K)
-    w, W = packed(N, K)
-    Wf = hip.pack_gemm_frag(W, N, K)
-    assert Wf is not None
-    bias = rnd(N, dtype=torch.float32, seed=3)
-    out = torch.full((M, N), float("nan"), device="cuda", dtype=BF16)
-    hip.gemm(A, W, out, N=N, K=K, bias=bias, W_frag=Wf)
-    want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias)
-    assert not torch.isnan(out.float()).any() and rel_err(out.float(), want) < TOL_BF16
-    old = torch.empty(M, N, device="cuda", dtype=BF16)
-    hip.gemm(A, W, old, N=N, K=K, bias=bias)                      # (no W_frag: gemm_kernel)
-    assert rel_err(out.float(), old.float()) < 2e-3
-
-
-def test_gemm8_epilogues_views_and_race_screen(gemm8, ref):
-    hip = gemm8
-    packing = sub("packing")
-    M, N, K = 777, 512, 384
-    A = rnd(M, K)
-    w, W = packed(N, K)
-    Wf = hip.pack_gemm_frag(W, N, K)
-    bias = rnd(N, dtype=torch.float32, seed=3)
-    gate = rnd(N, dtype=torch.float32, seed=4)
-    resid = rnd(M, N, seed=5)
-    for epi, kw in ((EPI_BIAS_SILU, {}), (EPI_BIAS_GELU, {}), (EPI_RESID_GATE, dict(gate=gate, resid=resid)),
-                    (EPI_RESID_GATE, dict(resid=resid)), (EPI_RESID_GATE, dict(gate=gate))):
-        out = torch.empty(M, N, device="cuda", dtype=BF16)
-        hip.gemm(A, W, out, N=N, K=K, bias=bias, epilogue=epi, W_frag=Wf, **kw)
-        want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias, epilogue=epi, **kw)
-        assert rel_err(out.float(), want) < TOL_BF16, epi
-    # in-place residual on row-sliced views (C aliases resid), as the DiT calls it; rows outside the view untouched
-    buf = rnd(M + 58, N, seed=6)
-    want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE,
-                    gate=gate, resid=buf[:M].clone())
-    tail = buf[M:].clone()
-    hip.gemm(A, W, buf[:M], N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE, gate=gate, resid=buf[:M], W_frag=Wf)
-    assert rel_err(buf[:M].float(), want) < TOL_BF16 and torch.equal(buf[M:], tail)
-    # SwiGLU (interleaved gate | in blocks), ragged M
-    M2, K2, Hd = 515, 256, 768
-    A2 = rnd(M2, K2)
-    wg, wi = rnd(Hd, K2, scale=1 / 16, seed=7), rnd(Hd, K2, scale=1 / 16, seed=8)
-    W2 = packing.pack_swiglu(wg, wi, "cuda")
-    out = torch.empty(M2, Hd, device="cuda", dtype=BF16)
-    hip.gemm(A2, W2, out, N=2 * Hd, K=K2, epilogue=EPI_SWIGLU, W_frag=hip.pack_gemm_frag(W2, 2 * Hd, K2))
-    want = torch.nn.functional.silu(A2.float() @ wg.float().t()) * (A2.float() @ wi.float().t())
-    assert rel_err(out.float(), want) < TOL_BF16
-    # a transposed / swapped layout cannot hide behind a tolerance: identity against an asymmetric W returns W^T exactly
-    Kt = Nt = 256
-    wt = (torch.arange(Nt * Kt, device="cuda").reshape(Nt, Kt) % 251).to(BF16)
-    Wt = packing.pack_matrix(wt, "cuda")
-    o = torch.empty(Kt, Nt, device="cuda", dtype=BF16)
-    hip.gemm(torch.eye(Kt, device="cuda", dtype=BF16), Wt, o, N=Nt, K=Kt, W_frag=hip.pack_gemm_frag(Wt, Nt, Kt))
-    assert torch.equal(o, wt.t().contiguous())
-    # race screen: look-ahead loads, LDS-DMA ring and counted waits -- repeated launches of a 108-stage problem are bit-identical
-    M3, N3, K3 = 3000, 2560, 6912
-    A3 = rnd(M3, K3)
-    w3, W3 = packed(N3, K3)
-    Wf3 = hip.pack_gemm_frag(W3, N3, K3)
-    outs = []
-    for _ in range(4):
-        o3 = torch.empty(M3, N3, device="cuda", dtype=BF16)
-        hip.gemm(A3, W3, o3, N=N3, K=K3, W_frag=Wf3)
-        outs.append(o3)
-    torch.cuda.synchronize()
-    assert all(torch.equal(o3, outs[0]) for o3 in outs[1:])
-    assert rel_err(outs[0].float(), ref.gemm(A3, W3, torch.empty(M3, N3, device="cuda"), N=N3, K=K3)) < TOL_BF16
-    # and a shape the kernel cannot serve is refused under gemm_impl = 2 (K = 192: not a multiple of 128)
-    w4, W4 = packed(256, 192)
-    with pytest.raises(Exception):
-        hip.gemm(rnd(64, 192), W4, torch.empty(64, 256, device="cuda", dtype=BF16), N=256, K=192, W_frag=W4.reshape(-1)[:256 * 192])
-
-
 # ------------------------------------------------------------------ implicit-GEMM causal conv
 CONV_ROWS_DEFAULT = 8        # the library's default for svr_set_option("conv_rows", ...)
 CONV_CASES = [
@@ -257,11 +169,12 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("conv_impl", [0, 2, -1, -2], ids=["halo16x32", "halo8x32", "wreg_4rows", "wreg_8rows"])
+@pytest.mark.parametrize("conv_impl", [0, pytest.param(1, marks=pytest.mark.variants), pytest.param(-1, marks=pytest.mark.variants), -2],
+                         ids=["halo16x32", "generic", "wreg_4rows", "wreg_8rows"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3d_implicit_gemm(hip, ref, case, conv_impl):
-    """conv_impl 0: the library's choice (16x32-voxel LDS-halo kernel where eligible), 2: the first (8x32) halo
-    kernel; geometries neither accepts run on the generic implicit-GEMM kernel in both.  "wreg_*": the library's
+    """conv_impl 0: the library's choice (16x32-voxel LDS-halo kernel where eligible), 1: the generic implicit-GEMM kernel
+    everywhere (geometries the halo kernel does not accept run on it anyway).  "wreg_*": the library's
     choice with the fragment-ordered weight copy supplied (weights streamed to registers, not through LDS), with 4
     patch rows per wave and two workgroups per CU, or 8 rows per wave and one wave per SIMD (conv_rows)."""
     hip.set_option("conv_impl", max(conv_impl, 0))
@@ -568,7 +481,7 @@ def test_conv_subpixel_fused_groupnorm_statistics(hip, T, H, W, Cin, Cout, hf, k
 @pytest.mark.parametrize("Cin,Cout,kt,T,H,W,hf", [(128, 3, 3, 3, 40, 70, 0), (512, 32, 3, 2, 19, 45, 2), (128, 3, 1, 2, 9, 33, 0), (192, 16, 3, 4, 8, 32, 0)])
 def test_conv_thin_output_kernel(hip, ref, Cin, Cout, kt, T, H, W, hf):
     """Thin-output convs (N <= 32: decoder conv_out 128 -> 3, encoder conv_out 512 -> 32) on the step-interval kernel
-    (svr_conv_thinout.hip) == the torch restatement, == the first halo kernel's 32-cout variant up to MFMA-order rounding,
+    (svr_conv_thinout.hip) == the torch restatement, == the generic implicit-GEMM kernel up to MFMA-order rounding,
     plain bias epilogue (production) and residual epilogue; repeated launches bit-identical (double-buffered LDS-DMA)."""
     packing, opsmod = sub("packing"), sub("ops")
     x = rnd(T, H, W, Cin)
@@ -591,12 +504,12 @@ def test_conv_thin_output_kernel(hip, ref, Cin, Cout, kt, T, H, W, hf):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
         want = ref.gemm(x, Wp, torch.empty(To, H, W, Cout, device="cuda"), **kw)
         assert not torch.isnan(outs[0].float()).any() and rel_err(outs[0].float(), want) < TOL_BF16
-        hip.set_option("conv_thinout", 0)
+        hip.set_option("conv_impl", 1)                      # the generic implicit-GEMM kernel on the same launch
         try:
             old = torch.empty(To, H, W, Cout, device="cuda", dtype=BF16)
             hip.gemm(x, Wp, old, **kw)
         finally:
-            hip.set_option("conv_thinout", 1)
+            hip.set_option("conv_impl", 0)
         assert rel_err(outs[0].float(), old.float()) < 2e-3
 
 
@@ -699,7 +612,8 @@ def test_vae_causal_head_two_term_sum_matches_three_taps_on_gpu(hip):
     assert rel_err(two.encode(x[:, :1]).float(), three.encode(x[:, :1]).float()) < 2e-2
 
 
-@pytest.fixture(params=[0, 4, 8], ids=["lds_weights", "wreg_4rows", "wreg_8rows"])
+@pytest.fixture(params=[pytest.param(0, marks=pytest.mark.variants), pytest.param(4, marks=pytest.mark.variants), 8],
+                ids=["lds_weights", "wreg_4rows", "wreg_8rows"])
 def conv_variant(request, hip):
     """The three shapes of the second LDS-halo conv kernel: weights through the LDS ring (no fragment-ordered copy), weights
     streamed to registers with 4 or with 8 patch rows per wave.  -> rows per wave (0: no fragment-ordered copy)."""
@@ -797,7 +711,7 @@ def _attn_case(lens, heads, D, n_rows, seed=0):
     return to(seq_rows), to(out_rows), torch.tensor(cu, dtype=torch.int32).cuda(), o
 
 
-@pytest.fixture(params=[0, 1], ids=["attn_win", "attn_gen1"])
+@pytest.fixture(params=[0, pytest.param(1, marks=pytest.mark.variants)], ids=["attn_win", "attn_gen1"])
 def attn_impl(request, hip):
     """Both window-attention kernels stay parity-green: 0 = second-generation kernel (svr_attn_win.hip) wherever it
     applies (head_dim 128, windows <= 2048 rows), 1 = the first kernel everywhere."""
@@ -814,7 +728,7 @@ def attn_impl(request, hip):
                                           ([2048, 77, 1215, 640], 5, 128),
                                           # one row more than the table: served by the first kernel whatever attn_impl says
                                           ([2049, 300], 1, 128)])
-def test_attn_varlen(hip, ref, attn_impl, lens, heads, D):
+def test_attn_varlen(hip, ref, attn_impl, lens, heads, D, request):
     n_rows = 1500
     qkv = rnd(n_rows, 3 * heads * D)
     seq_rows, out_rows, cu, total = _attn_case(lens, heads, D, n_rows)
@@ -829,7 +743,7 @@ def test_attn_varlen(hip, ref, attn_impl, lens, heads, D):
         again = torch.zeros_like(out)
         hip.attn_varlen(qkv, again, seq_rows, out_rows, cu, max(lens), heads, D, scale)
         assert torch.equal(again, out)
-    if attn_impl == 0 and D == 128:                 # the build variants of the second-generation kernel (A/B knob)
+    if attn_impl == 0 and D == 128 and "variants" in (request.config.getoption("-m") or ""):   # the kernel's build variants (A/B knob)
         for variant in (1, 3, 4):                   # 4 waves + s_setprio, 8 waves + s_setprio, 4 waves (default: 8 waves)
             hip.set_option("attn_variant", variant)
             try:

@@ -1,0 +1,208 @@
+"""-m gpu: the wide (fp32) residual trunk of ABI v5 -- fp32 outputs / fp32 residuals in the conv and GEMM epilogues, fp32 inputs
+of the normalisation kernels -- against the torch restatement of the same ops (tests/ops_reference.py) on identical inputs.
+
+Contract: the arithmetic is unchanged (bf16 MFMA operands, fp32 accumulate); what changes is that a value on the skip path is
+not rounded to bf16 when it is stored.  So an fp32 store must meet the fp32-store bound 1e-3 (measured ~3e-4: MFMA summation
+order), fused GroupNorm statistics are those of the fp32 values that were stored, and a bf16 store after an fp32 residual
+meets the bf16-store bound 2.5e-3."""
+import math
+
+import pytest
+import torch
+
+from conftest import sub, rel_err
+from ops_reference import TorchOps, EPI_BIAS, EPI_RESID_GATE
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+TOL_BF16, TOL_F32 = 2.5e-3, 1e-3
+
+
+@pytest.fixture(scope="module")
+def hip():
+    return sub("ops").HipOps("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return TorchOps("cuda:0", act_dtype=torch.float32)
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=BF16):
+    g = torch.Generator(device="cuda").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g, device="cuda") * scale).to(dtype)
+
+
+@pytest.mark.parametrize("frag", [True, pytest.param(False, marks=pytest.mark.variants)], ids=["wreg_8rows", "lds_weights"])
+@pytest.mark.parametrize("out_dt,res_dt", [(F32, None), (F32, F32), (F32, BF16), (BF16, F32)],
+                         ids=["f32_out", "f32_out_f32_resid", "f32_out_bf16_resid", "bf16_out_f32_resid"])
+@pytest.mark.parametrize("Cin,Cout,T,H,W,hf", [(128, 128, 3, 21, 70, 0), (256, 128, 2, 17, 33, 2)])
+def test_conv_halo_wide_trunk_epilogues(hip, ref, frag, out_dt, res_dt, Cin, Cout, T, H, W, hf):
+    """conv_halo2_kernel's compile-time option sets with fp32 output and / or fp32 residual, with and without the fused
+    GroupNorm statistics: output vs the torch conv, statistics == those of the tensor that was stored, launches bit-reproducible."""
+    packing, opsmod = sub("packing"), sub("ops")
+    x = rnd(T, H, W, Cin)
+    halo = rnd(hf, H, W, Cin, seed=9) if hf else None
+    w5 = rnd(Cout, Cin, 3, 3, 3, scale=1.0 / math.sqrt(Cin * 27), seed=2)
+    Wp = packing.pack_conv3d(w5, "cuda")
+    bias = rnd(Cout, dtype=F32, seed=3)
+    pt = hf if hf else 2
+    To = T + pt - 2
+    geom = opsmod.Conv3dGeom(T, H, W, Cin, To, H, W, (3, 3, 3), (1, 1, 1), (pt, 1, 1), halo)
+    resid = rnd(To, H, W, Cout, seed=11, dtype=res_dt) if res_dt is not None else None
+    kw = dict(N=Cout, K=Wp.shape[1], bias=bias, conv=geom, ldc=Cout, ldr=Cout, resid=resid,
+              epilogue=EPI_RESID_GATE if resid is not None else EPI_BIAS, W_frag=hip.pack_conv_frag(Wp, 3, Cin, Cout) if frag else None)
+    want = ref.gemm(x, Wp, torch.empty(To, H, W, Cout, device="cuda"), **{k: v for k, v in kw.items() if k != "W_frag"})
+    out = torch.full((To, H, W, Cout), float("nan"), device="cuda", dtype=out_dt)
+    got, stats = hip.gemm(x, Wp, out, gn_groups=32, out_f32=out_dt == F32, **kw)
+    assert got is out and stats is not None and not torch.isnan(out.float()).any()
+    assert rel_err(out.float(), want) < (TOL_F32 if out_dt == F32 else TOL_BF16)
+    plain = torch.empty_like(out)
+    hip.gemm(x, Wp, plain, out_f32=out_dt == F32, **kw)
+    assert torch.equal(plain, out)                                   # the fused statistics do not change the output
+    ws = ref.groupnorm_stats(out, torch.empty(To, 32, 2, device="cuda", dtype=torch.float64), 32)
+    assert torch.allclose(stats, ws, rtol=2e-6, atol=1e-5)
+    _, again = hip.gemm(x, Wp, torch.empty_like(out), gn_groups=32, out_f32=out_dt == F32, **kw)
+    assert torch.equal(again, stats)
+
+
+def test_conv_halo_wide_trunk_in_place_residual(hip, ref):
+    """out aliases the fp32 residual (how a block could update the trunk in place): each thread reads its 8 values before it
+    writes them, so the result equals the out-of-place launch."""
+    packing, opsmod = sub("packing"), sub("ops")
+    T, H, W, C = 2, 19, 45, 128
+    x = rnd(T, H, W, C)
+    Wp = packing.pack_conv3d(rnd(C, C, 3, 3, 3, scale=1.0 / math.sqrt(C * 27), seed=2), "cuda")
+    geom = opsmod.Conv3dGeom(T, H, W, C, T, H, W, (3, 3, 3), (1, 1, 1), (2, 1, 1), None)
+    trunk = rnd(T, H, W, C, seed=5, dtype=F32)
+    kw = dict(N=C, K=Wp.shape[1], bias=rnd(C, dtype=F32, seed=3), conv=geom, ldc=C, ldr=C, epilogue=EPI_RESID_GATE,
+              W_frag=hip.pack_conv_frag(Wp, 3, C, C), out_f32=True)
+    sep = torch.empty_like(trunk)
+    hip.gemm(x, Wp, sep, resid=trunk, **kw)
+    inplace = trunk.clone()
+    hip.gemm(x, Wp, inplace, resid=inplace, **kw)
+    assert torch.equal(inplace, sep)
+
+
+@pytest.mark.parametrize("kt,ts,hf", [(3, 1, 0), (2, 2, 1)])
+def test_conv_subpixel_fp32_output_and_statistics(hip, ref, kt, ts, hf):
+    """The sub-pixel upsampler kernel writing the upsampled tensor in fp32 (an upsampler whose output stays on the wide
+    trunk), all four phases, with the shared fused statistics."""
+    packing, opsmod = sub("packing"), sub("ops")
+    T, H, W, Cin, Cout, G = 3, 17, 33, 128, 128, 32
+    x = rnd(T, H, W, Cin)
+    halo = rnd(hf, H, W, Cin, seed=9) if hf else None
+    pt = hf if hf else kt - 1
+    To = T + pt - kt + 1
+    out = torch.full((To * ts, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=F32)
+    want = torch.zeros_like(out)
+    shared = {"frames": out.shape[0]}
+    for tz in range(ts):
+        for ph, (py, px) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+            Wp = packing.pack_conv3d(rnd(Cout, Cin, kt, 2, 2, scale=1.0 / math.sqrt(Cin * 4 * kt), seed=20 + ph + 4 * tz), "cuda")
+            geom = opsmod.Conv3dGeom(T, H, W, Cin, To, H, W, (kt, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
+            kw = dict(N=Cout, K=Wp.shape[1], bias=rnd(Cout, dtype=F32, seed=30 + ph), conv=geom,
+                      phase=opsmod.PhaseScatter(py, px, rnd(3, Cout, dtype=F32, seed=40 + ph), ts))
+            shared["frame0"] = tz
+            hip.gemm(x, Wp, out[tz:], W_frag=hip.pack_conv_frag(Wp, kt, Cin, Cout, taps=(2, 2)), gn_groups=G, gn_shared=shared,
+                     out_f32=True, **kw)
+            ref.gemm(x, Wp, want[tz:], **kw)
+    assert not torch.isnan(out).any() and rel_err(out, want) < TOL_F32
+    stats = hip.gn_shared_stats(shared)
+    ws = ref.groupnorm_stats(out, torch.empty(out.shape[0], G, 2, device="cuda", dtype=torch.float64), G)
+    assert stats is not None and torch.allclose(stats, ws, rtol=2e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("epi", [1, 2], ids=["epi_direct", "epi_lds"])
+@pytest.mark.parametrize("M,N,K", [(777, 512, 320), (3000, 2560, 2560), (58, 2560, 6912)])
+def test_gemm_wide_residual_stream(hip, ref, epi, M, N, K):
+    """gate + fp32 residual -> fp32 output, in place (the NaDiT residual stream: mmsr_block.py:108-126), both epilogue paths of
+    the GEMM kernel; and fp32 residual -> bf16 output (the 7B family's last block)."""
+    packing = sub("packing")
+    hip.set_option("gemm_epi", epi)
+    try:
+        A = rnd(M, K)
+        W = packing.pack_matrix(rnd(N, K, scale=1.0 / math.sqrt(K), seed=1), "cuda")
+        bias, gate = rnd(N, dtype=F32, seed=3), rnd(N, dtype=F32, seed=4)
+        hid = rnd(M + 58, N, seed=5, dtype=F32)
+        tail = hid[M:].clone()
+        want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE, gate=gate,
+                        resid=hid[:M].clone())
+        narrow = torch.empty(M, N, device="cuda", dtype=BF16)
+        hip.gemm(A, W, narrow, N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE, gate=gate, resid=hid[:M])
+        assert rel_err(narrow.float(), want) < TOL_BF16
+        hip.gemm(A, W, hid[:M], N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE, gate=gate, resid=hid[:M], out_f32=True)
+        assert rel_err(hid[:M], want) < TOL_F32 and torch.equal(hid[M:], tail)
+    finally:
+        hip.set_option("gemm_epi", 0)
+
+
+@pytest.mark.parametrize("rows,dim", [(1000, 2560), (58, 2560), (7, 3072), (333, 256)])
+def test_rmsnorm_mod_fp32_input(hip, ref, rows, dim):
+    x = rnd(rows, dim, scale=2.0, dtype=F32)
+    w, sc, sh = (rnd(dim, dtype=F32, seed=s) for s in (1, 2, 3))
+    for kw in (dict(), dict(scale=sc, shift=sh), dict(w=w, scale=sc, shift=sh)):
+        out = torch.empty(rows, dim, device="cuda", dtype=BF16)
+        hip.rmsnorm_mod(x, out, 1e-5, **kw)
+        assert rel_err(out.float(), ref.rmsnorm_mod(x, torch.empty(rows, dim, device="cuda"), 1e-5, **kw)) < TOL_BF16
+    # a bf16-representable fp32 input gives the bf16 kernel's bits
+    xb = rnd(rows, dim, scale=2.0)
+    a, b = torch.empty(rows, dim, device="cuda", dtype=BF16), torch.empty(rows, dim, device="cuda", dtype=BF16)
+    hip.rmsnorm_mod(xb, a, 1e-5, scale=sc, shift=sh)
+    hip.rmsnorm_mod(xb.float(), b, 1e-5, scale=sc, shift=sh)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C", [128, 256, 512])
+def test_groupnorm_fp32_input(hip, ref, C):
+    T, H, W = 3, 37, 41
+    x = rnd(T, H, W, C, scale=1.5, dtype=F32) + 0.7
+    gamma, beta = rnd(C, dtype=F32, seed=1) + 1, rnd(C, dtype=F32, seed=2)
+    stats = torch.empty(T, 32, 2, device="cuda", dtype=torch.float64)
+    hip.groupnorm_stats(x, stats, 32)
+    want_stats = ref.groupnorm_stats(x, torch.empty(T, 32, 2, device="cuda", dtype=torch.float64), 32)
+    assert torch.allclose(stats, want_stats, rtol=1e-5)
+    for silu in (True, False):
+        out = torch.empty(T, H, W, C, device="cuda", dtype=BF16)
+        hip.groupnorm_apply(x, out, stats, gamma, beta, 32, 1e-6, silu)
+        want = ref.groupnorm_apply(x, torch.empty(T, H, W, C, device="cuda"), want_stats, gamma, beta, 32, 1e-6, silu)
+        assert rel_err(out.float(), want) < TOL_BF16
+    xb = rnd(T, H, W, C, scale=1.5)                               # bf16-representable fp32 input == the bf16 kernel, bit for bit
+    sb, sf = torch.empty_like(stats), torch.empty_like(stats)
+    hip.groupnorm_stats(xb, sb, 32)
+    hip.groupnorm_stats(xb.float(), sf, 32)
+    assert torch.equal(sb, sf)
+    a, b = torch.empty_like(xb), torch.empty_like(xb)
+    hip.groupnorm_apply(xb, a, sb, gamma, beta, 32, 1e-6, True)
+    hip.groupnorm_apply(xb.float(), b, sb, gamma, beta, 32, 1e-6, True)
+    assert torch.equal(a, b)
+
+
+def test_conv_thin_input_fp32_output(hip, ref):
+    """encoder conv_in (RGB padded to 4 channels) storing the first trunk tensor in fp32, fused statistics included."""
+    packing, opsmod = sub("packing"), sub("ops")
+    T, H, W, Cout = 3, 21, 70, 128
+    x = rnd(T, H, W, 4)
+    x[..., 3] = 0
+    Wp = packing.pack_conv3d(rnd(Cout, 3, 3, 3, 3, scale=1.0 / math.sqrt(81), seed=2), "cuda", 4)
+    geom = opsmod.Conv3dGeom(T, H, W, 4, T, H, W, (3, 3, 3), (1, 1, 1), (2, 1, 1), None)
+    kw = dict(N=Cout, K=Wp.shape[1], bias=rnd(Cout, dtype=F32, seed=3), conv=geom, ldc=Cout)
+    out = torch.full((T, H, W, Cout), float("nan"), device="cuda", dtype=F32)
+    _, stats = hip.gemm(x, Wp, out, gn_groups=32, out_f32=True, **kw)
+    want = ref.gemm(x, Wp, torch.empty(T, H, W, Cout, device="cuda"), **kw)
+    assert rel_err(out, want) < TOL_F32 and stats is not None
+    assert torch.allclose(stats, ref.groupnorm_stats(out, torch.empty(T, 32, 2, device="cuda", dtype=torch.float64), 32), rtol=2e-6, atol=1e-5)
+
+
+def test_vae_engine_storage_regimes_agree_with_their_cpu_emulation(hip):
+    """The engine with and without the wide trunk on the HIP path vs the same host code over the torch double of the C ABI in
+    the same storage regime (bf16 activations, fp32 trunk): the two regimes are different functions (fewer roundings), each
+    must match its own emulation to the noise of one bf16 storage step."""
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    cfg = config.VAEConfig(block_out_channels=(128, 256, 256, 512))
+    sd = weights.synth_vae_state_dict(cfg, seed=7)
+    z = rnd(2, 6, 8, 16, seed=3)
+    for wide in (True, False):
+        got = vae.VideoVAEEngine(cfg, sd, hip, trunk_fp32=wide).decode(z).float().cpu()
+        emu = vae.VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=BF16), trunk_fp32=wide).decode(z.cpu()).float()
+        assert got.shape == emu.shape and rel_err(got, emu) < 1.2e-2, wide

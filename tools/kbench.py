@@ -95,10 +95,19 @@ def main():
             kw = {}
             if epi == ops_mod.EPI_RESID_GATE:
                 kw = dict(gate=torch.ones(N, dtype=torch.float32, device=dev), resid=rnd(M, N))
-            wf = ops.pack_gemm_frag(w, N, K)          # None unless SVR_OPTIONS=gemm_impl=1|2 (register-streamed weights)
-            sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, epilogue=epi, W_frag=wf, **kw), args.reps)
-            report(name + (" [gemm8]" if wf is not None else ""), sec, flops=2.0 * M * N * K)
-            del a, w, c, kw, wf
+            sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, epilogue=epi, **kw), args.reps)
+            report(name, sec, flops=2.0 * M * N * K)
+            del a, w, c, kw
+    if "blaslt" in only:
+        # calibration only (never on the product path): the vendor library's GEMM (hipBLASLt behind torch) on the same four shapes, same box
+        import torch.nn.functional as F
+        M = 291600
+        for name, N, K in (("qkv 2560->7680", 7680, 2560), ("attn-out 2560->2560", 2560, 2560),
+                           ("mlp-in 2560->13824", 13824, 2560), ("mlp-out 6912->2560", 2560, 6912)):
+            a, w = rnd(M, K), rnd(N, K)
+            sec = timeit(lambda: F.linear(a, w), args.reps)
+            report("hipBLASLt (torch F.linear, no epilogue) " + name, sec, flops=2.0 * M * N * K)
+            del a, w
     if "shortk" in only:
         # short-K problems of the VAE (tools/shape_census.py): pixel-shuffle upsamplers, 1x1 shortcut convs, attention scores
         for name, F_, H, W, Cc, rz in (("upsample gemm+pixel-shuffle 256->1024 @5x512^2", 5, 512, 512, 256, 1),
