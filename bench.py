@@ -38,12 +38,12 @@ PKG = "comfyui-seedvr2_videoupscaler_amd"
 
 WORKLOADS = {
     # name: (frames, H, W, vae_tiled, description)
-    "cfg3": (33, 2160, 3840, True, "SeedVR2-3B 33-frame (32+1 pad) 720p->4K clip, VAE tiled 1024/128"),
-    "cfg2": (9, 2048, 2048, False, "SeedVR2-3B 9-frame (8+1 pad) 512^2->2048^2 clip, VAE untiled"),
+    "cfg3": (33, 2160, 3840, True, "SeedVR2-3B 32-frame 720p->4K clip (padded to 33 = 4n+1 for encode + DiT, 32 decoded), VAE tiled 1024/128"),
+    "cfg2": (9, 2048, 2048, False, "SeedVR2-3B 8-frame 512^2->2048^2 clip (padded to 9 = 4n+1, 8 decoded), VAE untiled"),
     "cfg1": (1, 256, 256, False, "SeedVR2-3B single 256x256 image"),
     # BASELINE config 5's model and clip on ONE GPU, bf16 weights (the reference does no fp8 arithmetic either:
     # fp8 checkpoints are up-cast per op); not the metric config, run with --workload cfg5
-    "cfg5": (65, 2160, 3840, True, "SeedVR2-7B 65-frame (64+1 pad) 1080p->4K clip, VAE tiled 1024/128"),
+    "cfg5": (65, 2160, 3840, True, "SeedVR2-7B 64-frame 1080p->4K clip (padded to 65 = 4n+1, 64 decoded), VAE tiled 1024/128"),
     # BASELINE config 4: the whole pipeline over a 128-frame clip, temporal batches sharded over the ranks (strong scaling)
     "cfg4": (128, 2160, 3840, True, "SeedVR2-3B 128-frame 720p->4K clip, 8 temporal batches of 17 (overlap 1) sharded "
                                     "over the ranks, full pipeline (transform, encode, DiT, decode, blend, LAB colour fix)"),
@@ -180,6 +180,9 @@ def main():
     ap.add_argument("--three-tap-head", action="store_true",
                     help="A/B: keep three temporal taps on the first frame of every clip instead of the two-term sum of the taps "
                          "that fall on the replicated frame (VideoVAEEngine(merge_causal_head=False))")
+    ap.add_argument("--bf16-trunk", action="store_true",
+                    help="A/B: round 2's storage regime -- the VAE's residual trunk and the DiT's residual stream in bf16 instead of "
+                         "fp32 (48.1 instead of 51.2 dB end to end against the fp32 reference)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -201,9 +204,10 @@ def main():
     ops = make_profiled_ops(device)
     dcfg, vcfg = (config.DIT_7B if args.workload == "cfg5" else config.DIT_3B), config.VAE_V3
     # random-init weights of the exact architecture, generated on the GPU (no checkpoints available offline)
-    dit = sub("dit").NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, device=device), ops)
+    dit = sub("dit").NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, device=device), ops, hid_fp32=not args.bf16_trunk)
     vae = sub("vae").VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, device=device), ops,
-                                    merge_upsamplers=not args.two_step_upsampler, merge_causal_head=not args.three_tap_head)
+                                    merge_upsamplers=not args.two_step_upsampler, merge_causal_head=not args.three_tap_head,
+                                    trunk_fp32=not args.bf16_trunk)
     runner_mod = sub("runner")
     runner = runner_mod.VideoDiffusionInfer(
         runner_mod.default_config(), encode_tiled=tiled, encode_tile_size=(1024, 1024), encode_tile_overlap=(128, 128),
@@ -226,6 +230,7 @@ def main():
             out = dist_mod.upscale_sharded(images, runner, txt, **pipe_kw)      # [128, 2160, 3840, 3] on every rank
             return out, None
     else:
+        useful = frames - 1 if frames > 1 and frames % 4 == 1 else frames      # frames of the caller's clip in one padded batch
         x = (torch.rand(3, frames, H, W, generator=g, device=device) * 2 - 1).to(torch.bfloat16)
         noise = torch.randn(Tl, hl, wl, 16, generator=g, device=device).to(torch.bfloat16)
 
@@ -237,7 +242,9 @@ def main():
             cond = runner.get_condition(noise, latent_blur=lat, task="sr")
             x0 = runner.inference([noise], [cond], [txt], [txt])[0]
             if timed: ev[2].record()
-            out = runner.vae_decode([x0])[0]                       # [3, T, H, W] view of THWC
+            # the 4n+1 rule pads the clip with one reversed frame (generation_phases.py:398-404) that the pipeline trims after
+            # decode; as in pipeline.upscale (skip_trimmed_frames), the causal decoder is told not to produce it
+            out = runner.vae_decode([x0], keep_frames=[useful])[0]     # [3, useful, H, W] view of THWC
             if timed: ev[3].record()
             thwc = out.permute(1, 2, 3, 0) if out.dim() == 4 else out.permute(1, 2, 0)[None]
             gathered = dist_mod.all_gather_frames(thwc.contiguous())
@@ -281,22 +288,23 @@ def main():
             f_vae = flops.vae_flops_tiled(vcfg, bf, H, W, tiled)
             f_step = len(plans) * (f_dit["total"] + f_vae["encode"] + f_vae["decode"])
             f_exec = len(plans) * (f_dit["total"] + sum(flops.vae_flops_tiled(vcfg, bf, H, W, tiled, merged_upsamplers=not args.two_step_upsampler, causal_head=not args.three_tap_head).values()))
-            frames_per_step, useful_per_step = frames, frames
+            frames_per_step, padded_per_step = frames, frames
         else:
             f_dit = flops.dit_flops(dcfg, (Tl, hl // 2, wl // 2))
             f_vae = flops.vae_flops_tiled(vcfg, frames, H, W, tiled)
             f_step = f_dit["total"] + f_vae["encode"] + f_vae["decode"]
-            f_exec = f_dit["total"] + sum(flops.vae_flops_tiled(vcfg, frames, H, W, tiled, merged_upsamplers=not args.two_step_upsampler, causal_head=not args.three_tap_head).values())
-            frames_per_step = world * frames
-            # the 4n+1 rule pads a 32-frame clip with one reversed frame (generation_phases.py:398-404): it is computed but
-            # trimmed from the output, so the useful rate is (frames - 1) / frames of `value` for the padded workloads
-            useful_per_step = world * (frames - 1 if frames > 1 and frames % 4 == 1 else frames)
+            f_exec = f_dit["total"] + sum(flops.vae_flops_tiled(vcfg, frames, H, W, tiled, merged_upsamplers=not args.two_step_upsampler,
+                                                                causal_head=not args.three_tap_head, keep_frames=useful).values())
+            # `value` counts the frames of the caller's clip (32 of the 33-frame padded batch: the padding frame is encoded and goes
+            # through the DiT, the decoder skips it); `padded_frames_per_s` is the round-1/2 convention (all 33)
+            frames_per_step = world * useful
+            padded_per_step = world * frames
         kern = ops.summary()
         # dominant kernel: the LDS-halo implicit-GEMM conv (73 % of the step, profiles/r2_cfg3_kernel_stats.csv)
         dom = kern.get("conv_halo") or kern.get("conv_generic") or kern["gemm"]
         c_flops, c_sec, c_n = dom["flops"], dom["seconds"], dom["launches"]
         traffic, traffic_note = None, None
-        for name in ("r2_cfg3_pmc_traffic.json", "r1_cfg3_pmc_traffic.json"):
+        for name in ("r3_cfg3_pmc_traffic.json", "r2_cfg3_pmc_traffic.json", "r1_cfg3_pmc_traffic.json"):
             # HBM bytes per launch come from separate rocprofv3 --pmc passes of this workload (counters cannot be collected
             # inside the timed run); the file names the commit it was measured on
             try:
@@ -325,12 +333,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "storage": "bf16 activations (every MFMA operand), bf16 residual trunk / stream (round-2 regime)" if args.bf16_trunk else
+                       "bf16 activations (every MFMA operand), fp32 residual trunk (VAE) and residual stream (DiT)",
             "config": {"workload": f"{args.workload}: {desc}",
-                       "frames_per_step_per_gpu": frames if not sharded else f"{frames} per clip, 8 batches of 17 shared by the ranks",
+                       "frames_per_step_per_gpu": useful if not sharded else f"{frames} per clip, 8 batches of 17 shared by the ranks",
                        "pixels": [H, W], "latent": [Tl, hl, wl] if not sharded else [(CFG4["batch_size"] - 1) // 4 + 1, hl, wl],
                        "vae_tiled": tiled, "parallelism": f"dp{world}",
                        "weights": f"random-init SeedVR2-{family} + video_vae_v3 architecture (seeded)"},
-            "useful_frames_per_s": useful_per_step * args.steps / dt,
+            "padded_frames_per_s": padded_per_step * args.steps / dt,
             # FLOPs of the reference's algorithm for this workload, and of what this engine executes for it (the spatial-only
             # VAE upsampler runs in its sub-pixel form: same function, fewer multiply-adds); the achieved rate counts the latter
             "algorithmic_tflop_per_step": f_step / 1e12,

@@ -32,6 +32,12 @@ extern "C" {
 
 const char* svr_last_error(void) { return g_err; }
 int svr_abi_version(void) { return SVR_ABI_VERSION; }
+#ifndef SVR_BUILD_ID
+#define SVR_BUILD_ID "unknown"
+#endif
+// (stored behind a marker so that the loader can read it from the file without dlopen()ing a possibly stale binary)
+static const char g_build_id[] = "SVR_BUILD_ID=" SVR_BUILD_ID;
+const char* svr_build_id(void) { return g_build_id + 13; }
 
 int svr_set_option(const char* key, int32_t value) {
     if (!key) return fail("svr_set_option: null key");

@@ -228,11 +228,10 @@ static int launch_attn(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_ou
     constexpr int QB = 64 * QSUB;
     const size_t lds = (size_t)KT * D * 2 * 2;
     auto kern = attn_kernel<D, QSUB, KT>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    static uint64_t lds_attr_done = 0;               // per device (svr_common.h)
+    {
+        const int e = (lds > 48 * 1024) ? set_max_dynamic_lds((const void*)kern, (int)lds, lds_attr_done) : 0;
+        if (e != 0) return e;
     }
     dim3 grid((max_len + QB - 1) / QB, heads, n_seq);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)qkv, ld_qkv, (bf16_t*)out, ld_out,

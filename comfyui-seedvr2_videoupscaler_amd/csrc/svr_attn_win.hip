@@ -346,11 +346,10 @@ static int launch_attn_win_t(const void* qkv, int64_t ld_qkv, void* out, int64_t
                              const int32_t* out_rows, const int32_t* cu, int n_seq, int max_len, int heads, float scale,
                              hipStream_t s) {
     auto kern = attn_win_kernel<NW, PRIO>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AW_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    static uint64_t lds_attr_done = 0;               // per device (svr_common.h)
+    {
+        const int e = set_max_dynamic_lds((const void*)kern, AW_LDS, lds_attr_done);
+        if (e != 0) return e;
     }
     constexpr int QB = NW * 32;
     if ((ld_qkv * 2) % 16 != 0) return -3;            // (attn_dispatch only sends 16-byte aligned row pitches here)

@@ -78,4 +78,18 @@ SVR_DEVICE void glds16(const void* gptr, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE function attribute: a process that drives several GPUs (one
+// HipOps per device, e.g. ComfyUI nodes pinned to different cuda:N) must set it on each of them.  One bit per device and
+// launch site (`done` is the site's static mask); hipGetDevice is a thread-local read.
+static inline int set_max_dynamic_lds(const void* kern, int bytes, uint64_t& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done & bit) return 0;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done |= bit;
+    return 0;
+}
+
 }  // namespace svr

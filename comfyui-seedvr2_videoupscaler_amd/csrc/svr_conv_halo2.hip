@@ -907,11 +907,10 @@ template <int TY, int MODE, int DBG = 0> static int launch_conv_halo2_t(const sv
     typedef cg_geom<TY, MODE> G;
     const svr_conv_geom& g = a.conv;
     const int tiles = g.To * ((g.H + TY - 1) / TY) * ((g.W + CG_TX - 1) / CG_TX) * (a.N / 128);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_halo2_kernel<TY, MODE, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    static uint64_t lds_attr_done = 0;               // per device (svr_common.h)
+    {
+        const int e = set_max_dynamic_lds((const void*)conv_halo2_kernel<TY, MODE, DBG>, 160 * 1024, lds_attr_done);
+        if (e != 0) return e;
     }
     hipLaunchKernelGGL((conv_halo2_kernel<TY, MODE, DBG>), dim3(tiles), dim3(G::NT), g_conv_lds_dbg > G::LDS ? g_conv_lds_dbg : G::LDS, s, a,
                        g_conv_band);

@@ -432,11 +432,10 @@ static int conv_sub_gn_blocks(const svr_gemm_args& a) {
 static int launch_conv_sub(const svr_gemm_args& a, hipStream_t s) {
     const svr_conv_geom& g = a.conv;
     const int tiles = g.To * ((g.H + CS_TY - 1) / CS_TY) * ((g.W + CS_TX - 1) / CS_TX) * (a.N / 128);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_sub_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    static uint64_t lds_attr_done = 0;               // per device (svr_common.h)
+    {
+        const int e = set_max_dynamic_lds((const void*)conv_sub_kernel, 160 * 1024, lds_attr_done);
+        if (e != 0) return e;
     }
     hipLaunchKernelGGL(conv_sub_kernel, dim3(tiles), dim3(CS_NT), CS_LDS, s, a, g_conv_band);
     return (int)hipGetLastError();

@@ -189,11 +189,10 @@ __global__ __launch_bounds__(CT_NT) void conv_thinout_kernel(const svr_gemm_args
 static int launch_conv_thinout(const svr_gemm_args& a, hipStream_t s) {
     const svr_conv_geom& g = a.conv;
     const int tiles = g.To * ((g.H + CT_TY - 1) / CT_TY) * ((g.W + CT_TX - 1) / CT_TX);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_thinout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    static uint64_t lds_attr_done = 0;               // per device (svr_common.h)
+    {
+        const int e = set_max_dynamic_lds((const void*)conv_thinout_kernel, 160 * 1024, lds_attr_done);
+        if (e != 0) return e;
     }
     hipLaunchKernelGGL(conv_thinout_kernel, dim3(tiles), dim3(CT_NT), CT_LDS, s, a);
     return (int)hipGetLastError();

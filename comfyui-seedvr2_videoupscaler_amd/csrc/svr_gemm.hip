@@ -447,11 +447,10 @@ static int launch(const svr_gemm_args& a, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
     auto kern = gemm_kernel<BM, BN, WM, WN, CONV, EPI_LDS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    static uint64_t lds_attr_done = 0;               // per device (svr_common.h)
+    {
+        const int e = set_max_dynamic_lds((const void*)kern, (int)lds, lds_attr_done);
+        if (e != 0) return e;
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS), lds, s, a);
     return (int)hipGetLastError();

@@ -92,48 +92,79 @@ def gather_batches(owned: Sequence[torch.Tensor], owned_idx: Sequence[int], n_ba
     return result
 
 
+_INT_VIEW = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}     # same-width integer view (gloo has no bf16 transport)
+
+
 def exchange_heads_p2p(heads: dict, boundaries: Sequence[int], shape: tuple, device, dtype=torch.bfloat16) -> dict:
     """Overlap heads travel point to point: the owner of batch i (rank i mod world) sends the first ``overlap`` decoded
     frames of batch i to the owner of batch i-1, which blends them into its tail (pipeline.upscale phase 3).  One
-    bf16 message of overlap x H x W x 3 per batch boundary over the direct xGMI link of that rank pair -- 149 MB per
-    boundary at 4K / overlap 3 -- instead of a dense all-reduce over every batch of the clip (round 1: 2.4 GB at
-    BASELINE config 4, growing with clip length).  Returns {i: head} for the heads THIS rank has to blend."""
+    message of overlap x H x W x 3 in the pipeline's storage dtype (``dtype``: bf16 on the HIP path -- 149 MB per boundary at
+    4K / overlap 3 --, fp32 over the fp32 double of the C ABI, so the sharded run stays bit-identical to the single-rank run
+    in every regime) per batch boundary over the direct xGMI link of that rank pair, instead of a dense all-reduce over every
+    batch of the clip (round 1: 2.4 GB at BASELINE config 4, growing with clip length).  Returns {i: head} for the heads THIS
+    rank has to blend."""
     rank, world = dist.get_rank(), dist.get_world_size()
+    iv = _INT_VIEW[torch.empty((), dtype=dtype).element_size()]
     ops, recv = [], {}
     for i in boundaries:                               # every rank walks the same boundary list in the same order
         src, dst = i % world, (i - 1) % world
         if src == dst:
             continue
         if rank == src:
-            ops.append(dist.P2POp(dist.isend, heads[i].to(device=device, dtype=dtype).contiguous().view(torch.int16), dst))
+            ops.append(dist.P2POp(dist.isend, heads[i].to(device=device, dtype=dtype).contiguous().view(iv), dst))
         elif rank == dst:
             buf = torch.empty(shape, dtype=dtype, device=device)
             recv[i] = buf
-            ops.append(dist.P2POp(dist.irecv, buf.view(torch.int16), src))
+            ops.append(dist.P2POp(dist.irecv, buf.view(iv), src))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return recv
 
 
-def upscale_sharded(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, **kw) -> torch.Tensor:
+def gather_to_root(padded: torch.Tensor, root: int = 0) -> Optional[torch.Tensor]:
+    """[cap, ...] from every rank -> [world, cap, ...] on ``root`` only (None elsewhere): world - 1 point-to-point messages
+    into the root instead of an all-gather that delivers every share to every rank -- 1/world of the traffic when only one
+    process consumes the clip (the CLI's rank 0 writes the video; inference_cli.py:1166-1288 returns results to the parent
+    process the same way)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    iv = _INT_VIEW[padded.element_size()]
+    padded = padded.contiguous()
+    if rank != root:
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, padded.view(iv), root)]):
+            req.wait()
+        return None
+    out = torch.empty((world,) + tuple(padded.shape), dtype=padded.dtype, device=padded.device)
+    out[root] = padded
+    ops = [dist.P2POp(dist.irecv, out[r].view(iv), r) for r in range(world) if r != root]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
+
+
+def upscale_sharded(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, **kw) -> Optional[torch.Tensor]:
     """pipeline.upscale() with the temporal batches dealt round-robin to the ranks of the default process group;
     every rank returns the complete clip, identical to the single-rank result (same batch boundaries, the overlap
     blend done by the owner of the blended frames).  Communication: one point-to-point message per batch boundary
-    (only with temporal_overlap > 0, exchange_heads_p2p) and ONE all-gather of the upscaled bf16 frames."""
+    (only with temporal_overlap > 0, exchange_heads_p2p) and ONE all-gather of the upscaled bf16 frames.
+    ``gather="root"``: only rank 0 receives the clip (the others return None) -- gather_to_root instead of the all-gather."""
     from . import pipeline
     force = kw.pop("force_collectives", False)         # tests: walk the collective code path even in a one-rank group
+    gather = kw.pop("gather", "all")
+    if gather not in ("all", "root"):
+        raise ValueError("gather must be 'all' or 'root'")
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return pipeline.upscale(images_thwc, runner, text_pos, **kw)
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = runner.dit.device
 
-    def exchange(heads: dict, boundaries: list, shape: tuple) -> dict:
-        return exchange_heads_p2p(heads, boundaries, shape, dev)
+    def exchange(heads: dict, boundaries: list, shape: tuple, dtype=torch.bfloat16) -> dict:
+        return exchange_heads_p2p(heads, boundaries, shape, dev, dtype)
 
     final, spans = pipeline.upscale(images_thwc, runner, text_pos, batch_filter=lambda i: i % world == rank,
                                     exchange_heads=exchange, return_spans=True, **kw)
-    # all-gather the frames each rank produced (padded to the largest share), then place them by span
+    # gather the frames each rank produced (padded to the largest share), then place them by span
     mine = torch.cat([final[a:b] for _, (a, b) in sorted(spans.items())], dim=0) if spans else final[:0]
     counts = torch.zeros(world, dtype=torch.int64, device=final.device)
     counts[rank] = mine.shape[0]
@@ -141,12 +172,17 @@ def upscale_sharded(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *
     cap = int(counts.max())
     padded = torch.zeros((cap,) + tuple(final.shape[1:]), dtype=final.dtype, device=final.device)
     padded[:mine.shape[0]] = mine
-    gathered = all_gather_frames(padded, force).reshape((world, cap) + tuple(final.shape[1:]))
     table = torch.full((final.shape[0],), -1, dtype=torch.int64, device=final.device)          # frame -> owner rank
     for _, (a, b) in spans.items():
         table[a:b] = rank
     owner = table.clone()
     dist.all_reduce(owner, op=dist.ReduceOp.MAX)
+    if gather == "root":
+        gathered = gather_to_root(padded)
+        if gathered is None:
+            return None
+    else:
+        gathered = all_gather_frames(padded, force).reshape((world, cap) + tuple(final.shape[1:]))
     out = torch.empty_like(final)
     for r in range(world):
         idx = (owner == r).nonzero(as_tuple=True)[0]             # ascending = the order rank r concatenated them in

@@ -75,12 +75,19 @@ def vae_encode_flops(cfg: VAEConfig, T: int, H: int, W: int, causal_head: bool =
 
 
 def vae_decode_flops(cfg: VAEConfig, Tl: int, h: int, w: int, merged_upsamplers: bool = False,
-                     causal_head: bool = False) -> dict:
+                     causal_head: bool = False, keep_frames: int = None) -> dict:
     """``merged_upsamplers``: count the upsamplers as the engine runs them by default (sub-pixel convs over the
     low-resolution input, subpixel.py: 3 x 2 x 2 taps per output voxel for the spatial-only one, 2 x 2 x 2 for the temporal
-    ones, no upscale_conv) instead of as the reference's upscale_conv + 3x3x3 conv.  ``causal_head``: see ``_c3``."""
+    ones, no upscale_conv) instead of as the reference's upscale_conv + 3x3x3 conv.  ``causal_head``: see ``_c3``.
+    ``keep_frames``: VideoVAEEngine.decode(keep_frames=): latents that only feed trimmed frames are dropped, and from the last
+    temporal upsampler on only the kept frames are computed."""
     ch = list(reversed(cfg.block_out_channels))
     n = len(ch)
+    tf = cfg.temporal_downsample_factor
+    if keep_frames is not None and keep_frames < 1 + (Tl - 1) * tf:
+        Tl = (keep_frames - 1 + tf - 1) // tf + 1
+    else:
+        keep_frames = None
     t, c = Tl, ch[0]
     conv = conv_flops(cfg.latent_channels, c, (3, 3, 3), t * h * w)
     m_conv, m_attn = _mid(c, t, h, w, causal_head)
@@ -97,10 +104,14 @@ def vae_decode_flops(cfg: VAEConfig, Tl: int, h: int, w: int, merged_upsamplers:
                 conv += conv_flops(c, c, (2 if temporal else 3, 2, 2), t * h * w)
                 if temporal:                               # output frame 0 reads ONE low-resolution frame (subpixel.signature(0, 2))
                     conv -= conv_flops(c, c, (1, 2, 2), h * w)
+                if keep_frames is not None and i == cfg.temporal_scale_num - 1:
+                    t = min(t, keep_frames)                # (the upsampler itself still produced every frame of its slice)
                 continue
             conv += conv_flops(c, c * 4 * rz, (1, 1, 1), t * h * w)
             t, h, w = (t * 2 - 1 if temporal else t), h * 2, w * 2
             conv += _c3(c, c, t, h * w, causal_head)
+            if keep_frames is not None and i == cfg.temporal_scale_num - 1:
+                t = min(t, keep_frames)
     conv += _c3(c, cfg.out_channels, t, h * w, causal_head)
     return {"conv": conv, "attn": m_attn, "total": conv + m_attn}
 
@@ -117,19 +128,19 @@ def _tiles(total, tile, overlap):
 
 
 def vae_flops_tiled(cfg: VAEConfig, T: int, H: int, W: int, tiled: bool, tile=(1024, 1024), overlap=(128, 128),
-                    merged_upsamplers: bool = False, causal_head: bool = False) -> dict:
+                    merged_upsamplers: bool = False, causal_head: bool = False, keep_frames: int = None) -> dict:
     """Encode + decode FLOPs of one clip [T, H, W] (pixels), with the reference's tile grid if tiled."""
     s = cfg.spatial_downsample_factor
     Tl = (T - 1) // cfg.temporal_downsample_factor + 1
     Hl, Wl = (H + s - 1) // s, (W + s - 1) // s
     if not tiled or (H <= tile[0] and W <= tile[1]):
         return {"encode": vae_encode_flops(cfg, T, H, W, causal_head)["total"],
-                "decode": vae_decode_flops(cfg, Tl, Hl, Wl, merged_upsamplers, causal_head)["total"]}
+                "decode": vae_decode_flops(cfg, Tl, Hl, Wl, merged_upsamplers, causal_head, keep_frames)["total"]}
     lth, ltw = tile[0] // s, tile[1] // s
     loh, low = min(overlap[0] // s, lth - 1), min(overlap[1] // s, ltw - 1)
     enc = dec = 0.0
     for (y0, y1) in _tiles(Hl, lth, loh):
         for (x0, x1) in _tiles(Wl, ltw, low):
             enc += vae_encode_flops(cfg, T, min(y1 * s, H) - y0 * s, min(x1 * s, W) - x0 * s, causal_head)["total"]
-            dec += vae_decode_flops(cfg, Tl, y1 - y0, x1 - x0, merged_upsamplers, causal_head)["total"]
+            dec += vae_decode_flops(cfg, Tl, y1 - y0, x1 - x0, merged_upsamplers, causal_head, keep_frames)["total"]
     return {"encode": enc, "decode": dec}

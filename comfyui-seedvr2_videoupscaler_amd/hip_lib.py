@@ -4,6 +4,7 @@ The library is the product: if it is missing or fails to load, every op raises -
 CPU / eager-PyTorch fallback on purpose (a silent fallback would void every parity claim).
 """
 import ctypes as C
+import hashlib
 import os
 import subprocess
 import sys
@@ -83,6 +84,7 @@ SYMBOLS = {
     "svr_set_option": (C.c_int, [C.c_char_p, _i32]),
     "svr_last_error": (C.c_char_p, []),
     "svr_abi_version": (C.c_int, []),
+    "svr_build_id": (C.c_char_p, []),
     "svr_device_info": (C.c_int, [C.c_char_p, _i32]),
 }
 
@@ -97,11 +99,33 @@ def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] + [INCLUDE]
 
 
+def source_id() -> str:
+    """hex SHA-256 over the library's sources (names and contents, sorted by name): what svr_build_id() of a current build returns."""
+    h = hashlib.sha256()
+    for path in sources():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def built_id(path: str = None):
+    """The build id of the binary at ``path``, read from the FILE (the marker svr_build_id() returns a pointer into): dlopen
+    would hand back an already-loaded older mapping of the same path.  None: no such file / no marker."""
+    import re
+    try:
+        with open(path or LIB_PATH, "rb") as f:
+            m = re.search(rb"SVR_BUILD_ID=([0-9a-f]{64}|unknown)", f.read())
+        return m.group(1).decode() if m else None
+    except OSError:
+        return None
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
-        return True
-    mt = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(s) > mt for s in sources())
+    """True unless the binary was compiled from exactly the sources next to it (content hash embedded at build time -- file times
+    say nothing after a `git checkout`, and a stale binary newer than the sources would otherwise load silently)."""
+    return not os.path.exists(LIB_PATH) or built_id() != source_id()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -112,7 +136,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     extra = ["-DSVR_ABLATIONS"] if os.environ.get("SVR_BUILD_ABLATIONS") else []   # measurement-only kernel variants
-    cmd = [hipcc] + HIPCC_FLAGS + extra + [os.path.join(CSRC, "svr_api.hip"), "-o", LIB_PATH]
+    cmd = [hipcc] + HIPCC_FLAGS + extra + [f'-DSVR_BUILD_ID="{source_id()}"', os.path.join(CSRC, "svr_api.hip"), "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -142,6 +166,10 @@ def lib():
         fn.restype, fn.argtypes = res, args
     if handle.svr_abi_version() != ABI_VERSION:
         raise HipLibraryError("libseedvr2_hip.so ABI version mismatch; rebuild")
+    if handle.svr_build_id().decode() != source_id():
+        raise HipLibraryError(f"{LIB_PATH} was built from other sources than the ones next to it (build id "
+                              f"{handle.svr_build_id().decode()[:12]}, sources {source_id()[:12]}): rebuild with "
+                              "`python -c 'import __graft_entry__ as g; g.build()'`")
     # measurement knobs from the environment, e.g. SVR_OPTIONS="conv_rows=8,gemm_epi=1" (svr_set_option keys; an unknown key
     # or a malformed item is an error, not a silently ignored setting)
     for item in filter(None, (t.strip() for t in os.environ.get("SVR_OPTIONS", "").split(","))):

@@ -15,6 +15,7 @@ models and every intermediate tensor resident.
 what the CPU tests inspect.
 """
 import os
+import threading
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -219,6 +220,7 @@ def load_text_embedding(device, model_dir: Optional[str] = None) -> torch.Tensor
 
 
 _RUNNERS: Dict[Tuple, Any] = {}                   # (dit path, vae path, device, tiling) -> runner with resident engines
+_RUNNERS_LOCK = threading.Lock()                  # ComfyUI may execute nodes from several threads
 
 
 def get_runner(dit_cfg: Dict[str, Any], vae_cfg: Dict[str, Any], model_dir: Optional[str] = None):
@@ -230,7 +232,18 @@ def get_runner(dit_cfg: Dict[str, Any], vae_cfg: Dict[str, Any], model_dir: Opti
     tile = (bool(vae_cfg.get("encode_tiled")), int(vae_cfg.get("encode_tile_size", 1024)), int(vae_cfg.get("encode_tile_overlap", 128)),
             bool(vae_cfg.get("decode_tiled")), int(vae_cfg.get("decode_tile_size", 1024)), int(vae_cfg.get("decode_tile_overlap", 128)))
     key = (dit_path, vae_path, device, tile)
+    with _RUNNERS_LOCK:
+        return _get_runner_locked(key, dit_path, vae_path, device, tile)
+
+
+def _get_runner_locked(key, dit_path, vae_path, device, tile):
+    from . import checkpoint, ops as ops_mod, runner as runner_mod
     if key not in _RUNNERS:
+        # one resident model set per process: drop the old one BEFORE building its replacement (two full sets plus the
+        # fragment-ordered weight copies would otherwise sit in HBM during the load)
+        _RUNNERS.clear()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
         ops = ops_mod.HipOps(device)              # raises loudly when the HIP library is missing: no fallback
         dit, vae = checkpoint.build_engines(ops, dit_path, vae_path)
         r = runner_mod.VideoDiffusionInfer(
@@ -239,7 +252,6 @@ def get_runner(dit_cfg: Dict[str, Any], vae_cfg: Dict[str, Any], model_dir: Opti
             decode_tile_overlap=(tile[5], tile[5]))
         r.dit, r.vae = dit, vae
         r.configure_diffusion(device=torch.device(device), dtype=torch.bfloat16)
-        _RUNNERS.clear()                          # one resident model set per process
         _RUNNERS[key] = r
     return _RUNNERS[key]
 

@@ -95,8 +95,8 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
             batch_filter: Optional[Callable[[int], bool]] = None,
             progress: Optional[Callable[[str, int, int], None]] = None,
             noise_provider: Optional[Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None,
-            exchange_heads: Optional[Callable[[dict, list, tuple], dict]] = None,
-            return_spans: bool = False, skip_trimmed_frames: bool = False):
+            exchange_heads: Optional[Callable[[dict, list, tuple, torch.dtype], dict]] = None,
+            return_spans: bool = False, skip_trimmed_frames: bool = True):
     """images [T, H, W, 3] in [0, 1] (any float dtype, on the runner's device) -> upscaled [T, H', W', 3] in [0, 1].
 
     ``batch_filter(i)`` restricts phases 1-3 to the temporal batches a rank owns (data parallelism over
@@ -175,8 +175,8 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
         ori = plan.end - plan.start
         n_new = ori if (i == 0 or overlap == 0) else max(ori - overlap, 0)
         if i in upscaled:
-            # (skip_trimmed_frames: the decoder is causal in time, so our runner can leave out the padding frames that are
-            # trimmed two lines down -- same result; off by default until it has run on the GPU path: DESIGN.md 7)
+            # (skip_trimmed_frames: the decoder is causal in time, so our runner leaves out the padding frames that are trimmed
+            # two lines down -- same result, bit for bit on the HIP path (tools/gpu_r3_keep_frames.sh, round 3))
             sample = (runner.vae_decode([upscaled.pop(i)], keep_frames=[ori])[0]
                       if skip_trimmed_frames and _takes_keep_frames(runner) else runner.vae_decode([upscaled.pop(i)])[0])
             if sample.dim() == 3:
@@ -199,7 +199,7 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
         # batch boundaries that carry an overlap blend -- a function of the plans alone, so every rank derives the same list
         # and the point-to-point exchange posts matching sends and receives
         boundaries = [i for i, plan in enumerate(plans) if i > 0 and 0 < overlap < plan.end - plan.start and starts[i] >= overlap]
-        for i, head in exchange_heads(heads, boundaries, (overlap, true_h, true_w, 3)).items():
+        for i, head in exchange_heads(heads, boundaries, (overlap, true_h, true_w, 3), dt).items():    # (heads travel in the storage dtype)
             if (i - 1) in spans and i not in spans:
                 w = starts[i]
                 final[w - overlap:w] = transforms.blend_overlapping_frames(final[w - overlap:w], head.to(final), overlap)

@@ -547,7 +547,8 @@ class VideoVAEEngine:
                     st["__produced__"] = done + h.shape[0]
                     n = max(1, min(h.shape[0], st["__keep__"] - done))
                     if n < h.shape[0]:
-                        assert st.get("__last_slice__", False)
+                        if not st.get("__last_slice__", False):   # (decode_clip trims the latents so that only the last slice is cut)
+                            raise RuntimeError("keep_frames cuts a temporal slice that is not the clip's last one")
                         h, hs = h[:n], (hs[:n] if hs is not None else None)
         h = self._gn(self.dec_norm_out, h, True, hs)
         return self._conv(self.dec_conv_out, h, st, first)
@@ -582,6 +583,14 @@ class VideoVAEEngine:
     def decode_clip(self, z_thwc: torch.Tensor, latents_per_slice: Optional[int] = None,
                     keep_frames: Optional[int] = None) -> torch.Tensor:
         """[T', h, w, 16] -> [T, 8h, 8w, 3] (the first ``keep_frames`` frames of it: see decode)."""
+        tf = self.cfg.temporal_downsample_factor
+        if keep_frames is not None:
+            if keep_frames < 1:
+                raise ValueError("keep_frames must be >= 1")
+            if keep_frames >= 1 + (z_thwc.shape[0] - 1) * tf:
+                keep_frames = None                                   # nothing to trim
+            else:                                                    # latent j > 0 first shows in output frame tf (j - 1) + 1:
+                z_thwc = z_thwc[:(keep_frames - 1 + tf - 1) // tf + 1]     # drop the latents that only feed trimmed frames
         Tl, h, w, _ = z_thwc.shape
         if latents_per_slice is None:
             s = self.cfg.spatial_downsample_factor
@@ -650,14 +659,8 @@ class VideoVAEEngine:
         lat = latent_thwc.to(device=self.device, dtype=self.ops.act_dtype).contiguous()
         if lat.dim() == 3:
             lat = lat.unsqueeze(0)
-        tf = cfg.temporal_downsample_factor
-        if keep_frames is not None:
-            if keep_frames < 1:
-                raise ValueError("keep_frames must be >= 1")
-            if keep_frames >= 1 + (lat.shape[0] - 1) * tf:
-                keep_frames = None
-            else:
-                lat = lat[:(keep_frames - 1 + tf - 1) // tf + 1].contiguous()     # latent j > 0 first shows in output frame tf (j - 1) + 1
+        if keep_frames is not None and keep_frames < 1:
+            raise ValueError("keep_frames must be >= 1")
         Tl, H, W, lc = lat.shape
         z = ops.empty(Tl, H, W, lc)
         # latent / scale + shift  ==  (latent - (-shift*scale)) * (1/scale)

@@ -112,10 +112,7 @@ def load_frames(path: str, skip: int = 0, cap: int = 0):
     ext = os.path.splitext(path)[1].lower()
     fps = 30.0
     if os.path.isdir(path):
-        files = sorted(f for f in os.listdir(path) if os.path.splitext(f)[1].lower() in IMAGE_EXT)
-        if not files:
-            raise ValueError(f"no images in {path}")
-        frames = torch.cat([load_frames(os.path.join(path, f))[0] for f in files], dim=0)
+        raise ValueError(f"{path} is a directory: main() runs each media file in it as its own job (list_inputs)")
     elif ext in TENSOR_EXT:
         t = torch.load(path, weights_only=True) if ext == ".pt" else torch.from_numpy(np.load(path))
         frames = t.float()
@@ -174,6 +171,28 @@ def save_frames(frames, path: str, fmt: str, fps: float = 30.0):
         w.release()
 
 
+def list_inputs(path: str) -> List[str]:
+    """A directory input = one job per media file in it (images AND videos, sorted by name), as the reference's CLI processes
+    a folder (inference_cli.py: get_media_files / process_single_file): files of different sizes never meet in one clip and
+    unrelated images are not blended through the temporal overlap.  A file input = that one job."""
+    if not os.path.isdir(path):
+        return [path]
+    files = sorted(os.path.join(path, f) for f in os.listdir(path)
+                   if os.path.splitext(f)[1].lower() in IMAGE_EXT | VIDEO_EXT | TENSOR_EXT)
+    if not files:
+        raise ValueError(f"no images, videos or tensors in {path}")
+    return files
+
+
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def default_output(inp: str, fmt: str) -> str:
     stem = os.path.splitext(os.path.basename(os.path.normpath(inp)))[0]
     return os.path.join("output", f"{stem}_upscaled" + ("" if fmt == "png_dir" else f".{fmt}"))
@@ -199,8 +218,10 @@ def run(args, frames):
               prepend_frames=args.prepend_frames, color_correction=args.color_correction,
               input_noise_scale=args.input_noise_scale, latent_noise_scale=args.latent_noise_scale, seed=args.seed)
     t0 = time.time()
-    fn = dist_mod.upscale_sharded if world > 1 else pipeline.upscale
-    out = fn(frames.to(runner.dit.device), runner, text, **kw)
+    if world > 1:                                      # only rank 0 writes the result: gather the frames there, not everywhere
+        out = dist_mod.upscale_sharded(frames.to(runner.dit.device), runner, text, gather="root", **kw)
+    else:
+        out = pipeline.upscale(frames.to(runner.dit.device), runner, text, **kw)
     torch.cuda.synchronize()
     if rank == 0:
         dt = time.time() - t0
@@ -218,18 +239,22 @@ def main(argv: Optional[List[str]] = None) -> int:
         env = dict(os.environ, HIP_VISIBLE_DEVICES=",".join(devices))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={len(devices)}", "--master-addr",
-               "127.0.0.1", "--master-port", "29533", os.path.abspath(__file__)] + (argv if argv is not None else sys.argv[1:])
+               "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + (argv if argv is not None else sys.argv[1:])
         return subprocess.call(cmd, env=env)
     if len(devices) == 1 and "WORLD_SIZE" not in os.environ and devices[0] != "0":
         os.environ.setdefault("HIP_VISIBLE_DEVICES", devices[0])
-    frames, fps = load_frames(args.input, args.skip_first_frames, args.load_cap)
-    out, rank = run(args, frames)
-    if rank == 0:
-        ext = os.path.splitext(args.input)[1].lower()
-        fmt = args.output_format or ("mp4" if ext in VIDEO_EXT else "pt" if ext in TENSOR_EXT else "png")
-        path = args.output or default_output(args.input, fmt if not (fmt == "png" and out.shape[0] > 1) else "png_dir")
-        save_frames(out, path, fmt, fps)
-        print(f"Saved: {path}")
+    jobs = list_inputs(args.input)
+    for inp in jobs:                                   # the engines stay resident between jobs (interfaces.get_runner)
+        frames, fps = load_frames(inp, args.skip_first_frames, args.load_cap)
+        out, rank = run(args, frames)
+        if rank == 0:
+            ext = os.path.splitext(inp)[1].lower()
+            fmt = args.output_format or ("mp4" if ext in VIDEO_EXT else "pt" if ext in TENSOR_EXT else "png")
+            path = default_output(inp, fmt if not (fmt == "png" and out.shape[0] > 1) else "png_dir")
+            if args.output:                            # one job: the path as given; a folder of jobs: a directory to fill
+                path = args.output if len(jobs) == 1 else os.path.join(args.output, os.path.basename(path))
+            save_frames(out, path, fmt, fps)
+            print(f"Saved: {path}")
     return 0
 
 

@@ -188,3 +188,102 @@ def reference_glue():
               "_hue_conditional_saturation_match", "_histogram_match_1d", "wavelet_adaptive_color_correction",
               "_get_saturation_map"], ns)
     return ns
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The reference's four phase functions THEMSELVES (generation_phases.py:171 encode_all_batches, :542 upscale_all_batches,
+# :807 decode_all_batches, :1060 postprocess_all_batches + their three private helpers), compiled from the unmodified source
+# text, so a test can drive them over this repo's runner (the drop-in claim of INTEGRATION.md).  What the namespace provides
+# instead of the reference's own modules, and why:
+#   * torchvision (third-party, not installed): Compose / Lambda / Normalize stand-ins, TVF.resize as in reference_glue();
+#   * memory management (manage_tensor, manage_model_device, release_*, cleanup_*): host-RAM / VRAM policy, out of scope
+#     (SURVEY.md 8 "out of scope") -- manage_tensor keeps its contract (move + cast), the others are no-ops;
+#   * materialize_model / apply_model_specific_config / load_text_embeddings / process_alpha_for_batch: model management and
+#     the alpha path -- they raise if the phases ever reach them;
+#   * everything else (pad_video_temporal, blend_overlapping_frames, setup_video_transform, prepare_video_transforms,
+#     calculate_optimal_batch_params, check_interrupt, ensure_precision_initialized, set_seed, the optimized_* rearranges,
+#     NaResize / SideResize / DivisiblePad, the colour-fix functions) runs from the reference text.
+class PhaseDebug:
+    """Debug stand-in: swallows the phases' logging / timing calls (src/utils/debug.py is console output only)."""
+    encode_tile_boundaries = None
+    decode_tile_boundaries = None
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+def reference_phases(torch_module=None):
+    """-> namespace dict with the four phase functions.  ``torch_module``: what the phases see as ``torch`` (a proxy lets a
+    test inject the noise a golden was made with); default: torch itself."""
+    import typing
+    import random
+    import numpy as np
+    import torch
+    ns = reference_glue()
+    tm = torch_module if torch_module is not None else torch
+
+    class Compose:
+        def __init__(self, transforms):
+            self.transforms = list(transforms)
+
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+
+    class Lambda:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def __call__(self, x):
+            return self.fn(x)
+
+    class Normalize:                                   # torchvision.transforms.Normalize on a [..., C, H, W] float tensor
+        def __init__(self, mean, std):
+            self.mean, self.std = mean, std
+
+        def __call__(self, x):
+            return (x - self.mean) / self.std
+
+    def manage_tensor(tensor, target_device, tensor_name="", dtype=None, non_blocking=False, debug=None, reason=None,
+                      indent_level=0):
+        return tensor.to(device=target_device, dtype=dtype if dtype is not None else tensor.dtype)
+
+    def _never(name):
+        def f(*a, **k):
+            raise AssertionError(f"{name}() is model management / alpha handling: the phases must not need it over a ready runner")
+        return f
+
+    noop = lambda *a, **k: None
+    ns.update({"torch": tm, "os": os, "Dict": typing.Dict, "List": typing.List, "Optional": typing.Optional, "Tuple": typing.Tuple,
+               "Any": typing.Any, "Callable": typing.Callable, "Union": typing.Union, "Literal": typing.Literal,
+               "random": random, "np": np, "get_global_rank": lambda: 0,
+               "Compose": Compose, "Lambda": Lambda, "Normalize": Normalize, "AreaResize": None, "Resize": None, "CenterCrop": None,
+               "manage_tensor": manage_tensor, "manage_model_device": noop, "release_tensor_memory": noop,
+               "release_tensor_collection": noop, "cleanup_dit": noop, "cleanup_vae": noop, "cleanup_text_embeddings": noop,
+               "materialize_model": _never("materialize_model"), "apply_model_specific_config": _never("apply_model_specific_config"),
+               "load_text_embeddings": _never("load_text_embeddings"), "process_alpha_for_batch": _never("process_alpha_for_batch"),
+               "_draw_tile_boundaries": _never("_draw_tile_boundaries"), "script_directory": None})
+    _extract("src/common/seed.py", ["set_seed"], ns)
+    _extract("src/optimization/performance.py",
+             ["optimized_video_rearrange", "optimized_single_video_rearrange", "optimized_sample_to_image_format"], ns)
+    _extract("src/data/image/transforms/na_resize.py", ["NaResize"], ns)
+    _extract("src/core/generation_utils.py",
+             ["prepare_video_transforms", "setup_video_transform", "calculate_optimal_batch_params", "check_interrupt",
+              "ensure_precision_initialized"], ns)
+    _extract("src/core/generation_phases.py",
+             ["_prepare_video_batch", "_apply_4n1_padding", "_reconstruct_and_transform_batch", "encode_all_batches",
+              "upscale_all_batches", "decode_all_batches", "postprocess_all_batches"], ns)
+    return ns
+
+
+def phase_context(device, compute_dtype, text):
+    """The keys of setup_generation_context's dict (generation_utils.py:315-419) that the four phases read, for a runner whose
+    models are resident: no offload devices, no model cache, no interrupt hook."""
+    import torch
+    dev = torch.device(device)
+    return {"vae_device": dev, "dit_device": dev, "vae_offload_device": None, "dit_offload_device": None,
+            "tensor_offload_device": None, "compute_dtype": compute_dtype, "interrupt_fn": None, "video_transform": None,
+            "text_embeds": {"texts_pos": [text], "texts_neg": [text]},
+            "cache_context": {"vae_cache": False, "dit_cache": False, "cached_vae": None, "cached_dit": None,
+                              "vae_newly_cached": False, "dit_newly_cached": False}}

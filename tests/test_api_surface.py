@@ -193,3 +193,20 @@ def test_engines_answer_module_style_probes():
         assert p.device.type == "cpu" and p.dtype in (torch.float32, torch.bfloat16)
         assert m.eval() is m and m.to("cpu") is m and m.requires_grad_(False) is m
         assert sum(1 for _ in m.parameters()) > 10
+
+
+def test_cli_directory_input_is_one_job_per_media_file(tmp_path):
+    """A folder is processed file by file (images and videos, sorted), as the reference's CLI does -- never concatenated into
+    one clip; a file is one job."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("svr_cli", os.path.join(ROOT, "inference_cli.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    for name in ("b.png", "a.jpg", "clip.mp4", "notes.txt", "t.pt"):
+        (tmp_path / name).write_bytes(b"x")
+    jobs = cli.list_inputs(str(tmp_path))
+    assert [os.path.basename(j) for j in jobs] == ["a.jpg", "b.png", "clip.mp4", "t.pt"]
+    assert cli.list_inputs(str(tmp_path / "b.png")) == [str(tmp_path / "b.png")]
+    with pytest.raises(ValueError):
+        cli.load_frames(str(tmp_path))
+    assert cli.free_port() > 0

@@ -32,6 +32,8 @@ def test_library_builds_loads_and_exports_header_symbols():
     lib.svr_abi_version.restype = ctypes.c_int
     assert lib.svr_abi_version() == hip_lib.ABI_VERSION == 5
     assert hip_lib.lib().svr_abi_version() == 5
+    # the binary carries the content hash of the sources it was compiled from; the loader refuses any other
+    assert hip_lib.built_id() == hip_lib.source_id() and not hip_lib.needs_build()
 
 
 def test_struct_layout_matches_header():
@@ -76,3 +78,19 @@ def test_svr_options_environment_reaches_the_library():
     for bad in ("no_such_key=1", "conv_rows"):
         r = subprocess.run([sys.executable, "-c", code], env=dict(env, SVR_OPTIONS=bad), capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "SVR_OPTIONS" in r.stderr
+
+
+@pytest.mark.skipif(not HAVE_HIPCC, reason="hipcc not available")
+def test_loader_refuses_a_binary_built_from_other_sources(tmp_path, monkeypatch):
+    """svr_build_id() is the content hash of the sources the binary was compiled from: after any source edit (here: one more
+    header in the source list) the library counts as stale -- build() would recompile, lib() refuses to load it."""
+    hip_lib = sub("hip_lib")
+    hip_lib.build()
+    extra = tmp_path / "svr_extra.h"
+    extra.write_text("// an edit\n")
+    real = hip_lib.sources
+    monkeypatch.setattr(hip_lib, "sources", lambda: real() + [str(extra)])
+    assert hip_lib.needs_build()
+    monkeypatch.setattr(hip_lib, "_lib", None)
+    with pytest.raises(hip_lib.HipLibraryError, match="other sources"):
+        hip_lib.lib()

@@ -95,7 +95,7 @@ def test_gather_batches_with_a_rank_that_owns_nothing():
     assert all(ok for _, ok in res)
 
 
-def _pipeline_worker(rank, world, port, q, noise=0.0):
+def _pipeline_worker(rank, world, port, q, noise=0.0, case=None, gather="all"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
@@ -104,11 +104,10 @@ def _pipeline_worker(rank, world, port, q, noise=0.0):
     from test_glue import _IdentityRunner
     d = _sub("dist")
     d.init_from_env(backend="gloo")
-    images = torch.rand(23, 16, 24, 3, generator=torch.Generator().manual_seed(5))
-    kw = dict(resolution=32, batch_size=7, uniform_batch_size=True, temporal_overlap=2, color_correction="wavelet",
-              input_noise_scale=noise)
-    out = d.upscale_sharded(images, _IdentityRunner(), torch.zeros(58, 8), **kw)
-    q.put((rank, out.float()))
+    frames, kw = case or (23, dict(resolution=32, batch_size=7, uniform_batch_size=True, temporal_overlap=2, color_correction="wavelet"))
+    images = torch.rand(frames, 16, 24, 3, generator=torch.Generator().manual_seed(5))
+    out = d.upscale_sharded(images, _IdentityRunner(), torch.zeros(58, 8), input_noise_scale=noise, gather=gather, **kw)
+    q.put((rank, None if out is None else out.float()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -136,3 +135,36 @@ def test_sharded_pipeline_equals_single_rank_with_overlap_blend(world, noise):
         assert p.exitcode == 0
     for _, out in res:
         assert out.shape == want.shape and torch.equal(out, want)
+
+
+CFG4_PLAN = (128, dict(resolution=32, batch_size=17, uniform_batch_size=True, temporal_overlap=1, color_correction="lab"))
+
+
+@pytest.mark.parametrize("gather", ["all", "root"])
+def test_world8_cfg4_plan_equals_single_rank(gather):
+    """BASELINE config 4's plan on 8 ranks (what bench.py --workload cfg4 --gpus 8 runs): a 128-frame clip = 8 temporal batches
+    of 17 with a 1-frame overlap (the last one 9 frames, padded to 17), one batch per rank, 7 point-to-point overlap heads
+    between neighbouring ranks, then the frame gather -- to every rank, or (``gather="root"``, the CLI's case) to rank 0 only.
+    Bit-equal to the single-rank pipeline."""
+    from test_glue import _IdentityRunner
+    pipeline = sub("pipeline")
+    frames, kw = CFG4_PLAN
+    plans, ov = pipeline.plan_batches(frames, kw["batch_size"], kw["temporal_overlap"], kw["uniform_batch_size"])
+    assert len(plans) == 8 and ov == 1 and plans[-1].end - plans[-1].start == 16 and plans[-1].uniform_pad == 1
+    images = torch.rand(frames, 16, 24, 3, generator=torch.Generator().manual_seed(5))
+    want = pipeline.upscale(images, _IdentityRunner(), torch.zeros(58, 8), **kw).float()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 8, port, q, 0.0, CFG4_PLAN, gather)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, out in res.items():
+        if gather == "root" and r != 0:
+            assert out is None
+        else:
+            assert out.shape == want.shape and torch.equal(out, want), r

@@ -206,6 +206,12 @@ def test_flop_model_counts_what_the_engine_launches():
         for ph in (0, 1):
             assert abs((got[a][ph] - got[b][ph]) - (model[a][ph] - model[b][ph])) <= 1e-9 * model[a][ph]
     assert got[True, True][0] < got[True, False][0] and got[True, True][1] < got[True, False][1] < got[False, False][1]
+    # decode(keep_frames=): the frames the caller trims are not computed, and the model counts the same launches
+    for keep in (8, 5, 2):
+        ops = Counting("cpu", act_dtype=torch.float32)
+        vae.VideoVAEEngine(cfg, sd, ops).decode(z, latents_per_slice=1, keep_frames=keep)
+        f = flops.vae_decode_flops(cfg, z.shape[0], H // 8, W // 8, True, True, keep_frames=keep)["total"]
+        assert abs(ops.macs / f - 1) < 1e-4 and f < model[True, True][1], (keep, ops.macs, f)     # (slack: decoder conv_in's K pad)
 
 
 def test_dit_engine_host_logic_matches_reference_golden():
@@ -235,6 +241,19 @@ def test_dit_engine_7b_family_matches_reference_golden_and_oracle():
     vid, t2 = torch.randn(5, 36, 60, 33), torch.randn(58, 5120)
     want = dit_oracle.dit_forward(sd, cfg, vid, t2, 1000.0, windows_mod=windows)
     assert rel_err(eng.forward(vid, t2, 1000.0), want) < 1e-5
+
+
+def test_dit_engine_7b_production_width_host_logic_matches_reference_golden():
+    """The 7B family's host logic at PRODUCTION width (3072 / 24 heads: 60 rotated dims, GELU MLP of 12288, rope tables per
+    window extent) over the fp32 torch double of the C ABI == the imported reference's dit_7b code (tests/golden/dit7b_w2l_crop.pt)."""
+    from oracle import make_golden as mg
+    config, weights, dit = sub("config"), sub("weights"), sub("dit")
+    g = torch.load(os.path.join(GOLDEN, "dit7b_w2l_crop.pt"), weights_only=True)
+    txt = torch.load(os.path.join(GOLDEN, "text_pos_emb.pt"), weights_only=True)
+    cfg = mg.dit7b_r3_config(config)
+    eng = dit.NaDiTEngine(cfg, weights.synth_dit_state_dict(cfg, seed=g["seed_weights"]), TorchOps("cpu", act_dtype=torch.float32))
+    out = eng.forward(mg.dit_inputs(*g["latent"], seed=g["seed_input"]).float(), txt.float(), 1000.0)
+    assert rel_err(out, g["out"]) < 2e-5
 
 
 def test_dit_engine_ragged_grid_vs_oracle():
