@@ -23,6 +23,7 @@
 #include "../../include/seedvr2_hip.h"
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace svr {
 
@@ -225,6 +226,150 @@ SVR_DEVICE void epilogue_store8(const svr_gemm_args& a, const float (&acc8)[8], 
     }
 }
 
+// Epilogue through LDS, shared by the GEMM kernels below.  Lane holds C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) + 0..3] in
+// acc[i][j] (wave tile WM x WN at (wm0, wn0) of the BM x BN block tile); the caller has passed its last K-loop barrier and no
+// LDS-DMA is in flight (smem is free).  Passes of RI row fragments per wave are parked as fp32 [rows][BN + 4] and leave
+// row-contiguous, 8 columns (16 bytes of bf16) per thread, so every global store / residual load instruction covers whole
+// 128-byte lines.  (For short-K problems -- 1x1 convs, the pixel-shuffle upsamplers: 2 .. 8 K tiles per output tile -- the direct
+// epilogue's 8-byte scattered stores, 16 rows x 32 bytes per instruction, were most of the kernel's time.)
+// Round 3: the store side runs in branch-free sweeps of four rows per thread -- their LDS reads, then their residual loads,
+// are all in flight before the first store -- and a pass parks four row fragments per wave where LDS allows it (half the
+// barriers).  Measured on gemm_w4_kernel (one workgroup per CU: nothing else covers a tile's epilogue), the row-at-a-time
+// form cost 16-40 % of the kernel (profiles/r3_gemm_w4_ablations.txt).
+template <int BM, int BN, int WM, int WN> constexpr int epilogue_lds_bytes() {
+    return (BM / WM) * ((WM / 16) % 4 == 0 ? 4 : 2) * 16 * (BN * 4 + 16);
+}
+template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES>
+SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const f32x4 (&acc)[WM / 16][WN / 16], char* smem, int m0, int n0,
+                                     int tid, int lane, int wave) {
+    constexpr int WAVES_N = BN / WN, FM = WM / 16, FN = WN / 16;
+    const int frow = lane & 15, ng = (lane >> 4) * 4;
+    const int wn0 = (wave % WAVES_N) * WN;
+    constexpr int WAVES_M = BM / WM;
+    constexpr int RI = FM % 4 == 0 ? 4 : 2;
+    constexpr int PASS_ROWS = WAVES_M * RI * 16;
+    constexpr int PITCH = BN * 4 + 16;
+    constexpr int CH = BN / 8, ROWS_IT = NTHREADS / CH, ITERS = PASS_ROWS / ROWS_IT;
+    constexpr int SW = ITERS % 4 == 0 ? 4 : (ITERS % 2 == 0 ? 2 : 1);       // rows per sweep
+    static_assert(PASS_ROWS * PITCH <= LDS_BYTES && FM % RI == 0 && PASS_ROWS % ROWS_IT == 0, "epilogue staging fits the LDS allocation");
+    const int c8 = tid % CH, r_it = tid / CH;
+    const int n = n0 + c8 * 8;
+    const bool swiglu = a.epilogue == SVR_EPI_SWIGLU;
+    const bool col_ok = n < a.N && !(swiglu && (c8 & 2));      // SwiGLU: "in" blocks are consumed by their gate block's threads
+    float bias8[8], gate8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; gate8[e] = 1.f; }
+    if (col_ok && !swiglu) {
+        if (a.bias) {
+            const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
+            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+            bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
+        if (a.gate && a.epilogue == SVR_EPI_RESID_GATE) {
+            const float4 g0 = *(const float4*)(a.gate + n), g1 = *(const float4*)(a.gate + n + 4);
+            gate8[0] = g0.x; gate8[1] = g0.y; gate8[2] = g0.z; gate8[3] = g0.w;
+            gate8[4] = g1.x; gate8[5] = g1.y; gate8[6] = g1.z; gate8[7] = g1.w;
+        }
+    }
+    // plain [M, ldc] output (no pixel shuffle / phase scatter): the sweep form; otherwise row by row through epilogue_store8
+    const bool plain = !a.ps.enabled && !a.phase.enabled;
+    const int epi = a.epilogue;
+    const bool with_gate = epi == SVR_EPI_RESID_GATE && a.gate != nullptr;
+    const bool with_resid = epi == SVR_EPI_RESID_GATE && a.resid != nullptr;
+#pragma unroll
+    for (int p = 0; p < FM / RI; ++p) {
+        if (p > 0) __syncthreads();                     // the previous pass has been read out
+#pragma unroll
+        for (int ii = 0; ii < RI; ++ii) {
+            char* row = smem + (((wave / WAVES_N) * RI + ii) * 16 + frow) * PITCH;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) *(f32x4*)(row + (wn0 + 16 * j + ng) * 4) = acc[p * RI + ii][j];
+        }
+        __syncthreads();
+        if (!col_ok) continue;
+#pragma unroll
+        for (int s0 = 0; s0 < ITERS; s0 += SW) {
+            int mrow[SW];
+            bool ok[SW];
+            f32x4 lo[SW], hi[SW], ul[SW], uh[SW];
+#pragma unroll
+            for (int it = 0; it < SW; ++it) {
+                const int lr = (s0 + it) * ROWS_IT + r_it;  // parked row -> (wave row, fragment, row in fragment)
+                mrow[it] = m0 + (lr / (RI * 16)) * WM + 16 * (p * RI + ((lr >> 4) % RI)) + (lr & 15);
+                ok[it] = mrow[it] < a.M;
+                const char* src = smem + lr * PITCH + c8 * 32;
+                lo[it] = *(const f32x4*)src;
+                hi[it] = *(const f32x4*)(src + 16);
+                if (swiglu) { ul[it] = *(const f32x4*)(src + 64); uh[it] = *(const f32x4*)(src + 80); }
+            }
+            if (!plain) {
+#pragma unroll
+                for (int it = 0; it < SW; ++it) {
+                    if (!ok[it]) continue;
+                    const float v8[8] = {lo[it][0], lo[it][1], lo[it][2], lo[it][3], hi[it][0], hi[it][1], hi[it][2], hi[it][3]};
+                    const float u8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    epilogue_store8(a, v8, u8, mrow[it], n, bias8, gate8);
+                }
+                continue;
+            }
+            // residual rows of the sweep (out-of-range rows read row M - 1 and are masked at the store)
+            float r8[SW][8];
+            if (with_resid) {
+                if (a.resid_f32) {
+#pragma unroll
+                    for (int it = 0; it < SW; ++it) load8<true>(a.resid, (int64_t)min(mrow[it], a.M - 1) * a.ldr + n, r8[it]);
+                } else {
+#pragma unroll
+                    for (int it = 0; it < SW; ++it) load8<false>(a.resid, (int64_t)min(mrow[it], a.M - 1) * a.ldr + n, r8[it]);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < SW; ++it) {
+                float v[8] = {lo[it][0], lo[it][1], lo[it][2], lo[it][3], hi[it][0], hi[it][1], hi[it][2], hi[it][3]};
+                int64_t off;
+                if (swiglu) {                                   // (same arithmetic, in the same order, as epilogue_store8)
+                    const float u[8] = {ul[it][0], ul[it][1], ul[it][2], ul[it][3], uh[it][0], uh[it][1], uh[it][2], uh[it][3]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu(v[e]) * u[e];
+                    off = (int64_t)mrow[it] * a.ldc + (((n >> 5) << 4) + (n & 15));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+                    if (epi == SVR_EPI_BIAS_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+                    } else if (epi == SVR_EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+                    }
+                    if (with_gate) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= gate8[e];
+                    }
+                    if (with_resid) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += r8[it][e];
+                    }
+                    off = (int64_t)mrow[it] * a.ldc + n;
+                }
+                if (!ok[it]) continue;
+                if (a.out_f32) {
+                    float* cp = (float*)a.C + off;
+                    *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    *(uint4*)((bf16_t*)a.C + off) = pack8(v);
+                }
+            }
+        }
+    }
+}
+
+// dynamic LDS of gemm_kernel: its two K-loop stages, or the epilogue's parking area if that is larger
+template <int BM, int BN, int WM, int WN, bool EPI_LDS> constexpr int gemm_lds_bytes() {
+    constexpr int stages = 2 * (BM + BN) * BK * 2, epi = EPI_LDS ? epilogue_lds_bytes<BM, BN, WM, WN>() : 0;
+    return stages > epi ? stages : epi;
+}
 template <int BM, int BN, int WM, int WN, bool CONV, bool EPI_LDS = false>
 __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
     constexpr int WAVES_N = BN / WN;
@@ -285,7 +430,6 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
         const int n = n0 + (tid >> 3) + 64 * i;               // W is padded to a multiple of BN rows
         wrow[i] = (const char*)a.W + (int64_t)n * a.K * 2 + chunk_src * 16;
     }
-
     const int nk = a.K / BK;
 
     auto stage = [&](int kt, int s) {
@@ -370,63 +514,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
     // ---- epilogue.  Lane holds C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) + 0..3].
     const int ng = (lane >> 4) * 4;
     if constexpr (EPI_LDS) {
-        // Through LDS (the K loop's stage buffers are free after its last barrier): passes of RI row fragments per wave
-        // are parked as fp32 [rows][BN + 4] and leave row-contiguous, 8 columns (16 bytes of bf16) per thread, so every
-        // global store / residual load instruction covers whole 128-byte lines.  For short-K problems (1x1 convs, the
-        // pixel-shuffle upsamplers: 2 .. 8 K tiles per output tile) the direct epilogue's 8-byte scattered stores
-        // -- 16 rows x 32 bytes per instruction -- were most of the kernel's time.
-        constexpr int WAVES_M = BM / WM;
-        constexpr int RI = 2;
-        constexpr int PASS_ROWS = WAVES_M * RI * 16;
-        constexpr int PITCH = BN * 4 + 16;
-        constexpr int CH = BN / 8, ROWS_IT = THREADS / CH, ITERS = PASS_ROWS / ROWS_IT;
-        static_assert(PASS_ROWS * PITCH <= 2 * STAGE_BYTES && FM % RI == 0 && PASS_ROWS % ROWS_IT == 0, "epilogue staging fits the stage buffers");
-        const int c8 = tid % CH, r_it = tid / CH;
-        const int n = n0 + c8 * 8;
-        const bool swiglu = a.epilogue == SVR_EPI_SWIGLU;
-        const bool col_ok = n < a.N && !(swiglu && (c8 & 2));      // SwiGLU: "in" blocks are consumed by their gate block's threads
-        float bias8[8], gate8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; gate8[e] = 1.f; }
-        if (col_ok && !swiglu) {
-            if (a.bias) {
-                const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
-                bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
-                bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
-            }
-            if (a.gate && a.epilogue == SVR_EPI_RESID_GATE) {
-                const float4 g0 = *(const float4*)(a.gate + n), g1 = *(const float4*)(a.gate + n + 4);
-                gate8[0] = g0.x; gate8[1] = g0.y; gate8[2] = g0.z; gate8[3] = g0.w;
-                gate8[4] = g1.x; gate8[5] = g1.y; gate8[6] = g1.z; gate8[7] = g1.w;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < FM / RI; ++p) {
-            if (p > 0) __syncthreads();                     // the previous pass has been read out
-#pragma unroll
-            for (int ii = 0; ii < RI; ++ii) {
-                char* row = smem + (((wave / WAVES_N) * RI + ii) * 16 + frow) * PITCH;
-#pragma unroll
-                for (int j = 0; j < FN; ++j) *(f32x4*)(row + (wn0 + 16 * j + ng) * 4) = acc[p * RI + ii][j];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const int lr = it * ROWS_IT + r_it;         // parked row -> (wave row, fragment, row in fragment)
-                const int m = m0 + (lr / (RI * 16)) * WM + 16 * (p * RI + ((lr >> 4) % RI)) + (lr & 15);
-                if (!col_ok || m >= a.M) continue;
-                const char* src = smem + lr * PITCH + c8 * 32;
-                const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 16);
-                const float v8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                float u8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (swiglu) {
-                    const f32x4 ul = *(const f32x4*)(src + 64), uh = *(const f32x4*)(src + 80);
-                    u8[0] = ul[0]; u8[1] = ul[1]; u8[2] = ul[2]; u8[3] = ul[3];
-                    u8[4] = uh[0]; u8[5] = uh[1]; u8[6] = uh[2]; u8[7] = uh[3];
-                }
-                epilogue_store8(a, v8, u8, m, n, bias8, gate8);
-            }
-        }
+        epilogue_through_lds<BM, BN, WM, WN, THREADS, gemm_lds_bytes<BM, BN, WM, WN, EPI_LDS>()>(a, acc, smem, m0, n0, tid, lane, wave);
         return;
     }
 #pragma unroll
@@ -442,10 +530,282 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_w4_kernel (round 3): the plain GEMMs of the NaDiT (M = 291 600 tokens at BASELINE config 3) -- 256 x 256 x 64 tiles, FOUR
+// waves of 128 x 128 (8 x 8 accumulator fragments = 256 registers per lane: one wave per SIMD), both operands by 16-byte
+// LDS-DMA into two 64 KiB stages, prefetch distance two K tiles.  Why a second main loop: gemm_kernel's eight 128 x 64 wave
+// tiles read 24 KiB of fragments per wave and K tile for 64 MFMAs (192 KiB per CU), issue their eight LDS-DMA pieces in one
+// burst at the top of the tile and drain vmcnt(0) at its only barrier; the vendor library's kernel for these shapes
+// (hipBLASLt, MT256x256x64 MI16x16x1, 4 waves of 8 x 8 fragments, direct-to-LDS, PGR2 -- read from its kernel name and
+// metadata; 1.36-1.49 PFLOP/s where gemm_kernel reaches 0.94-1.23 on the same box, profiles/r3_kbench_gemm.jsonl) reads 32 KiB
+// per wave for 128 MFMAs (128 KiB per CU) and spreads one DMA piece over every ~4 MFMAs.  This kernel takes that shape:
+//   iteration t (stage s = t & 1; fragments of k-half 0 already in registers):
+//     phase 1  64 MFMAs of k-half 0, the 16 fragment reads of k-half 1 issued two per group of 8 MFMAs;
+//              lgkmcnt(0), barrier  -> every wave is done with stage s
+//     phase 2  64 MFMAs of k-half 1; the 16 DMA pieces of K tile t + 2 -> stage s, four per group of 8 MFMAs;
+//              vmcnt(16) (only those may be in flight), barrier  -> K tile t + 1 has landed in stage s ^ 1 for everybody;
+//              its 16 fragment reads of k-half 0 under the last 24 MFMAs; lgkmcnt(0)
+// Fragment reads are inline asm with immediate offsets (hipcc would schedule read -> wait -> MFMA); every consumer sits behind
+// a counted wait naming its registers.  Same MFMA instruction, operand order, k order and epilogue arithmetic as gemm_kernel
+// -> bit-identical results (tests/test_gpu_kernels.py::test_gemm_w4_matches_the_eight_wave_kernel).
+// ------------------------------------------------------------------------------------------------
+constexpr int W4_THREADS = 256, W4_T = 256, W4_STAGE = 2 * W4_T * BK * 2;                            // 64 KiB per stage
+constexpr int W4_LDS = 2 * W4_STAGE > epilogue_lds_bytes<W4_T, W4_T, 128, 128>() ? 2 * W4_STAGE : epilogue_lds_bytes<W4_T, W4_T, 128, 128>();
+
+template <int OFF> SVR_DEVICE void w4_rd(bf16x8& r, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N> SVR_DEVICE void w4_wait_lgkm(bf16x8 (&x)[8], bf16x8 (&y)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%16)"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                   "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]) : "n"(N));
+    __builtin_amdgcn_sched_barrier(0);
+}
+// The MFMAs are inline asm too: with the builtin hipcc split the 256 accumulators between the two register files and moved
+// ~370 registers per K tile between them; "+a" pins every accumulator to its AGPRs for the whole loop, the fragments stay in
+// VGPRs.  Every accumulator is touched once per 64 MFMAs (no back-to-back dependence); the s_nops after the loop cover the
+// MFMA -> v_accvgpr_read hazard hipcc cannot see.
+template <bool ON = true> SVR_DEVICE void w4_mfma_t(f32x4& c, const bf16x8& w, const bf16x8& x) {
+    if constexpr (ON) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(x));
+    else asm volatile("" : "+a"(c) : "v"(w), "v"(x));
+}
+template <int N> SVR_DEVICE void w4_wait_lgkm_n() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> SVR_DEVICE void w4_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ABL (builds with -DSVR_ABLATIONS only; results invalid): 1 no LDS-DMA in the K loop, 2 no fragment reads in the K loop, 4 no
+// barriers in the K loop, 8 no MFMAs, 16 no epilogue
+template <int ABL>
+__global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const svr_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- tile id: XCD-contiguous bands, then grouped (4 row panels x all column panels) order (as gemm_kernel)
+    const int tiles_m = (a.M + W4_T - 1) / W4_T;
+    const int tiles_n = a.N / W4_T;
+    int t;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, j = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    constexpr int GM = 4;
+    const int group_size = GM * tiles_n;
+    const int group = t / group_size;
+    const int first_m = group * GM;
+    const int gm = min(tiles_m - first_m, GM);
+    const int tm = first_m + (t % group_size) % gm;
+    const int tn = (t % group_size) / gm;
+    const int m0 = tm * W4_T, n0 = tn * W4_T;
+
+    // ---- staging roles: piece q (0..7) of an operand = rows q * 32 + wave * 8 + (lane >> 3), 16-byte chunk (lane & 7) of the row's
+    // 128 bytes; the chunk index is XORed with (row & 7) on the SOURCE side (LDS-DMA destinations are lane-linear)
+    const int chunk_src = (lane & 7) ^ (lane >> 3);
+    const int srow = wave * 8 + (lane >> 3);
+    const char* const Abase = (const char*)a.A + (int64_t)m0 * a.lda * 2;
+    const char* const Bbase = (const char*)a.W + (int64_t)n0 * a.K * 2;
+    uint32_t aoff[8];                                      // byte offset of this thread's chunk in piece q of A, rows clamped to M - 1
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        aoff[q] = (uint32_t)((int64_t)(min(m0 + q * 32 + srow, a.M - 1) - m0) * a.lda * 2) + chunk_src * 16;
+    const uint32_t boff = (uint32_t)((int64_t)srow * a.K * 2) + chunk_src * 16;
+    const uint32_t bstep = (uint32_t)(32 * a.K * 2);       // W is padded to whole 128-row panels and N % 256 == 0: no clamp
+    char* const dstA = smem + wave * 1024;                 // + stage * W4_STAGE + q * 4096
+    char* const dstB = dstA + W4_T * BK * 2;
+    auto dmaA = [&](auto qc, int kt, int st) {             // piece q of A, K tile kt -> stage st
+        constexpr int Q = decltype(qc)::value;
+        glds16(Abase + aoff[Q] + (int64_t)kt * (BK * 2), dstA + st * W4_STAGE + Q * 4096);
+    };
+    auto dmaB = [&](auto qc, int kt, int st) {
+        constexpr int Q = decltype(qc)::value;
+        glds16(Bbase + (boff + Q * bstep) + (int64_t)kt * (BK * 2), dstB + st * W4_STAGE + Q * 4096);
+    };
+    auto dma = [&](auto qc, int kt, int st) { dmaA(qc, kt, st); dmaB(qc, kt, st); };
+
+    // ---- compute roles: wave (wm, wn) owns rows wm * 128 .., columns wn * 128 ..
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ko0 = (unsigned)(((0 * 4 + (lane >> 4)) ^ (lane & 7)) << 4), ko1 = (unsigned)(((1 * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
+    const unsigned rA = lds0 + (unsigned)((wm * 128 + frow) * 128), rB = lds0 + (unsigned)(W4_T * BK * 2 + (wn * 128 + frow) * 128);
+    // fragment read addresses [k-half] of the CURRENT stage; XOR with W4_STAGE flips them to the other stage (both stage bases are
+    // multiples of 64 KiB apart inside one 128 KiB window whose base is 64 KiB aligned only by luck -- so the flip is an add / sub
+    // chosen by the stage bit, not an XOR); the fragment index is an immediate offset (ds offsets are 16 bits)
+    unsigned rdA0 = rA + ko0, rdA1 = rA + ko1, rdB0 = rB + ko0, rdB1 = rB + ko1;
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 A0[8], B0[8], A1[8], B1[8];
+
+#define W4_RD(DST, BASE, I) do { if constexpr (!(ABL & 2) || W4_IN_PROLOGUE) w4_rd<(I) * 2048>(DST[I], BASE); } while (0)
+#define W4_IN_PROLOGUE true
+#define W4_MM8(AF, BF, G) \
+    w4_mfma(acc[G][0], BF[0], AF[G]); w4_mfma(acc[G][1], BF[1], AF[G]); w4_mfma(acc[G][2], BF[2], AF[G]); w4_mfma(acc[G][3], BF[3], AF[G]); \
+    w4_mfma(acc[G][4], BF[4], AF[G]); w4_mfma(acc[G][5], BF[5], AF[G]); w4_mfma(acc[G][6], BF[6], AF[G]); w4_mfma(acc[G][7], BF[7], AF[G])
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define w4_mfma w4_mfma_t<!(ABL & 8)>
+#define W4_DMA2(QA, QB, KT, ST) do { dma(std::integral_constant<int, QA>{}, KT, ST); dma(std::integral_constant<int, QB>{}, KT, ST); } while (0)
+
+    const int nk = a.K / BK;
+    // ---- prologue: K tiles 0 and 1 on their way, fragments of tile 0 / k-half 0 in registers
+    W4_DMA2(0, 1, 0, 0); W4_DMA2(2, 3, 0, 0); W4_DMA2(4, 5, 0, 0); W4_DMA2(6, 7, 0, 0);
+    W4_DMA2(0, 1, 1, 1); W4_DMA2(2, 3, 1, 1); W4_DMA2(4, 5, 1, 1); W4_DMA2(6, 7, 1, 1);
+    W4_FENCE();
+    w4_wait_vmcnt<16>();                                   // K tile 0 has landed (tile 1 may still be in flight)
+    __builtin_amdgcn_s_barrier();
+    W4_FENCE();
+    W4_RD(A0, rdA0, 0);                                    // (the look-ahead order of the loop: its counted waits start right here)
+    W4_RD(B0, rdB0, 0); W4_RD(B0, rdB0, 1); W4_RD(B0, rdB0, 2); W4_RD(B0, rdB0, 3);
+    W4_RD(B0, rdB0, 4); W4_RD(B0, rdB0, 5); W4_RD(B0, rdB0, 6); W4_RD(B0, rdB0, 7);
+    W4_RD(A0, rdA0, 1); W4_RD(A0, rdA0, 2); W4_RD(A0, rdA0, 3); W4_RD(A0, rdA0, 4);
+    W4_RD(A0, rdA0, 5); W4_RD(A0, rdA0, 6); W4_RD(A0, rdA0, 7);
+    W4_FENCE();
+
+#undef W4_IN_PROLOGUE
+#define W4_IN_PROLOGUE false
+    // ONE loop body for every K tile (a peeled tail makes hipcc shuffle the 256 accumulators between register files at its
+    // entry): the stage is a run-time bit; the last two tiles skip their DMA pieces behind a scalar branch; the last tile's
+    // look-ahead reads fetch stale bytes nobody uses.  Side operations ride between PAIRS of MFMAs (32 cycles of matrix work):
+    // one fragment read per pair, one LDS-DMA piece per two pairs (a piece blocks the wave's issue for ~60 cycles,
+    // MI355X_MICROARCH.md; with one wave per SIMD nobody else fills the gap, so pieces never follow each other directly).
+    // LDS operations complete in order, so phase 1 waits with counted lgkmcnt for exactly the look-ahead fragments its next
+    // pair needs (read order A0[0], B0[0..7], A0[1..7]) while the reads of k-half 1 are already being issued behind them.
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        const bool more = kt + 2 < nk && !(ABL & 1);       // K tile kt + 2 exists: staged into this tile's stage under phase 2
+        // ---- phase 1: k-half 0 from registers; the 16 fragment reads of k-half 1 under its first 32 MFMAs
+        w4_wait_lgkm_n<13>(); w4_mfma(acc[0][0], B0[0], A0[0]); w4_mfma(acc[0][1], B0[1], A0[0]); W4_FENCE(); W4_RD(B1, rdB1, 0); W4_FENCE();
+        w4_wait_lgkm_n<12>(); w4_mfma(acc[0][2], B0[2], A0[0]); w4_mfma(acc[0][3], B0[3], A0[0]); W4_FENCE(); W4_RD(B1, rdB1, 1); W4_FENCE();
+        w4_wait_lgkm_n<11>(); w4_mfma(acc[0][4], B0[4], A0[0]); w4_mfma(acc[0][5], B0[5], A0[0]); W4_FENCE(); W4_RD(B1, rdB1, 2); W4_FENCE();
+        w4_wait_lgkm_n<10>(); w4_mfma(acc[0][6], B0[6], A0[0]); w4_mfma(acc[0][7], B0[7], A0[0]); W4_FENCE(); W4_RD(B1, rdB1, 3); W4_FENCE();
+        w4_wait_lgkm_n<10>(); w4_mfma(acc[1][0], B0[0], A0[1]); w4_mfma(acc[1][1], B0[1], A0[1]); W4_FENCE(); W4_RD(B1, rdB1, 4); W4_FENCE();
+        w4_mfma(acc[1][2], B0[2], A0[1]); w4_mfma(acc[1][3], B0[3], A0[1]); W4_FENCE(); W4_RD(B1, rdB1, 5); W4_FENCE();
+        w4_mfma(acc[1][4], B0[4], A0[1]); w4_mfma(acc[1][5], B0[5], A0[1]); W4_FENCE(); W4_RD(B1, rdB1, 6); W4_FENCE();
+        w4_mfma(acc[1][6], B0[6], A0[1]); w4_mfma(acc[1][7], B0[7], A0[1]); W4_FENCE(); W4_RD(B1, rdB1, 7); W4_FENCE();
+        w4_wait_lgkm_n<13>(); w4_mfma(acc[2][0], B0[0], A0[2]); w4_mfma(acc[2][1], B0[1], A0[2]); W4_FENCE(); W4_RD(A1, rdA1, 0); W4_FENCE();
+        w4_mfma(acc[2][2], B0[2], A0[2]); w4_mfma(acc[2][3], B0[3], A0[2]); W4_FENCE(); W4_RD(A1, rdA1, 1); W4_FENCE();
+        w4_mfma(acc[2][4], B0[4], A0[2]); w4_mfma(acc[2][5], B0[5], A0[2]); W4_FENCE(); W4_RD(A1, rdA1, 2); W4_FENCE();
+        w4_mfma(acc[2][6], B0[6], A0[2]); w4_mfma(acc[2][7], B0[7], A0[2]); W4_FENCE(); W4_RD(A1, rdA1, 3); W4_FENCE();
+        w4_wait_lgkm_n<15>(); w4_mfma(acc[3][0], B0[0], A0[3]); w4_mfma(acc[3][1], B0[1], A0[3]); W4_FENCE(); W4_RD(A1, rdA1, 4); W4_FENCE();
+        w4_mfma(acc[3][2], B0[2], A0[3]); w4_mfma(acc[3][3], B0[3], A0[3]); W4_FENCE(); W4_RD(A1, rdA1, 5); W4_FENCE();
+        w4_mfma(acc[3][4], B0[4], A0[3]); w4_mfma(acc[3][5], B0[5], A0[3]); W4_FENCE(); W4_RD(A1, rdA1, 6); W4_FENCE();
+        w4_mfma(acc[3][6], B0[6], A0[3]); w4_mfma(acc[3][7], B0[7], A0[3]); W4_FENCE(); W4_RD(A1, rdA1, 7); W4_FENCE();
+        w4_wait_lgkm_n<15>(); w4_mfma(acc[4][0], B0[0], A0[4]); w4_mfma(acc[4][1], B0[1], A0[4]); W4_FENCE();
+        w4_mfma(acc[4][2], B0[2], A0[4]); w4_mfma(acc[4][3], B0[3], A0[4]); W4_FENCE();
+        w4_mfma(acc[4][4], B0[4], A0[4]); w4_mfma(acc[4][5], B0[5], A0[4]); W4_FENCE();
+        w4_mfma(acc[4][6], B0[6], A0[4]); w4_mfma(acc[4][7], B0[7], A0[4]); W4_FENCE();
+        w4_wait_lgkm_n<15>(); w4_mfma(acc[5][0], B0[0], A0[5]); w4_mfma(acc[5][1], B0[1], A0[5]); W4_FENCE();
+        w4_mfma(acc[5][2], B0[2], A0[5]); w4_mfma(acc[5][3], B0[3], A0[5]); W4_FENCE();
+        w4_mfma(acc[5][4], B0[4], A0[5]); w4_mfma(acc[5][5], B0[5], A0[5]); W4_FENCE();
+        w4_mfma(acc[5][6], B0[6], A0[5]); w4_mfma(acc[5][7], B0[7], A0[5]); W4_FENCE();
+        w4_wait_lgkm_n<15>(); w4_mfma(acc[6][0], B0[0], A0[6]); w4_mfma(acc[6][1], B0[1], A0[6]); W4_FENCE();
+        w4_mfma(acc[6][2], B0[2], A0[6]); w4_mfma(acc[6][3], B0[3], A0[6]); W4_FENCE();
+        w4_mfma(acc[6][4], B0[4], A0[6]); w4_mfma(acc[6][5], B0[5], A0[6]); W4_FENCE();
+        w4_mfma(acc[6][6], B0[6], A0[6]); w4_mfma(acc[6][7], B0[7], A0[6]); W4_FENCE();
+        w4_wait_lgkm_n<15>(); w4_mfma(acc[7][0], B0[0], A0[7]); w4_mfma(acc[7][1], B0[1], A0[7]); W4_FENCE();
+        w4_mfma(acc[7][2], B0[2], A0[7]); w4_mfma(acc[7][3], B0[3], A0[7]); W4_FENCE();
+        w4_mfma(acc[7][4], B0[4], A0[7]); w4_mfma(acc[7][5], B0[5], A0[7]); W4_FENCE();
+        w4_mfma(acc[7][6], B0[6], A0[7]); w4_mfma(acc[7][7], B0[7], A0[7]); W4_FENCE();
+        // ---- barrier 1: every wave's reads of stage st are complete -> it may be overwritten
+        w4_wait_lgkm_n<0>();
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+        W4_FENCE();
+        {
+            const unsigned d = st ? (unsigned)-W4_STAGE : (unsigned)W4_STAGE;      // flip the read addresses to the other stage
+            rdA0 += d; rdA1 += d; rdB0 += d; rdB1 += d;
+        }
+        // ---- phase 2: k-half 1; K tile kt + 2 -> stage st, one piece per two pairs; barrier 2; look-ahead reads of K tile kt + 1
+        w4_mfma(acc[0][0], B1[0], A1[0]); w4_mfma(acc[0][1], B1[1], A1[0]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 0>{}, kt + 2, st); W4_FENCE();
+        w4_mfma(acc[0][2], B1[2], A1[0]); w4_mfma(acc[0][3], B1[3], A1[0]); W4_FENCE();
+        w4_mfma(acc[0][4], B1[4], A1[0]); w4_mfma(acc[0][5], B1[5], A1[0]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 0>{}, kt + 2, st); W4_FENCE();
+        w4_mfma(acc[0][6], B1[6], A1[0]); w4_mfma(acc[0][7], B1[7], A1[0]); W4_FENCE();
+        w4_mfma(acc[1][0], B1[0], A1[1]); w4_mfma(acc[1][1], B1[1], A1[1]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 1>{}, kt + 2, st); W4_FENCE();
+        w4_mfma(acc[1][2], B1[2], A1[1]); w4_mfma(acc[1][3], B1[3], A1[1]); W4_FENCE();
+        w4_mfma(acc[1][4], B1[4], A1[1]); w4_mfma(acc[1][5], B1[5], A1[1]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 1>{}, kt + 2, st); W4_FENCE();
+        w4_mfma(acc[1][6], B1[6], A1[1]); w4_mfma(acc[1][7], B1[7], A1[1]); W4_FENCE();
+        w4_mfma(acc[2][0], B1[0], A1[2]); w4_mfma(acc[2][1], B1[1], A1[2]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 2>{}, kt + 2, st); W4_FENCE();
+        w4_mfma(acc[2][2], B1[2], A1[2]); w4_mfma(acc[2][3], B1[3], A1[2]); W4_FENCE();
+        w4_mfma(acc[2][4], B1[4], A1[2]); w4_mfma(acc[2][5], B1[5], A1[2]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 2>{}, kt + 2, st); W4_FENCE();
+        w4_mfma(acc[2][6], B1[6], A1[2]); w4_mfma(acc[2][7], B1[7], A1[2]); W4_FENCE();
+        w4_mfma(acc[3][0], B1[0], A1[3]); w4_mfma(acc[3][1], B1[1], A1[3]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 3>{}, kt + 2, st); W4_FENCE();
+        w4_mfma(acc[3][2], B1[2], A1[3]); w4_mfma(acc[3][3], B1[3], A1[3]); W4_FENCE();
+        w4_mfma(acc[3][4], B1[4], A1[3]); w4_mfma(acc[3][5], B1[5], A1[3]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 3>{}, kt + 2, st); W4_FENCE();
+        w4_mfma(acc[3][6], B1[6], A1[3]); w4_mfma(acc[3][7], B1[7], A1[3]); W4_FENCE();
+        w4_mfma(acc[4][0], B1[0], A1[4]); w4_mfma(acc[4][1], B1[1], A1[4]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 4>{}, kt + 2, st); W4_FENCE();
+        w4_mfma(acc[4][2], B1[2], A1[4]); w4_mfma(acc[4][3], B1[3], A1[4]); W4_FENCE();
+        w4_mfma(acc[4][4], B1[4], A1[4]); w4_mfma(acc[4][5], B1[5], A1[4]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 4>{}, kt + 2, st); W4_FENCE();
+        w4_mfma(acc[4][6], B1[6], A1[4]); w4_mfma(acc[4][7], B1[7], A1[4]); W4_FENCE();
+        w4_mfma(acc[5][0], B1[0], A1[5]); w4_mfma(acc[5][1], B1[1], A1[5]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 5>{}, kt + 2, st); W4_FENCE();
+        w4_mfma(acc[5][2], B1[2], A1[5]); w4_mfma(acc[5][3], B1[3], A1[5]); W4_FENCE();
+        w4_mfma(acc[5][4], B1[4], A1[5]); w4_mfma(acc[5][5], B1[5], A1[5]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 5>{}, kt + 2, st); W4_FENCE();
+        // K tile kt + 1 -- its pieces were issued a whole tile ago; younger: the 12 pieces of K tile kt + 2 issued above --
+        // has landed for this wave (vmcnt) and, past the barrier, for everybody: its first fragments may be read
+        if (more) w4_wait_vmcnt<12>(); else w4_wait_vmcnt<0>();
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+        W4_FENCE();
+        w4_mfma(acc[5][6], B1[6], A1[5]); w4_mfma(acc[5][7], B1[7], A1[5]); W4_FENCE(); W4_RD(A0, rdA0, 0); W4_RD(B0, rdB0, 0); W4_FENCE();
+        w4_mfma(acc[6][0], B1[0], A1[6]); w4_mfma(acc[6][1], B1[1], A1[6]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 6>{}, kt + 2, st); W4_FENCE(); W4_RD(B0, rdB0, 1); W4_RD(B0, rdB0, 2); W4_FENCE();
+        w4_mfma(acc[6][2], B1[2], A1[6]); w4_mfma(acc[6][3], B1[3], A1[6]); W4_FENCE(); W4_RD(B0, rdB0, 3); W4_RD(B0, rdB0, 4); W4_FENCE();
+        w4_mfma(acc[6][4], B1[4], A1[6]); w4_mfma(acc[6][5], B1[5], A1[6]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 6>{}, kt + 2, st); W4_FENCE(); W4_RD(B0, rdB0, 5); W4_RD(B0, rdB0, 6); W4_FENCE();
+        w4_mfma(acc[6][6], B1[6], A1[6]); w4_mfma(acc[6][7], B1[7], A1[6]); W4_FENCE(); W4_RD(B0, rdB0, 7); W4_RD(A0, rdA0, 1); W4_FENCE();
+        w4_mfma(acc[7][0], B1[0], A1[7]); w4_mfma(acc[7][1], B1[1], A1[7]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 7>{}, kt + 2, st); W4_FENCE(); W4_RD(A0, rdA0, 2); W4_RD(A0, rdA0, 3); W4_FENCE();
+        w4_mfma(acc[7][2], B1[2], A1[7]); w4_mfma(acc[7][3], B1[3], A1[7]); W4_FENCE(); W4_RD(A0, rdA0, 4); W4_RD(A0, rdA0, 5); W4_FENCE();
+        w4_mfma(acc[7][4], B1[4], A1[7]); w4_mfma(acc[7][5], B1[5], A1[7]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 7>{}, kt + 2, st); W4_FENCE(); W4_RD(A0, rdA0, 6); W4_RD(A0, rdA0, 7); W4_FENCE();
+        w4_mfma(acc[7][6], B1[6], A1[7]); w4_mfma(acc[7][7], B1[7], A1[7]); W4_FENCE();
+    }
+    w4_wait_lgkm_n<0>();
+#undef W4_RD
+#undef W4_MM8
+#undef W4_FENCE
+#undef W4_DMA2
+#undef w4_mfma
+#undef W4_IN_PROLOGUE
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs retire before the accumulators are read
+    // (no LDS-DMA in flight: the last two tiles waited vmcnt(0); the barrier orders the last look-ahead reads of the other waves
+    // before the first epilogue pass overwrites the stages)
+    __syncthreads();
+    if constexpr (!(ABL & 16)) epilogue_through_lds<W4_T, W4_T, 128, 128, W4_THREADS, W4_LDS>(a, acc, smem, m0, n0, tid, lane, wave);
+    else if (a.M < 0) *(f32x4*)a.C = acc[0][0];      // (keeps the accumulators alive)
+}
+
+int g_gemm_w4 = 0;     // svr_set_option("gemm_w4"): 1 big plain GEMMs on gemm_w4_kernel | 0 (default) everything on gemm_kernel: the two
+                       // measure within +-4 % of each other (profiles/r3_gemm_w4_ablations.txt says why)
+template <int ABL> static int launch_gemm_w4_t(const svr_gemm_args& a, hipStream_t s) {
+    const int tiles = ((a.M + W4_T - 1) / W4_T) * (a.N / W4_T);
+    static uint64_t lds_attr_done = 0;
+    {
+        const int e = set_max_dynamic_lds((const void*)gemm_w4_kernel<ABL>, W4_LDS, lds_attr_done);
+        if (e != 0) return e;
+    }
+    hipLaunchKernelGGL(gemm_w4_kernel<ABL>, dim3(tiles), dim3(W4_THREADS), W4_LDS, s, a);
+    return (int)hipGetLastError();
+}
+extern int g_pipe_abl;
+static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
+#ifdef SVR_ABLATIONS
+    switch (g_pipe_abl) {
+        case 1: return launch_gemm_w4_t<1>(a, s);
+        case 2: return launch_gemm_w4_t<2>(a, s);
+        case 3: return launch_gemm_w4_t<3>(a, s);
+        case 4: return launch_gemm_w4_t<4>(a, s);
+        case 7: return launch_gemm_w4_t<7>(a, s);
+        case 8: return launch_gemm_w4_t<8>(a, s);
+        case 16: return launch_gemm_w4_t<16>(a, s);
+        case 23: return launch_gemm_w4_t<23>(a, s);
+        default: break;
+    }
+#endif
+    return launch_gemm_w4_t<0>(a, s);
+}
+
 template <int BM, int BN, int WM, int WN, bool CONV, bool EPI_LDS = false>
 static int launch(const svr_gemm_args& a, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+    const size_t lds = gemm_lds_bytes<BM, BN, WM, WN, EPI_LDS>();
     auto kern = gemm_kernel<BM, BN, WM, WN, CONV, EPI_LDS>;
     static uint64_t lds_attr_done = 0;               // per device (svr_common.h)
     {
@@ -478,14 +838,23 @@ int g_pipe_abl = 0;
 // 1x1 convs x1.5, DiT attn-out x1.12, qkv / mlp-out x1.02-1.03, mlp-in SwiGLU x0.98).
 int g_gemm_epi = 0;
 constexpr int GEMM_EPI_LDS_MAX_K_SWIGLU = 1024;
-static bool gemm_epi_lds(const svr_gemm_args& a) {
-    if (g_gemm_epi == 1) return false;
-    const bool aligned = (a.N % 8) == 0 && ((uintptr_t)a.C % 16) == 0 && (!a.resid || (((uintptr_t)a.resid % 16) == 0 && (a.ldr % 8) == 0)) &&
+static bool gemm_epi_lds_aligned(const svr_gemm_args& a) {
+    return (a.N % 8) == 0 && ((uintptr_t)a.C % 16) == 0 && (!a.resid || (((uintptr_t)a.resid % 16) == 0 && (a.ldr % 8) == 0)) &&
                          (!a.bias || ((uintptr_t)a.bias % 16) == 0) && (!a.gate || ((uintptr_t)a.gate % 16) == 0) &&
                          (a.ps.enabled ? (a.ps.C % 8) == 0 : a.phase.enabled ? true : (a.ldc % 8) == 0) &&
                          (!a.phase.bias_border || ((uintptr_t)a.phase.bias_border % 16) == 0);
-    if (!aligned) return false;
+}
+static bool gemm_epi_lds(const svr_gemm_args& a) {
+    if (g_gemm_epi == 1 || !gemm_epi_lds_aligned(a)) return false;
     return g_gemm_epi == 2 || a.epilogue != SVR_EPI_SWIGLU || a.K <= GEMM_EPI_LDS_MAX_K_SWIGLU;
+}
+// what gemm_w4_kernel serves: plain GEMMs with whole 256-column tiles, at least two K tiles, 16-byte aligned rows, the
+// row-contiguous epilogue's alignment, and enough tiles to fill the chip (one workgroup per CU)
+static bool gemm_w4_eligible(const svr_gemm_args& a) {
+    return g_gemm_w4 && !a.conv.enabled && !a.ps.enabled && !a.phase.enabled && (a.N % 256) == 0 && a.K >= 2 * BK &&
+           (a.lda % 8) == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0 && gemm_epi_lds_aligned(a) &&
+           (int64_t)a.lda * 2 * 255 < ((int64_t)1 << 31) && (int64_t)a.K * 2 * 255 < ((int64_t)1 << 31) &&
+           (int64_t)((a.M + 255) / 256) * (a.N / 256) >= 256;
 }
 
 // per-frame partial blocks of fused GroupNorm statistics for this problem (0: not produced)
@@ -525,6 +894,7 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
     if (g_conv_impl != 1 && conv_halo_eligible(a) && a.N <= 32) return launch_conv_thinout(a, s);
     // 256-wide tiles when N allows it (otherwise W is padded to a multiple of 128 rows) -- unless they would leave CUs idle:
     // the VAE attention's P V product (16384 x 512 x 16384) has only 128 such tiles for 256 CUs
+    if (gemm_w4_eligible(a)) return launch_gemm_w4(a, s);
     const bool wide = (a.N % 256) == 0 &&
                       (int64_t)((a.M + 255) / 256) * (a.N / 256) >= (a.conv.enabled ? 0 : 256);
     if (gemm_epi_lds(a)) {

@@ -145,6 +145,51 @@ def test_gemm_swiglu(hip, ref, gemm_epi):
     assert rel_err(w2, want) < 1e-5
 
 
+@pytest.mark.variants
+@pytest.mark.parametrize("M,N,K", [(16384, 4096, 128), (16300, 4096, 192), (9000, 7680, 320), (70000, 256, 2560), (4100, 4096, 6912)])
+def test_gemm_w4_matches_the_eight_wave_kernel(hip, ref, M, N, K):
+    """gemm_w4_kernel (four waves of 128 x 128, 256 accumulators each; plain GEMMs with N % 256 == 0 and >= 256 tiles, i.e. the
+    NaDiT's projections) issues the same MFMA instruction with the same operands in the same k order as gemm_kernel and shares
+    its epilogue code: every fused epilogue must come out BIT-IDENTICAL (2, 3, 5, 40 and 108 K tiles; ragged last row panel),
+    repeated launches too (LDS-DMA two K tiles ahead, hand-counted waits), and both must match the fp32 restatement."""
+    packing = sub("packing")
+    A = rnd(M, K)
+    w, W = packed(N, K)
+    bias, gate = rnd(N, dtype=torch.float32, seed=3), rnd(N, dtype=torch.float32, seed=4)
+    resid = rnd(M, N, seed=5)
+    hid = rnd(M, N, seed=6, dtype=torch.float32)
+    cases = [dict(bias=bias), dict(bias=bias, epilogue=EPI_BIAS_GELU), dict(bias=bias, epilogue=EPI_RESID_GATE, gate=gate, resid=resid),
+             dict(bias=bias, epilogue=EPI_RESID_GATE, gate=gate, resid=hid, out_f32=True), dict(out_f32=True)]
+    for kw in cases:
+        outs = {}
+        for w4 in (1, 0, 1):
+            hip.set_option("gemm_w4", w4)
+            try:
+                out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if kw.get("out_f32") else BF16)
+                hip.gemm(A, W, out, N=N, K=K, **kw)
+            finally:
+                hip.set_option("gemm_w4", 0)
+            if w4 in outs:
+                assert torch.equal(out, outs[w4])                      # deterministic
+            outs[w4] = out
+        assert not torch.isnan(outs[1].float()).any() and torch.equal(outs[1], outs[0]), kw.get("epilogue", 0)
+        want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, **{k: v for k, v in kw.items() if k != "out_f32"})
+        assert rel_err(outs[1].float(), want) < (TOL_F32 if kw.get("out_f32") else TOL_BF16)
+    # SwiGLU (interleaved gate | in weights): N = 2 x hidden
+    Hd = N // 2
+    Wsw = packing.pack_swiglu(rnd(Hd, K, scale=1.0 / math.sqrt(K), seed=7), rnd(Hd, K, scale=1.0 / math.sqrt(K), seed=8), "cuda")
+    outs = []
+    for w4 in (1, 0):
+        hip.set_option("gemm_w4", w4)
+        try:
+            o = torch.full((M, Hd), float("nan"), device="cuda", dtype=BF16)
+            hip.gemm(A, Wsw, o, N=N, K=K, epilogue=EPI_SWIGLU)
+        finally:
+            hip.set_option("gemm_w4", 0)
+        outs.append(o)
+    assert not torch.isnan(outs[0].float()).any() and torch.equal(outs[0], outs[1])
+
+
 # ------------------------------------------------------------------ implicit-GEMM causal conv
 CONV_ROWS_DEFAULT = 8        # the library's default for svr_set_option("conv_rows", ...)
 CONV_CASES = [
