@@ -163,10 +163,14 @@ int svr_conv_pack_frag(const void* W, void* out, int32_t N, int32_t K, int32_t k
 int svr_softmax_rows(const float* S, void* P, int64_t rows, int32_t cols, int64_t ld_s, int64_t ld_p, float scale,
                      void* stream) {
     if (rows <= 0 || cols <= 0) return 0;
-    if (cols % 4 || cols > 256 * SM_MAXV * 4 || ld_s % 4 || ld_p % 4)
-        return fail("svr_softmax_rows: cols must be a multiple of 4 and <= 16384, leading dimensions multiples of 4");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, (bf16_t*)P, cols,
-                       ld_s, ld_p, scale * 1.4426950408889634f);
+    if (cols % 4 || cols > 1024 * SM_MAXV * 4 || ld_s % 4 || ld_p % 4)
+        return fail("svr_softmax_rows: cols must be a multiple of 4 and <= 65536, leading dimensions multiples of 4");
+    if (cols <= 256 * SM_MAXV * 4)
+        hipLaunchKernelGGL(softmax_rows_kernel<256>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, (bf16_t*)P, cols,
+                           ld_s, ld_p, scale * 1.4426950408889634f);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, S, (bf16_t*)P, cols,
+                           ld_s, ld_p, scale * 1.4426950408889634f);
     return check(hipGetLastError(), "svr_softmax_rows");
 }
 

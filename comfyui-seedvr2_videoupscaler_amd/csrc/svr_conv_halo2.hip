@@ -919,29 +919,13 @@ template <int TY, int MODE, int DBG = 0> static int launch_conv_halo2_t(const sv
 
 static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
 #ifdef SVR_ABLATIONS
+    // measurement variants of the shipped kernel (round 2's ablations of the 4-row kernel and the combined variants are in the git
+    // history; every variant costs ~10 s of compile time in the measurement build)
     if (conv_halo2_wreg(a) && g_conv_rows == 8) switch (g_pipe_abl) {
-        case 256: return launch_conv_halo2_t<16, 3, 256>(a, s);
-        case 16: return launch_conv_halo2_t<16, 3, 16>(a, s);
-        case 1: return launch_conv_halo2_t<16, 3, 1>(a, s);
-        case 64: return launch_conv_halo2_t<16, 3, 64>(a, s);
-        case 17: return launch_conv_halo2_t<16, 3, 17>(a, s);
-        case 81: return launch_conv_halo2_t<16, 3, 81>(a, s);
-        case 128: return launch_conv_halo2_t<16, 3, 128>(a, s);
-        default: break;
-    }
-    if (conv_halo2_wreg(a)) switch (g_pipe_abl) {
-        case 1: return launch_conv_halo2_t<8, 1, 1>(a, s);
-        case 2: return launch_conv_halo2_t<8, 1, 2>(a, s);
-        case 4: return launch_conv_halo2_t<8, 1, 4>(a, s);
-        case 7: return launch_conv_halo2_t<8, 1, 7>(a, s);
-        case 8: return launch_conv_halo2_t<8, 1, 8>(a, s);
-        case 16: return launch_conv_halo2_t<8, 1, 16>(a, s);
-        case 32: return launch_conv_halo2_t<8, 1, 32>(a, s);
-        case 64: return launch_conv_halo2_t<8, 1, 64>(a, s);
-        case 48: return launch_conv_halo2_t<8, 1, 48>(a, s);
-        case 112: return launch_conv_halo2_t<8, 1, 112>(a, s);
-        case 128: return launch_conv_halo2_t<8, 1, 128>(a, s);
-        case 256: return launch_conv_halo2_t<8, 1, 256>(a, s);
+        case 256: return launch_conv_halo2_t<16, 3, 256>(a, s);     // s_memtime timeline (tools/conv_timeline.py)
+        case 16: return launch_conv_halo2_t<16, 3, 16>(a, s);       // no halo staging in the K loop
+        case 1: return launch_conv_halo2_t<16, 3, 1>(a, s);         // no weight loads
+        case 64: return launch_conv_halo2_t<16, 3, 64>(a, s);       // no fragment reads
         default: break;
     }
 #endif

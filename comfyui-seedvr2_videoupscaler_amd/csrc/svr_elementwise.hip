@@ -361,11 +361,15 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __rest
 // mid-block attention (single 512-wide head over H*W tokens, attn_video_vae.py:659-665), which runs as
 // Q K^T (MFMA GEMM, fp32 out) -> this kernel -> P V (MFMA GEMM).
 // ------------------------------------------------------------------------------------------------
-constexpr int SM_MAXV = 16;   // float4 per thread -> 256 * 16 * 4 = 16384 columns
+constexpr int SM_MAXV = 16;   // float4 per thread -> 256 * 16 * 4 = 16384 columns (1024 threads: 65536)
 
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, bf16_t* __restrict__ P, int cols,
-                                                           int64_t ld_s, int64_t ld_p, float scale_log2) {
-    __shared__ float red[4];
+// NT = 256 threads for rows up to 16384 columns (every tiled call); NT = 1024 for the untiled 2K / 4K frames of BASELINE config 2
+// (65536 tokens per frame).  The row lives in registers either way.
+template <int NT>
+__global__ __launch_bounds__(NT) void softmax_rows_kernel(const float* __restrict__ S, bf16_t* __restrict__ P, int cols,
+                                                          int64_t ld_s, int64_t ld_p, float scale_log2) {
+    constexpr int NW = NT / 64;
+    __shared__ float red[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* sp = (const float4*)(S + (int64_t)blockIdx.x * ld_s);
     const int nv = cols >> 2;
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < SM_MAXV; ++i) {
-        const int c = tid + 256 * i;
+        const int c = tid + NT * i;
         if (c < nv) {
             v[i] = sp[c];
             v[i].x *= scale_log2; v[i].y *= scale_log2; v[i].z *= scale_log2; v[i].w *= scale_log2;
@@ -383,12 +387,18 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if constexpr (NW == 4) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    } else {
+        mx = red[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
+    }
     __syncthreads();
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < SM_MAXV; ++i) {
-        const int c = tid + 256 * i;
+        const int c = tid + NT * i;
         if (c < nv) {
             v[i].x = fast_exp2(v[i].x - mx); v[i].y = fast_exp2(v[i].y - mx);
             v[i].z = fast_exp2(v[i].z - mx); v[i].w = fast_exp2(v[i].w - mx);
@@ -398,11 +408,19 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
-    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    float tot;
+    if constexpr (NW == 4) {
+        tot = (red[0] + red[1]) + (red[2] + red[3]);
+    } else {
+        tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += red[w];       // fixed order
+    }
+    const float inv = 1.0f / tot;
     uint2* pp = (uint2*)(P + (int64_t)blockIdx.x * ld_p);
 #pragma unroll
     for (int i = 0; i < SM_MAXV; ++i) {
-        const int c = tid + 256 * i;
+        const int c = tid + NT * i;
         if (c < nv) pp[c] = make_uint2(pack2bf(v[i].x * inv, v[i].y * inv), pack2bf(v[i].z * inv, v[i].w * inv));
     }
 }

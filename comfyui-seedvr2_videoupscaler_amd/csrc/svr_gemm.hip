@@ -788,11 +788,9 @@ extern int g_pipe_abl;
 static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
 #ifdef SVR_ABLATIONS
     switch (g_pipe_abl) {
+        // (profiles/r3_gemm_w4_ablations.txt also lists 2 = no fragment reads, 4 = no barriers, 7 = 1 + 2 + 4: measured, dropped from
+        // the build to keep its compile time down)
         case 1: return launch_gemm_w4_t<1>(a, s);
-        case 2: return launch_gemm_w4_t<2>(a, s);
-        case 3: return launch_gemm_w4_t<3>(a, s);
-        case 4: return launch_gemm_w4_t<4>(a, s);
-        case 7: return launch_gemm_w4_t<7>(a, s);
         case 8: return launch_gemm_w4_t<8>(a, s);
         case 16: return launch_gemm_w4_t<16>(a, s);
         case 23: return launch_gemm_w4_t<23>(a, s);

@@ -387,30 +387,35 @@ class VideoVAEEngine:
 
     def _attention(self, ab: _Attn, x):
         """Per-frame spatial self-attention of the mid block (1 head x C=512 over n = H*W tokens).
-        n <= 16384 (every tiled call): Q K^T as an MFMA GEMM with fp32 scores, row softmax, P V as a second GEMM --
+        n <= 65536: Q K^T as an MFMA GEMM with fp32 scores, row softmax, P V as a second GEMM, in blocks of 16384 query rows --
         1 KiB of K/V fragments per MFMA makes the fused single-pass kernel LDS-bound at head_dim 512, two plain
-        GEMMs around a materialised score matrix (1 GiB fp32 per frame, 288 GB of HBM) are ~2x faster.
-        Larger n (untiled 4K frames) uses the fused variable-length kernel."""
+        GEMMs around a materialised score matrix (1 GiB fp32 per 1024-px tile frame, 4 GiB per block of an untiled 2048^2
+        frame; 288 GB of HBM) are ~2x faster.  Larger n (untiled 4K frames) uses the fused variable-length kernel."""
         ops = self.ops
         T, H, W, Cc = x.shape
         n = H * W
         y = self._gn(ab.norm, x, False)
         out = ops.empty(T, H, W, Cc, dtype=self.trunk_dtype)
-        if self.attn_as_gemm and n <= 16384 and n % 64 == 0:
+        if self.attn_as_gemm and n <= 65536 and n % 64 == 0:
+            # query rows in blocks of at most 16384 (1 GiB of fp32 scores at a 1024-px tile; 4 GiB per block for the 65536-token
+            # frames of an untiled 2048^2 clip -- BASELINE config 2 -- where the single-pass kernel is LDS-bound at head_dim 512)
+            rb = min(n, 16384)
             npad = (n + 255) // 256 * 256
             q, v = ops.empty(T * n, Cc), ops.empty(T * n, Cc)
             k = ops.empty(T * n + npad, Cc)                               # slack: the GEMM reads whole 256-row W panels
             y2 = y.reshape(T * n, Cc)
             for dst, j in ((q, 0), (k, 1), (v, 2)):                       # (qkv_w rows are q | k | v blocks of C)
                 ops.gemm(y2, ab.qkv_w[j * Cc:(j + 1) * Cc], dst[:T * n], N=Cc, K=Cc, bias=ab.qkv_b[j * Cc:(j + 1) * Cc].contiguous())
-            S = ops.empty(n, n, dtype=torch.float32)
-            P = ops.empty(n, n)
+            S = ops.empty(rb, n, dtype=torch.float32)
+            P = ops.empty(rb, n)
             att = ops.empty(T * n, Cc)
             for t in range(T):
-                ops.gemm(q[t * n:(t + 1) * n], k[t * n:t * n + npad], S, N=n, K=Cc, out_f32=True)
-                ops.softmax_rows(S, P, 1.0 / math.sqrt(Cc))
                 vt = v[t * n:(t + 1) * n].t().contiguous()               # layout only: V^T [C, n] is the K-contiguous W operand
-                ops.gemm(P, vt, att[t * n:(t + 1) * n], N=Cc, K=n)
+                for r0 in range(0, n, rb):
+                    r1 = min(r0 + rb, n)
+                    ops.gemm(q[t * n + r0:t * n + r1], k[t * n:t * n + npad], S[:r1 - r0], N=n, K=Cc, out_f32=True)
+                    ops.softmax_rows(S[:r1 - r0], P[:r1 - r0], 1.0 / math.sqrt(Cc))
+                    ops.gemm(P[:r1 - r0], vt, att[t * n + r0:t * n + r1], N=Cc, K=n)
         else:
             qkv = ops.empty(T * n, 3 * Cc)
             ops.gemm(y.reshape(T * n, Cc), ab.qkv_w, qkv, N=3 * Cc, K=Cc, bias=ab.qkv_b)

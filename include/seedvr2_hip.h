@@ -177,7 +177,7 @@ int svr_groupnorm_reduce(const void* partial, double* stats, int32_t T, int32_t 
 int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float* gamma, const float* beta,
                         int32_t T, int64_t HW, int32_t C, int32_t groups, float eps, int32_t apply_silu,
                         int32_t x_f32, void* stream);
-/* P[r, :] = softmax(scale * S[r, :]): fp32 scores [rows, cols] (ld_s) -> bf16 probabilities (ld_p); cols <= 16384.
+/* P[r, :] = softmax(scale * S[r, :]): fp32 scores [rows, cols] (ld_s) -> bf16 probabilities (ld_p); cols <= 65536.
  * The softmax of the VAE mid-block attention (diffusers Attention, 1 head x 512; attn_video_vae.py:659-665) when it is
  * run as two MFMA GEMMs around a materialised score matrix.                                            */
 int svr_softmax_rows(const float* S, void* P, int64_t rows, int32_t cols, int64_t ld_s, int64_t ld_p, float scale,

@@ -924,7 +924,7 @@ def test_blend_and_affine(hip, ref):
     assert rel_err(o.float(), ref.affine_slice(inp, torch.empty(50, 16, device="cuda"), 1 / 0.9152, -0.05)) < TOL_BF16
 
 
-@pytest.mark.parametrize("rows,cols", [(64, 64), (100, 4416), (33, 16384), (7, 260)])
+@pytest.mark.parametrize("rows,cols", [(64, 64), (100, 4416), (33, 16384), (7, 260), (9, 20000), (5, 65536)])
 def test_softmax_rows(hip, rows, cols):
     g = torch.Generator(device="cuda").manual_seed(rows + cols)
     S = torch.randn(rows, cols, device="cuda", generator=g) * 30.0
@@ -936,15 +936,17 @@ def test_softmax_rows(hip, rows, cols):
     assert (P.float().sum(-1) - 1).abs().max() < 2e-2
 
 
-def test_vae_attention_gemm_path_matches_fused_kernel(hip):
-    """Mid-block attention run as QK^T GEMM -> softmax -> PV GEMM vs the fused variable-length kernel and fp32 torch."""
+@pytest.mark.parametrize("T,H,W", [(2, 16, 24), (1, 128, 160)], ids=["one_block", "two_row_blocks_20480_tokens"])
+def test_vae_attention_gemm_path_matches_fused_kernel(hip, T, H, W):
+    """Mid-block attention run as QK^T GEMM -> softmax -> PV GEMM (in blocks of 16384 query rows: the second case has 20480 tokens
+    per frame, as the untiled frames of BASELINE config 2 have 65536) vs the fused variable-length kernel and fp32 torch."""
     from conftest import sub
     vae_mod, weights, config = sub("vae"), sub("weights"), sub("config")
     cfg = config.VAEConfig(block_out_channels=(128, 128, 128, 128))
     sd = weights.synth_vae_state_dict(cfg, seed=3)
     eng = vae_mod.VideoVAEEngine(cfg, sd, hip)
     ab = eng.enc_mid[1]
-    x = (torch.randn(2, 16, 24, 128, device="cuda") * 0.7).bfloat16()
+    x = (torch.randn(T, H, W, 128, device="cuda") * 0.7).bfloat16()
     got = eng._attention(ab, x).float()
     eng.attn_as_gemm = False
     fused = eng._attention(ab, x).float()
@@ -955,7 +957,7 @@ def test_vae_attention_gemm_path_matches_fused_kernel(hip):
           "to_v.weight", "to_v.bias", "to_out.0.weight", "to_out.0.bias")}
     xf = x.float()
     y = torch.nn.functional.group_norm(xf.permute(0, 3, 1, 2), 32, w["group_norm.weight"], w["group_norm.bias"], 1e-6)
-    y = y.permute(0, 2, 3, 1).reshape(2, -1, 128)
+    y = y.permute(0, 2, 3, 1).reshape(T, -1, 128)
     q, k, v = (y @ w[f"to_{c}.weight"].T + w[f"to_{c}.bias"] for c in "qkv")
     o = torch.softmax(q @ k.transpose(1, 2) / 128 ** 0.5, -1) @ v
     want = (o @ w["to_out.0.weight"].T + w["to_out.0.bias"]).reshape(xf.shape) + xf
