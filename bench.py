@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--bf16-trunk", action="store_true",
                     help="A/B: round 2's storage regime -- the VAE's residual trunk and the DiT's residual stream in bf16 instead of "
                          "fp32 (48.1 instead of 51.2 dB end to end against the fp32 reference)")
+    ap.add_argument("--branch", choices=["fp32", "bf16"], default=None,
+                    help="A/B: storage of conv1's output inside a VAE block (VideoVAEEngine(branch_fp32=...)); default: the engine's")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -207,7 +209,8 @@ def main():
     dit = sub("dit").NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, device=device), ops, hid_fp32=not args.bf16_trunk)
     vae = sub("vae").VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, device=device), ops,
                                     merge_upsamplers=not args.two_step_upsampler, merge_causal_head=not args.three_tap_head,
-                                    trunk_fp32=not args.bf16_trunk)
+                                    trunk_fp32=not args.bf16_trunk,
+                                    **({} if args.branch is None else {"branch_fp32": args.branch == "fp32"}))
     runner_mod = sub("runner")
     runner = runner_mod.VideoDiffusionInfer(
         runner_mod.default_config(), encode_tiled=tiled, encode_tile_size=(1024, 1024), encode_tile_overlap=(128, 128),

@@ -119,7 +119,7 @@ def _cos_ramp(n: int) -> Optional[torch.Tensor]:
 class VideoVAEEngine:
     def __init__(self, cfg: VAEConfig, state_dict: Dict[str, torch.Tensor], ops,
                  act_budget_bytes: int = 12 << 30, merge_upsamplers: bool = True, merge_causal_head: bool = True,
-                 trunk_fp32: bool = True, branch_fp32: bool = True):
+                 trunk_fp32: bool = True, branch_fp32: bool = False):
         """``merge_upsamplers``: run the spatial-only upsampler (upscale_conv + pixel shuffle + 3x3x3 conv) as four sub-pixel
         convs over its low-resolution input (subpixel.py) -- same function, 12 instead of 28 MACs per output voxel and channel
         pair, no upsampled intermediate; False keeps the reference's two steps.
@@ -133,8 +133,10 @@ class VideoVAEEngine:
         directly as an MFMA operand (in front of a down/upsampler or a shortcut conv): 5 instead of 17 bf16 roundings on the
         decoder's skip path, +2.6 dB against the fp32 reference (tools/error_budget.py) for ~1.5 x the bytes of the
         GroupNorm-apply reads and the conv2 epilogue stores.  False keeps every activation in the ops' storage dtype.
-        ``branch_fp32`` (with ``trunk_fp32``): conv1's output inside a block -- read only by norm2 -- is stored fp32 as well, so a
-        block rounds to bf16 exactly where an MFMA consumes the value (the two GroupNorm-apply outputs): +1.3 dB more."""
+        ``branch_fp32`` (with ``trunk_fp32``; off by default): conv1's output inside a block -- read only by norm2 -- is stored
+        fp32 as well, so a block rounds to bf16 exactly where an MFMA consumes the value (the two GroupNorm-apply outputs).
+        Measured on one MI355X (tools/branch_ab.py, bench.py --branch): +0.4 dB end to end (51.15 vs 50.74 dB on
+        pipeline_small), +0.6 dB on the decoder alone (52.5 vs 51.9 dB), for +2.1 % step time at BASELINE config 3."""
         self.cfg, self.ops = cfg, ops
         self.trunk_dtype = torch.float32 if trunk_fp32 else None      # None: the ops' activation dtype
         self.branch_wide = bool(trunk_fp32 and branch_fp32)
