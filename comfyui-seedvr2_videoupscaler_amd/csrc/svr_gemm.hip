@@ -239,8 +239,11 @@ SVR_DEVICE void epilogue_store8(const svr_gemm_args& a, const float (&acc8)[8], 
 template <int BM, int BN, int WM, int WN> constexpr int epilogue_lds_bytes() {
     return (BM / WM) * ((WM / 16) % 4 == 0 ? 4 : 2) * 16 * (BN * 4 + 16);
 }
-template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES>
-SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const f32x4 (&acc)[WM / 16][WN / 16], char* smem, int m0, int n0,
+// M32: the accumulators are v_mfma_f32_32x32x16 tiles (f32x16 acc[WM / 32][WN / 32]; lane holds row l & 31, columns 8 g + 4 (l >> 5) + e)
+// instead of 16x16x32 tiles (f32x4 acc[WM / 16][WN / 16]); only the parking side differs.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES, bool M32 = false, typename ACC>
+SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0,
                                      int tid, int lane, int wave) {
     constexpr int WAVES_N = BN / WN, FM = WM / 16, FN = WN / 16;
     const int frow = lane & 15, ng = (lane >> 4) * 4;
@@ -279,11 +282,28 @@ SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const f32x4 (&acc)[
 #pragma unroll
     for (int p = 0; p < FM / RI; ++p) {
         if (p > 0) __syncthreads();                     // the previous pass has been read out
+        if constexpr (M32) {
+            static_assert(!M32 || RI == 4, "two 32-row fragments per pass");
 #pragma unroll
-        for (int ii = 0; ii < RI; ++ii) {
-            char* row = smem + (((wave / WAVES_N) * RI + ii) * 16 + frow) * PITCH;
+            for (int ii = 0; ii < 2; ++ii) {
+                char* row = smem + ((wave / WAVES_N) * 64 + ii * 32 + (lane & 31)) * PITCH;
 #pragma unroll
-            for (int j = 0; j < FN; ++j) *(f32x4*)(row + (wn0 + 16 * j + ng) * 4) = acc[p * RI + ii][j];
+                for (int j = 0; j < WN / 32; ++j) {
+                    const f32x16 v = acc[p * 2 + ii][j];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                        *(f32x4*)(row + (wn0 + 32 * j + 8 * g + 4 * (lane >> 5)) * 4) = o;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < RI; ++ii) {
+                char* row = smem + (((wave / WAVES_N) * RI + ii) * 16 + frow) * PITCH;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) *(f32x4*)(row + (wn0 + 16 * j + ng) * 4) = acc[p * RI + ii][j];
+            }
         }
         __syncthreads();
         if (!col_ok) continue;
@@ -531,23 +551,28 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm_w4_kernel (round 3): the plain GEMMs of the NaDiT (M = 291 600 tokens at BASELINE config 3) -- 256 x 256 x 64 tiles, FOUR
-// waves of 128 x 128 (8 x 8 accumulator fragments = 256 registers per lane: one wave per SIMD), both operands by 16-byte
-// LDS-DMA into two 64 KiB stages, prefetch distance two K tiles.  Why a second main loop: gemm_kernel's eight 128 x 64 wave
-// tiles read 24 KiB of fragments per wave and K tile for 64 MFMAs (192 KiB per CU), issue their eight LDS-DMA pieces in one
-// burst at the top of the tile and drain vmcnt(0) at its only barrier; the vendor library's kernel for these shapes
-// (hipBLASLt, MT256x256x64 MI16x16x1, 4 waves of 8 x 8 fragments, direct-to-LDS, PGR2 -- read from its kernel name and
-// metadata; 1.36-1.49 PFLOP/s where gemm_kernel reaches 0.94-1.23 on the same box, profiles/r3_kbench_gemm.jsonl) reads 32 KiB
-// per wave for 128 MFMAs (128 KiB per CU) and spreads one DMA piece over every ~4 MFMAs.  This kernel takes that shape:
-//   iteration t (stage s = t & 1; fragments of k-half 0 already in registers):
-//     phase 1  64 MFMAs of k-half 0, the 16 fragment reads of k-half 1 issued two per group of 8 MFMAs;
-//              lgkmcnt(0), barrier  -> every wave is done with stage s
-//     phase 2  64 MFMAs of k-half 1; the 16 DMA pieces of K tile t + 2 -> stage s, four per group of 8 MFMAs;
-//              vmcnt(16) (only those may be in flight), barrier  -> K tile t + 1 has landed in stage s ^ 1 for everybody;
-//              its 16 fragment reads of k-half 0 under the last 24 MFMAs; lgkmcnt(0)
-// Fragment reads are inline asm with immediate offsets (hipcc would schedule read -> wait -> MFMA); every consumer sits behind
-// a counted wait naming its registers.  Same MFMA instruction, operand order, k order and epilogue arithmetic as gemm_kernel
-// -> bit-identical results (tests/test_gpu_kernels.py::test_gemm_w4_matches_the_eight_wave_kernel).
+// gemm_w4_kernel (round 3): the plain GEMMs of the NaDiT (M = 291 600 tokens at BASELINE config 3) in the shape of the vendor
+// library's kernel for them (hipBLASLt MT256x256x64, 4 waves of 8 x 8 fragments, direct-to-LDS, PGR2 -- read from its kernel
+// name and metadata; 1.36-1.49 PFLOP/s where gemm_kernel reaches 0.94-1.23 on the same box): 256 x 256 x 64 tiles, FOUR waves
+// of 128 x 128 (256 accumulators per lane: one wave per SIMD), both operands by 16-byte LDS-DMA into two 64 KiB stages.
+// History of this kernel (profiles/r3_gemm_w4_ablations.txt): with v_mfma_f32_16x16x32 it tied gemm_kernel in three schedules,
+// and its in-place ablations showed the costs ADD UP instead of overlapping -- MFMAs 1.0, LDS-DMA pieces 0.44, fragment reads
+// 0.06, epilogue 0.3-0.47 of the matrix time: with one wave per SIMD an LDS-DMA piece blocks the wave's issue for ~56 cycles
+// (MI355X_MICROARCH.md) and a 16-cycle MFMA in flight cannot cover that.  Hence v_mfma_f32_32x32x16 here (half as many, twice
+// as long matrix instructions: a piece now hides behind two of them, a fragment read behind one), as in the conv kernels:
+//   K tile t (stage s = t & 1) = four k16 steps of 16 MFMAs; fragment sets X (steps 0, 2) and Y (steps 1, 3), 32 VGPRs each;
+//   step k:  lgkmcnt(0) -> its fragments (read during step k - 1) are there; 16 MFMAs; the 8 fragment reads of step k + 1 and
+//            8 LDS-DMA pieces ride in the slots between them, never two pieces in a row;
+//   step 0:  pieces 8..15 of K tile t + 1 -> stage s ^ 1;
+//   step 3:  first vmcnt(0) + THE barrier of the tile: every wave has read stage s for the last time (step 3's fragments were
+//            read during step 2) and K tile t + 1 has landed in stage s ^ 1; then the reads of its step 0 and pieces 0..7 of
+//            K tile t + 2 -> stage s.
+// Fragment reads and MFMAs are inline asm ("+a" pins the 256 accumulators to AGPRs for the whole loop: with the builtin hipcc
+// split them between the register files and moved ~370 registers per K tile); every consumer sits behind a counted wait.
+// LDS rows are 128 B; chunk c of row r sits at position c ^ ((r >> 1) & 7) (source-side XOR: LDS-DMA destinations are
+// lane-linear), which makes the 32-row fragment reads of ds_read_b128 bank-conflict free in all four of its lane groups.
+// Different MFMA shape = different fp32 summation order than gemm_kernel: equal to the fp32 restatement within the same
+// tolerances, not bit-identical to the eight-wave kernel.
 // ------------------------------------------------------------------------------------------------
 constexpr int W4_THREADS = 256, W4_T = 256, W4_STAGE = 2 * W4_T * BK * 2;                            // 64 KiB per stage
 constexpr int W4_LDS = 2 * W4_STAGE > epilogue_lds_bytes<W4_T, W4_T, 128, 128>() ? 2 * W4_STAGE : epilogue_lds_bytes<W4_T, W4_T, 128, 128>();
@@ -555,18 +580,8 @@ constexpr int W4_LDS = 2 * W4_STAGE > epilogue_lds_bytes<W4_T, W4_T, 128, 128>()
 template <int OFF> SVR_DEVICE void w4_rd(bf16x8& r, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(OFF) : "memory");
 }
-template <int N> SVR_DEVICE void w4_wait_lgkm(bf16x8 (&x)[8], bf16x8 (&y)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(%16)"
-                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
-                   "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]) : "n"(N));
-    __builtin_amdgcn_sched_barrier(0);
-}
-// The MFMAs are inline asm too: with the builtin hipcc split the 256 accumulators between the two register files and moved
-// ~370 registers per K tile between them; "+a" pins every accumulator to its AGPRs for the whole loop, the fragments stay in
-// VGPRs.  Every accumulator is touched once per 64 MFMAs (no back-to-back dependence); the s_nops after the loop cover the
-// MFMA -> v_accvgpr_read hazard hipcc cannot see.
-template <bool ON = true> SVR_DEVICE void w4_mfma_t(f32x4& c, const bf16x8& w, const bf16x8& x) {
-    if constexpr (ON) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(x));
+template <bool ON = true> SVR_DEVICE void w4_mfma_t(f32x16& c, const bf16x8& w, const bf16x8& x) {
+    if constexpr (ON) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(x));
     else asm volatile("" : "+a"(c) : "v"(w), "v"(x));
 }
 template <int N> SVR_DEVICE void w4_wait_lgkm_n() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
@@ -599,10 +614,10 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const svr_gemm_a
     const int tn = (t % group_size) / gm;
     const int m0 = tm * W4_T, n0 = tn * W4_T;
 
-    // ---- staging roles: piece q (0..7) of an operand = rows q * 32 + wave * 8 + (lane >> 3), 16-byte chunk (lane & 7) of the row's
-    // 128 bytes; the chunk index is XORed with (row & 7) on the SOURCE side (LDS-DMA destinations are lane-linear)
-    const int chunk_src = (lane & 7) ^ (lane >> 3);
+    // ---- staging roles: piece q (0..7) of an operand = rows q * 32 + wave * 8 + (lane >> 3), position (lane & 7) of the row's eight
+    // 16-byte chunks; the lane at position p fetches SOURCE chunk p ^ key(row), key = (row >> 1) & 7
     const int srow = wave * 8 + (lane >> 3);
+    const int chunk_src = (lane & 7) ^ ((srow >> 1) & 7);
     const char* const Abase = (const char*)a.A + (int64_t)m0 * a.lda * 2;
     const char* const Bbase = (const char*)a.W + (int64_t)n0 * a.K * 2;
     uint32_t aoff[8];                                      // byte offset of this thread's chunk in piece q of A, rows clamped to M - 1
@@ -621,155 +636,124 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const svr_gemm_a
         constexpr int Q = decltype(qc)::value;
         glds16(Bbase + (boff + Q * bstep) + (int64_t)kt * (BK * 2), dstB + st * W4_STAGE + Q * 4096);
     };
-    auto dma = [&](auto qc, int kt, int st) { dmaA(qc, kt, st); dmaB(qc, kt, st); };
 
-    // ---- compute roles: wave (wm, wn) owns rows wm * 128 .., columns wn * 128 ..
+    // ---- compute roles: wave (wm, wn) owns rows wm * 128 .., columns wn * 128 ..; a 32x32x16 operand fragment = 32 rows x 16 k:
+    // lane l supplies row (l & 31), k 8 (l >> 5) .. + 7 = chunk 2 ks + (l >> 5) of the row, at position chunk ^ key
     const int wm = wave >> 1, wn = wave & 1;
-    const int frow = lane & 15;
+    const int l31 = lane & 31, hi = lane >> 5;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned ko0 = (unsigned)(((0 * 4 + (lane >> 4)) ^ (lane & 7)) << 4), ko1 = (unsigned)(((1 * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
-    const unsigned rA = lds0 + (unsigned)((wm * 128 + frow) * 128), rB = lds0 + (unsigned)(W4_T * BK * 2 + (wn * 128 + frow) * 128);
-    // fragment read addresses [k-half] of the CURRENT stage; XOR with W4_STAGE flips them to the other stage (both stage bases are
-    // multiples of 64 KiB apart inside one 128 KiB window whose base is 64 KiB aligned only by luck -- so the flip is an add / sub
-    // chosen by the stage bit, not an XOR); the fragment index is an immediate offset (ds offsets are 16 bits)
-    unsigned rdA0 = rA + ko0, rdA1 = rA + ko1, rdB0 = rB + ko0, rdB1 = rB + ko1;
-
-    f32x4 acc[8][8];
+    const unsigned key = (unsigned)((l31 >> 1) & 7);
+    const unsigned rA = lds0 + (unsigned)((wm * 128 + l31) * 128), rB = lds0 + (unsigned)(W4_T * BK * 2 + (wn * 128 + l31) * 128);
+    // read addresses [k16 step] of the CURRENT stage (flipped to the other stage by an add / sub once per K tile); the fragment index
+    // (32 rows = 4096 bytes) is an immediate offset
+    unsigned rdA[4], rdB[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 A0[8], B0[8], A1[8], B1[8];
+    for (int ks = 0; ks < 4; ++ks) {
+        const unsigned po = (((unsigned)(2 * ks + hi)) ^ key) << 4;
+        rdA[ks] = rA + po;
+        rdB[ks] = rB + po;
+    }
 
-#define W4_RD(DST, BASE, I) do { if constexpr (!(ABL & 2) || W4_IN_PROLOGUE) w4_rd<(I) * 2048>(DST[I], BASE); } while (0)
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bf16x8 AX[4], BX[4], AY[4], BY[4];
+
 #define W4_IN_PROLOGUE true
-#define W4_MM8(AF, BF, G) \
-    w4_mfma(acc[G][0], BF[0], AF[G]); w4_mfma(acc[G][1], BF[1], AF[G]); w4_mfma(acc[G][2], BF[2], AF[G]); w4_mfma(acc[G][3], BF[3], AF[G]); \
-    w4_mfma(acc[G][4], BF[4], AF[G]); w4_mfma(acc[G][5], BF[5], AF[G]); w4_mfma(acc[G][6], BF[6], AF[G]); w4_mfma(acc[G][7], BF[7], AF[G])
+#define W4_RD(DST, BASE, I) do { if constexpr (!(ABL & 2) || W4_IN_PROLOGUE) w4_rd<(I) * 4096>(DST[I], BASE); } while (0)
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define w4_mfma w4_mfma_t<!(ABL & 8)>
-#define W4_DMA2(QA, QB, KT, ST) do { dma(std::integral_constant<int, QA>{}, KT, ST); dma(std::integral_constant<int, QB>{}, KT, ST); } while (0)
+#define W4_Q(Q) std::integral_constant<int, Q>{}
 
     const int nk = a.K / BK;
-    // ---- prologue: K tiles 0 and 1 on their way, fragments of tile 0 / k-half 0 in registers
-    W4_DMA2(0, 1, 0, 0); W4_DMA2(2, 3, 0, 0); W4_DMA2(4, 5, 0, 0); W4_DMA2(6, 7, 0, 0);
-    W4_DMA2(0, 1, 1, 1); W4_DMA2(2, 3, 1, 1); W4_DMA2(4, 5, 1, 1); W4_DMA2(6, 7, 1, 1);
+    // ---- prologue: K tile 0 and the first half of K tile 1 on their way; fragments of tile 0 / step 0 being read
+    dmaA(W4_Q(0), 0, 0); dmaB(W4_Q(0), 0, 0); dmaA(W4_Q(1), 0, 0); dmaB(W4_Q(1), 0, 0);
+    dmaA(W4_Q(2), 0, 0); dmaB(W4_Q(2), 0, 0); dmaA(W4_Q(3), 0, 0); dmaB(W4_Q(3), 0, 0);
+    dmaA(W4_Q(4), 0, 0); dmaB(W4_Q(4), 0, 0); dmaA(W4_Q(5), 0, 0); dmaB(W4_Q(5), 0, 0);
+    dmaA(W4_Q(6), 0, 0); dmaB(W4_Q(6), 0, 0); dmaA(W4_Q(7), 0, 0); dmaB(W4_Q(7), 0, 0);
+    dmaA(W4_Q(0), 1, 1); dmaB(W4_Q(0), 1, 1); dmaA(W4_Q(1), 1, 1); dmaB(W4_Q(1), 1, 1);
+    dmaA(W4_Q(2), 1, 1); dmaB(W4_Q(2), 1, 1); dmaA(W4_Q(3), 1, 1); dmaB(W4_Q(3), 1, 1);
     W4_FENCE();
-    w4_wait_vmcnt<16>();                                   // K tile 0 has landed (tile 1 may still be in flight)
+    w4_wait_vmcnt<8>();                                    // K tile 0 has landed (the eight pieces of tile 1 may still be in flight)
     __builtin_amdgcn_s_barrier();
     W4_FENCE();
-    W4_RD(A0, rdA0, 0);                                    // (the look-ahead order of the loop: its counted waits start right here)
-    W4_RD(B0, rdB0, 0); W4_RD(B0, rdB0, 1); W4_RD(B0, rdB0, 2); W4_RD(B0, rdB0, 3);
-    W4_RD(B0, rdB0, 4); W4_RD(B0, rdB0, 5); W4_RD(B0, rdB0, 6); W4_RD(B0, rdB0, 7);
-    W4_RD(A0, rdA0, 1); W4_RD(A0, rdA0, 2); W4_RD(A0, rdA0, 3); W4_RD(A0, rdA0, 4);
-    W4_RD(A0, rdA0, 5); W4_RD(A0, rdA0, 6); W4_RD(A0, rdA0, 7);
+    W4_RD(BX, rdB[0], 0); W4_RD(BX, rdB[0], 1); W4_RD(BX, rdB[0], 2); W4_RD(BX, rdB[0], 3);
+    W4_RD(AX, rdA[0], 0); W4_RD(AX, rdA[0], 1); W4_RD(AX, rdA[0], 2); W4_RD(AX, rdA[0], 3);
     W4_FENCE();
-
 #undef W4_IN_PROLOGUE
 #define W4_IN_PROLOGUE false
-    // ONE loop body for every K tile (a peeled tail makes hipcc shuffle the 256 accumulators between register files at its
-    // entry): the stage is a run-time bit; the last two tiles skip their DMA pieces behind a scalar branch; the last tile's
-    // look-ahead reads fetch stale bytes nobody uses.  Side operations ride between PAIRS of MFMAs (32 cycles of matrix work):
-    // one fragment read per pair, one LDS-DMA piece per two pairs (a piece blocks the wave's issue for ~60 cycles,
-    // MI355X_MICROARCH.md; with one wave per SIMD nobody else fills the gap, so pieces never follow each other directly).
-    // LDS operations complete in order, so phase 1 waits with counted lgkmcnt for exactly the look-ahead fragments its next
-    // pair needs (read order A0[0], B0[0..7], A0[1..7]) while the reads of k-half 1 are already being issued behind them.
+
+// one k16 step: 16 MFMAs of fragment sets (AF, BF); SIDEn = the side operation riding behind MFMA n (a statement or nothing)
+#define W4_STEP(AF, BF, S0, S1, S2, S3, S4, S5, S6, S7, S8, S9, S10, S11, S12, S13, S14, S15) \
+        w4_mfma(acc[0][0], BF[0], AF[0]); W4_FENCE(); S0;  W4_FENCE(); w4_mfma(acc[0][1], BF[1], AF[0]); W4_FENCE(); S1;  W4_FENCE(); \
+        w4_mfma(acc[0][2], BF[2], AF[0]); W4_FENCE(); S2;  W4_FENCE(); w4_mfma(acc[0][3], BF[3], AF[0]); W4_FENCE(); S3;  W4_FENCE(); \
+        w4_mfma(acc[1][0], BF[0], AF[1]); W4_FENCE(); S4;  W4_FENCE(); w4_mfma(acc[1][1], BF[1], AF[1]); W4_FENCE(); S5;  W4_FENCE(); \
+        w4_mfma(acc[1][2], BF[2], AF[1]); W4_FENCE(); S6;  W4_FENCE(); w4_mfma(acc[1][3], BF[3], AF[1]); W4_FENCE(); S7;  W4_FENCE(); \
+        w4_mfma(acc[2][0], BF[0], AF[2]); W4_FENCE(); S8;  W4_FENCE(); w4_mfma(acc[2][1], BF[1], AF[2]); W4_FENCE(); S9;  W4_FENCE(); \
+        w4_mfma(acc[2][2], BF[2], AF[2]); W4_FENCE(); S10; W4_FENCE(); w4_mfma(acc[2][3], BF[3], AF[2]); W4_FENCE(); S11; W4_FENCE(); \
+        w4_mfma(acc[3][0], BF[0], AF[3]); W4_FENCE(); S12; W4_FENCE(); w4_mfma(acc[3][1], BF[1], AF[3]); W4_FENCE(); S13; W4_FENCE(); \
+        w4_mfma(acc[3][2], BF[2], AF[3]); W4_FENCE(); S14; W4_FENCE(); w4_mfma(acc[3][3], BF[3], AF[3]); W4_FENCE(); S15; W4_FENCE()
+#define W4_NOP ((void)0)
+
+    // ONE loop body for every K tile (a peeled tail makes hipcc shuffle the accumulators between register files at its entry): the
+    // stage is a run-time bit, the tail tiles skip their DMA pieces behind scalar branches, the last tile's look-ahead reads fetch
+    // stale bytes nobody uses.
     for (int kt = 0; kt < nk; ++kt) {
         const int st = kt & 1;
-        const bool more = kt + 2 < nk && !(ABL & 1);       // K tile kt + 2 exists: staged into this tile's stage under phase 2
-        // ---- phase 1: k-half 0 from registers; the 16 fragment reads of k-half 1 under its first 32 MFMAs
-        w4_wait_lgkm_n<13>(); w4_mfma(acc[0][0], B0[0], A0[0]); w4_mfma(acc[0][1], B0[1], A0[0]); W4_FENCE(); W4_RD(B1, rdB1, 0); W4_FENCE();
-        w4_wait_lgkm_n<12>(); w4_mfma(acc[0][2], B0[2], A0[0]); w4_mfma(acc[0][3], B0[3], A0[0]); W4_FENCE(); W4_RD(B1, rdB1, 1); W4_FENCE();
-        w4_wait_lgkm_n<11>(); w4_mfma(acc[0][4], B0[4], A0[0]); w4_mfma(acc[0][5], B0[5], A0[0]); W4_FENCE(); W4_RD(B1, rdB1, 2); W4_FENCE();
-        w4_wait_lgkm_n<10>(); w4_mfma(acc[0][6], B0[6], A0[0]); w4_mfma(acc[0][7], B0[7], A0[0]); W4_FENCE(); W4_RD(B1, rdB1, 3); W4_FENCE();
-        w4_wait_lgkm_n<10>(); w4_mfma(acc[1][0], B0[0], A0[1]); w4_mfma(acc[1][1], B0[1], A0[1]); W4_FENCE(); W4_RD(B1, rdB1, 4); W4_FENCE();
-        w4_mfma(acc[1][2], B0[2], A0[1]); w4_mfma(acc[1][3], B0[3], A0[1]); W4_FENCE(); W4_RD(B1, rdB1, 5); W4_FENCE();
-        w4_mfma(acc[1][4], B0[4], A0[1]); w4_mfma(acc[1][5], B0[5], A0[1]); W4_FENCE(); W4_RD(B1, rdB1, 6); W4_FENCE();
-        w4_mfma(acc[1][6], B0[6], A0[1]); w4_mfma(acc[1][7], B0[7], A0[1]); W4_FENCE(); W4_RD(B1, rdB1, 7); W4_FENCE();
-        w4_wait_lgkm_n<13>(); w4_mfma(acc[2][0], B0[0], A0[2]); w4_mfma(acc[2][1], B0[1], A0[2]); W4_FENCE(); W4_RD(A1, rdA1, 0); W4_FENCE();
-        w4_mfma(acc[2][2], B0[2], A0[2]); w4_mfma(acc[2][3], B0[3], A0[2]); W4_FENCE(); W4_RD(A1, rdA1, 1); W4_FENCE();
-        w4_mfma(acc[2][4], B0[4], A0[2]); w4_mfma(acc[2][5], B0[5], A0[2]); W4_FENCE(); W4_RD(A1, rdA1, 2); W4_FENCE();
-        w4_mfma(acc[2][6], B0[6], A0[2]); w4_mfma(acc[2][7], B0[7], A0[2]); W4_FENCE(); W4_RD(A1, rdA1, 3); W4_FENCE();
-        w4_wait_lgkm_n<15>(); w4_mfma(acc[3][0], B0[0], A0[3]); w4_mfma(acc[3][1], B0[1], A0[3]); W4_FENCE(); W4_RD(A1, rdA1, 4); W4_FENCE();
-        w4_mfma(acc[3][2], B0[2], A0[3]); w4_mfma(acc[3][3], B0[3], A0[3]); W4_FENCE(); W4_RD(A1, rdA1, 5); W4_FENCE();
-        w4_mfma(acc[3][4], B0[4], A0[3]); w4_mfma(acc[3][5], B0[5], A0[3]); W4_FENCE(); W4_RD(A1, rdA1, 6); W4_FENCE();
-        w4_mfma(acc[3][6], B0[6], A0[3]); w4_mfma(acc[3][7], B0[7], A0[3]); W4_FENCE(); W4_RD(A1, rdA1, 7); W4_FENCE();
-        w4_wait_lgkm_n<15>(); w4_mfma(acc[4][0], B0[0], A0[4]); w4_mfma(acc[4][1], B0[1], A0[4]); W4_FENCE();
-        w4_mfma(acc[4][2], B0[2], A0[4]); w4_mfma(acc[4][3], B0[3], A0[4]); W4_FENCE();
-        w4_mfma(acc[4][4], B0[4], A0[4]); w4_mfma(acc[4][5], B0[5], A0[4]); W4_FENCE();
-        w4_mfma(acc[4][6], B0[6], A0[4]); w4_mfma(acc[4][7], B0[7], A0[4]); W4_FENCE();
-        w4_wait_lgkm_n<15>(); w4_mfma(acc[5][0], B0[0], A0[5]); w4_mfma(acc[5][1], B0[1], A0[5]); W4_FENCE();
-        w4_mfma(acc[5][2], B0[2], A0[5]); w4_mfma(acc[5][3], B0[3], A0[5]); W4_FENCE();
-        w4_mfma(acc[5][4], B0[4], A0[5]); w4_mfma(acc[5][5], B0[5], A0[5]); W4_FENCE();
-        w4_mfma(acc[5][6], B0[6], A0[5]); w4_mfma(acc[5][7], B0[7], A0[5]); W4_FENCE();
-        w4_wait_lgkm_n<15>(); w4_mfma(acc[6][0], B0[0], A0[6]); w4_mfma(acc[6][1], B0[1], A0[6]); W4_FENCE();
-        w4_mfma(acc[6][2], B0[2], A0[6]); w4_mfma(acc[6][3], B0[3], A0[6]); W4_FENCE();
-        w4_mfma(acc[6][4], B0[4], A0[6]); w4_mfma(acc[6][5], B0[5], A0[6]); W4_FENCE();
-        w4_mfma(acc[6][6], B0[6], A0[6]); w4_mfma(acc[6][7], B0[7], A0[6]); W4_FENCE();
-        w4_wait_lgkm_n<15>(); w4_mfma(acc[7][0], B0[0], A0[7]); w4_mfma(acc[7][1], B0[1], A0[7]); W4_FENCE();
-        w4_mfma(acc[7][2], B0[2], A0[7]); w4_mfma(acc[7][3], B0[3], A0[7]); W4_FENCE();
-        w4_mfma(acc[7][4], B0[4], A0[7]); w4_mfma(acc[7][5], B0[5], A0[7]); W4_FENCE();
-        w4_mfma(acc[7][6], B0[6], A0[7]); w4_mfma(acc[7][7], B0[7], A0[7]); W4_FENCE();
-        // ---- barrier 1: every wave's reads of stage st are complete -> it may be overwritten
+        const bool next = kt + 1 < nk && !(ABL & 1), more = kt + 2 < nk && !(ABL & 1);
+        // ---- step 0 (set X); reads of step 1 -> Y; pieces 4..7 of K tile kt + 1 -> the other stage (freed at the last barrier)
         w4_wait_lgkm_n<0>();
+        W4_STEP(AX, BX,
+                W4_RD(BY, rdB[1], 0), if (next) dmaA(W4_Q(4), kt + 1, st ^ 1), W4_RD(BY, rdB[1], 1), if (next) dmaB(W4_Q(4), kt + 1, st ^ 1),
+                W4_RD(BY, rdB[1], 2), if (next) dmaA(W4_Q(5), kt + 1, st ^ 1), W4_RD(BY, rdB[1], 3), if (next) dmaB(W4_Q(5), kt + 1, st ^ 1),
+                W4_RD(AY, rdA[1], 0), if (next) dmaA(W4_Q(6), kt + 1, st ^ 1), W4_RD(AY, rdA[1], 1), if (next) dmaB(W4_Q(6), kt + 1, st ^ 1),
+                W4_RD(AY, rdA[1], 2), if (next) dmaA(W4_Q(7), kt + 1, st ^ 1), W4_RD(AY, rdA[1], 3), if (next) dmaB(W4_Q(7), kt + 1, st ^ 1));
+        // ---- step 1 (set Y); reads of step 2 -> X
+        w4_wait_lgkm_n<0>();
+        W4_STEP(AY, BY,
+                W4_RD(BX, rdB[2], 0), W4_NOP, W4_RD(BX, rdB[2], 1), W4_NOP, W4_RD(BX, rdB[2], 2), W4_NOP, W4_RD(BX, rdB[2], 3), W4_NOP,
+                W4_RD(AX, rdA[2], 0), W4_NOP, W4_RD(AX, rdA[2], 1), W4_NOP, W4_RD(AX, rdA[2], 2), W4_NOP, W4_RD(AX, rdA[2], 3), W4_NOP);
+        // ---- step 2 (set X); reads of step 3 -> Y: the last reads of this stage
+        w4_wait_lgkm_n<0>();
+        W4_STEP(AX, BX,
+                W4_RD(BY, rdB[3], 0), W4_NOP, W4_RD(BY, rdB[3], 1), W4_NOP, W4_RD(BY, rdB[3], 2), W4_NOP, W4_RD(BY, rdB[3], 3), W4_NOP,
+                W4_RD(AY, rdA[3], 0), W4_NOP, W4_RD(AY, rdA[3], 1), W4_NOP, W4_RD(AY, rdA[3], 2), W4_NOP, W4_RD(AY, rdA[3], 3), W4_NOP);
+        // ---- the barrier of the tile: this wave's reads of stage st are complete (lgkmcnt) and its pieces of K tile kt + 1 have landed
+        // (vmcnt: the youngest were issued two steps ago); past it that holds for every wave
+        w4_wait_lgkm_n<0>();
+        w4_wait_vmcnt<0>();
         if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         W4_FENCE();
         {
             const unsigned d = st ? (unsigned)-W4_STAGE : (unsigned)W4_STAGE;      // flip the read addresses to the other stage
-            rdA0 += d; rdA1 += d; rdB0 += d; rdB1 += d;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { rdA[ks] += d; rdB[ks] += d; }
         }
-        // ---- phase 2: k-half 1; K tile kt + 2 -> stage st, one piece per two pairs; barrier 2; look-ahead reads of K tile kt + 1
-        w4_mfma(acc[0][0], B1[0], A1[0]); w4_mfma(acc[0][1], B1[1], A1[0]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 0>{}, kt + 2, st); W4_FENCE();
-        w4_mfma(acc[0][2], B1[2], A1[0]); w4_mfma(acc[0][3], B1[3], A1[0]); W4_FENCE();
-        w4_mfma(acc[0][4], B1[4], A1[0]); w4_mfma(acc[0][5], B1[5], A1[0]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 0>{}, kt + 2, st); W4_FENCE();
-        w4_mfma(acc[0][6], B1[6], A1[0]); w4_mfma(acc[0][7], B1[7], A1[0]); W4_FENCE();
-        w4_mfma(acc[1][0], B1[0], A1[1]); w4_mfma(acc[1][1], B1[1], A1[1]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 1>{}, kt + 2, st); W4_FENCE();
-        w4_mfma(acc[1][2], B1[2], A1[1]); w4_mfma(acc[1][3], B1[3], A1[1]); W4_FENCE();
-        w4_mfma(acc[1][4], B1[4], A1[1]); w4_mfma(acc[1][5], B1[5], A1[1]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 1>{}, kt + 2, st); W4_FENCE();
-        w4_mfma(acc[1][6], B1[6], A1[1]); w4_mfma(acc[1][7], B1[7], A1[1]); W4_FENCE();
-        w4_mfma(acc[2][0], B1[0], A1[2]); w4_mfma(acc[2][1], B1[1], A1[2]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 2>{}, kt + 2, st); W4_FENCE();
-        w4_mfma(acc[2][2], B1[2], A1[2]); w4_mfma(acc[2][3], B1[3], A1[2]); W4_FENCE();
-        w4_mfma(acc[2][4], B1[4], A1[2]); w4_mfma(acc[2][5], B1[5], A1[2]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 2>{}, kt + 2, st); W4_FENCE();
-        w4_mfma(acc[2][6], B1[6], A1[2]); w4_mfma(acc[2][7], B1[7], A1[2]); W4_FENCE();
-        w4_mfma(acc[3][0], B1[0], A1[3]); w4_mfma(acc[3][1], B1[1], A1[3]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 3>{}, kt + 2, st); W4_FENCE();
-        w4_mfma(acc[3][2], B1[2], A1[3]); w4_mfma(acc[3][3], B1[3], A1[3]); W4_FENCE();
-        w4_mfma(acc[3][4], B1[4], A1[3]); w4_mfma(acc[3][5], B1[5], A1[3]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 3>{}, kt + 2, st); W4_FENCE();
-        w4_mfma(acc[3][6], B1[6], A1[3]); w4_mfma(acc[3][7], B1[7], A1[3]); W4_FENCE();
-        w4_mfma(acc[4][0], B1[0], A1[4]); w4_mfma(acc[4][1], B1[1], A1[4]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 4>{}, kt + 2, st); W4_FENCE();
-        w4_mfma(acc[4][2], B1[2], A1[4]); w4_mfma(acc[4][3], B1[3], A1[4]); W4_FENCE();
-        w4_mfma(acc[4][4], B1[4], A1[4]); w4_mfma(acc[4][5], B1[5], A1[4]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 4>{}, kt + 2, st); W4_FENCE();
-        w4_mfma(acc[4][6], B1[6], A1[4]); w4_mfma(acc[4][7], B1[7], A1[4]); W4_FENCE();
-        w4_mfma(acc[5][0], B1[0], A1[5]); w4_mfma(acc[5][1], B1[1], A1[5]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 5>{}, kt + 2, st); W4_FENCE();
-        w4_mfma(acc[5][2], B1[2], A1[5]); w4_mfma(acc[5][3], B1[3], A1[5]); W4_FENCE();
-        w4_mfma(acc[5][4], B1[4], A1[5]); w4_mfma(acc[5][5], B1[5], A1[5]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 5>{}, kt + 2, st); W4_FENCE();
-        // K tile kt + 1 -- its pieces were issued a whole tile ago; younger: the 12 pieces of K tile kt + 2 issued above --
-        // has landed for this wave (vmcnt) and, past the barrier, for everybody: its first fragments may be read
-        if (more) w4_wait_vmcnt<12>(); else w4_wait_vmcnt<0>();
-        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
-        W4_FENCE();
-        w4_mfma(acc[5][6], B1[6], A1[5]); w4_mfma(acc[5][7], B1[7], A1[5]); W4_FENCE(); W4_RD(A0, rdA0, 0); W4_RD(B0, rdB0, 0); W4_FENCE();
-        w4_mfma(acc[6][0], B1[0], A1[6]); w4_mfma(acc[6][1], B1[1], A1[6]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 6>{}, kt + 2, st); W4_FENCE(); W4_RD(B0, rdB0, 1); W4_RD(B0, rdB0, 2); W4_FENCE();
-        w4_mfma(acc[6][2], B1[2], A1[6]); w4_mfma(acc[6][3], B1[3], A1[6]); W4_FENCE(); W4_RD(B0, rdB0, 3); W4_RD(B0, rdB0, 4); W4_FENCE();
-        w4_mfma(acc[6][4], B1[4], A1[6]); w4_mfma(acc[6][5], B1[5], A1[6]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 6>{}, kt + 2, st); W4_FENCE(); W4_RD(B0, rdB0, 5); W4_RD(B0, rdB0, 6); W4_FENCE();
-        w4_mfma(acc[6][6], B1[6], A1[6]); w4_mfma(acc[6][7], B1[7], A1[6]); W4_FENCE(); W4_RD(B0, rdB0, 7); W4_RD(A0, rdA0, 1); W4_FENCE();
-        w4_mfma(acc[7][0], B1[0], A1[7]); w4_mfma(acc[7][1], B1[1], A1[7]); W4_FENCE(); if (more) dmaA(std::integral_constant<int, 7>{}, kt + 2, st); W4_FENCE(); W4_RD(A0, rdA0, 2); W4_RD(A0, rdA0, 3); W4_FENCE();
-        w4_mfma(acc[7][2], B1[2], A1[7]); w4_mfma(acc[7][3], B1[3], A1[7]); W4_FENCE(); W4_RD(A0, rdA0, 4); W4_RD(A0, rdA0, 5); W4_FENCE();
-        w4_mfma(acc[7][4], B1[4], A1[7]); w4_mfma(acc[7][5], B1[5], A1[7]); W4_FENCE(); if (more) dmaB(std::integral_constant<int, 7>{}, kt + 2, st); W4_FENCE(); W4_RD(A0, rdA0, 6); W4_RD(A0, rdA0, 7); W4_FENCE();
-        w4_mfma(acc[7][6], B1[6], A1[7]); w4_mfma(acc[7][7], B1[7], A1[7]); W4_FENCE();
+        // ---- step 3 (set Y); reads of K tile kt + 1 / step 0 -> X (other stage); pieces 0..3 of K tile kt + 2 -> this stage
+        W4_STEP(AY, BY,
+                W4_RD(BX, rdB[0], 0), if (more) dmaA(W4_Q(0), kt + 2, st), W4_RD(BX, rdB[0], 1), if (more) dmaB(W4_Q(0), kt + 2, st),
+                W4_RD(BX, rdB[0], 2), if (more) dmaA(W4_Q(1), kt + 2, st), W4_RD(BX, rdB[0], 3), if (more) dmaB(W4_Q(1), kt + 2, st),
+                W4_RD(AX, rdA[0], 0), if (more) dmaA(W4_Q(2), kt + 2, st), W4_RD(AX, rdA[0], 1), if (more) dmaB(W4_Q(2), kt + 2, st),
+                W4_RD(AX, rdA[0], 2), if (more) dmaA(W4_Q(3), kt + 2, st), W4_RD(AX, rdA[0], 3), if (more) dmaB(W4_Q(3), kt + 2, st));
     }
     w4_wait_lgkm_n<0>();
 #undef W4_RD
-#undef W4_MM8
 #undef W4_FENCE
-#undef W4_DMA2
 #undef w4_mfma
+#undef W4_Q
+#undef W4_STEP
+#undef W4_NOP
 #undef W4_IN_PROLOGUE
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs retire before the accumulators are read
-    // (no LDS-DMA in flight: the last two tiles waited vmcnt(0); the barrier orders the last look-ahead reads of the other waves
-    // before the first epilogue pass overwrites the stages)
+    // (no LDS-DMA in flight: the tail tiles issue none and the last barrier waited vmcnt(0); the barrier orders the last look-ahead
+    // reads of the other waves before the first epilogue pass overwrites the stages)
     __syncthreads();
-    if constexpr (!(ABL & 16)) epilogue_through_lds<W4_T, W4_T, 128, 128, W4_THREADS, W4_LDS>(a, acc, smem, m0, n0, tid, lane, wave);
-    else if (a.M < 0) *(f32x4*)a.C = acc[0][0];      // (keeps the accumulators alive)
+    if constexpr (!(ABL & 16)) epilogue_through_lds<W4_T, W4_T, 128, 128, W4_THREADS, W4_LDS, true>(a, acc, smem, m0, n0, tid, lane, wave);
+    else if (a.M < 0) *(float*)a.C = acc[0][0][0];      // (keeps the accumulators alive)
 }
 
 int g_gemm_w4 = 0;     // svr_set_option("gemm_w4"): 1 big plain GEMMs on gemm_w4_kernel | 0 (default) everything on gemm_kernel: the two

@@ -214,7 +214,7 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
 int svr_set_option(const char* key, int32_t value);
 const char* svr_last_error(void);
 int svr_abi_version(void);
-/* hex SHA-256 of the sources (csrc/*.hip, csrc/*.h, this header; sorted by name) this binary was compiled from, as passed by the
+/* hex SHA-256 of the sources (every .hip and .h file under csrc/ and this header; sorted by name) this binary was compiled from, as passed by the
  * build (-DSVR_BUILD_ID=...); "unknown" if the build did not pass one.  The Python loader refuses a library whose id differs
  * from the sources next to it (a stale binary shipped with newer sources). */
 const char* svr_build_id(void);
