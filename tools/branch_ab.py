@@ -1,3 +1,5 @@
+"""GPU A/B of VideoVAEEngine(branch_fp32=): parity of the whole pipeline (pipeline_small) and of the tiled 17-frame decode (vae_tiled17)
+against the reference's fp32 goldens with conv1 outputs stored in fp32 vs bf16.  usage: python tools/branch_ab.py"""
 import sys, os, math, torch
 sys.path.insert(0, "tests")
 from conftest import sub, rel_err, GOLDEN
