@@ -176,7 +176,7 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
         n_new = ori if (i == 0 or overlap == 0) else max(ori - overlap, 0)
         if i in upscaled:
             # (skip_trimmed_frames: the decoder is causal in time, so our runner leaves out the padding frames that are trimmed
-            # two lines down -- same result, bit for bit on the HIP path (tools/gpu_r3_keep_frames.sh, round 3))
+            # two lines down -- same result, bit for bit on the HIP path (tests/test_gpu_parity.py::test_vae_decode_keep_frames_bit_exact))
             sample = (runner.vae_decode([upscaled.pop(i)], keep_frames=[ori])[0]
                       if skip_trimmed_frames and _takes_keep_frames(runner) else runner.vae_decode([upscaled.pop(i)])[0])
             if sample.dim() == 3:

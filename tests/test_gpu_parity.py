@@ -259,6 +259,23 @@ def test_vae_temporal_slicing_invariance(hip):
     assert a.shape == (3, 13, 64, 64) and torch.equal(a, b), rel_err(b.float(), a.float())
 
 
+def test_vae_decode_keep_frames_bit_exact(hip):
+    """VideoVAEEngine.decode(keep_frames=n) -- what pipeline.upscale asks for by default so that the 4n+1 / uniform-batch padding it
+    trims is never decoded -- equals the first n frames of the full decode BIT FOR BIT on the HIP path: untiled, forced one-latent
+    slices, spatially tiled; every cut position incl. "nothing to trim"."""
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    cfg = config.VAE_V3
+    eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg, device="cuda"), hip)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    z = (torch.randn(4, 12, 10, cfg.latent_channels, generator=g, device="cuda") * 0.5).to(BF16)
+    for kw in ({}, dict(latents_per_slice=1), dict(tiled=True, tile_size=(64, 64), tile_overlap=(16, 16))):
+        full = eng.decode(z, **kw)
+        for k in (1, 2, 5, 9, 12, 13):
+            y = eng.decode(z, keep_frames=k, **kw)
+            y = y.unsqueeze(1) if y.dim() == 3 else y
+            assert y.shape[1] == k and torch.equal(y, full[:, :k]), (kw, k)
+
+
 def test_vae_oracle_live_ragged(hip):
     """Live CPU-oracle comparison on a ragged (non multiple-of-tile) size with 3 tiles per axis."""
     from oracle import vae_oracle
