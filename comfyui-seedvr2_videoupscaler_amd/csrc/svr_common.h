@@ -92,4 +92,17 @@ static inline int set_max_dynamic_lds(const void* kern, int bytes, uint64_t& don
     return 0;
 }
 
+// compute units of the current device (persistent kernels launch one workgroup per CU); cached per device
+static inline int device_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cached[dev & 63];
+    if (c == 0) {
+        int n = 0;
+        c = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return c;
+}
+
 }  // namespace svr

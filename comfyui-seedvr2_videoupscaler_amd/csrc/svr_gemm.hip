@@ -242,18 +242,19 @@ template <int BM, int BN, int WM, int WN> constexpr int epilogue_lds_bytes() {
 // M32: the accumulators are v_mfma_f32_32x32x16 tiles (f32x16 acc[WM / 32][WN / 32]; lane holds row l & 31, columns 8 g + 4 (l >> 5) + e)
 // instead of 16x16x32 tiles (f32x4 acc[WM / 16][WN / 16]); only the parking side differs.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES, bool M32 = false, typename ACC>
-SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0,
+template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES, bool M32 = false, int RI_FORCE = 0, int SW_FORCE = 0, int EDBG = 0, typename ACC>
+SVR_DEVICE void epilogue_generic_lds(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0,
                                      int tid, int lane, int wave) {
     constexpr int WAVES_N = BN / WN, FM = WM / 16, FN = WN / 16;
     const int frow = lane & 15, ng = (lane >> 4) * 4;
     const int wn0 = (wave % WAVES_N) * WN;
     constexpr int WAVES_M = BM / WM;
-    constexpr int RI = FM % 4 == 0 ? 4 : 2;
+    constexpr int RI = RI_FORCE ? RI_FORCE : (FM % 4 == 0 ? 4 : 2);      // 16-row fragments per wave and pass
     constexpr int PASS_ROWS = WAVES_M * RI * 16;
     constexpr int PITCH = BN * 4 + 16;
     constexpr int CH = BN / 8, ROWS_IT = NTHREADS / CH, ITERS = PASS_ROWS / ROWS_IT;
-    constexpr int SW = ITERS % 4 == 0 ? 4 : (ITERS % 2 == 0 ? 2 : 1);       // rows per sweep
+    constexpr int SW = SW_FORCE ? SW_FORCE : (ITERS % 4 == 0 ? 4 : (ITERS % 2 == 0 ? 2 : 1));       // rows per sweep
+    static_assert(ITERS % SW == 0, "whole sweeps");
     static_assert(PASS_ROWS * PITCH <= LDS_BYTES && FM % RI == 0 && PASS_ROWS % ROWS_IT == 0, "epilogue staging fits the LDS allocation");
     const int c8 = tid % CH, r_it = tid / CH;
     const int n = n0 + c8 * 8;
@@ -283,16 +284,17 @@ SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, cha
     for (int p = 0; p < FM / RI; ++p) {
         if (p > 0) __syncthreads();                     // the previous pass has been read out
         if constexpr (M32) {
-            static_assert(!M32 || RI == 4, "two 32-row fragments per pass");
+            static_assert(!M32 || RI % 2 == 0, "whole 32-row fragments per pass");
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                char* row = smem + ((wave / WAVES_N) * 64 + ii * 32 + (lane & 31)) * PITCH;
+            for (int ii = 0; ii < RI / 2; ++ii) {
+                char* row = smem + ((wave / WAVES_N) * (RI * 16) + ii * 32 + (lane & 31)) * PITCH;
 #pragma unroll
                 for (int j = 0; j < WN / 32; ++j) {
-                    const f32x16 v = acc[p * 2 + ii][j];
+                    const f32x16 v = acc[p * (RI / 2) + ii][j];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                        if constexpr (EDBG & 2) { if (a.M < 0) *(f32x4*)row = o; continue; }
                         *(f32x4*)(row + (wn0 + 32 * j + 8 * g + 4 * (lane >> 5)) * 4) = o;
                     }
                 }
@@ -306,7 +308,7 @@ SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, cha
             }
         }
         __syncthreads();
-        if (!col_ok) continue;
+        if (!col_ok || (EDBG & 4)) continue;
 #pragma unroll
         for (int s0 = 0; s0 < ITERS; s0 += SW) {
             int mrow[SW];
@@ -316,7 +318,7 @@ SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, cha
             for (int it = 0; it < SW; ++it) {
                 const int lr = (s0 + it) * ROWS_IT + r_it;  // parked row -> (wave row, fragment, row in fragment)
                 mrow[it] = m0 + (lr / (RI * 16)) * WM + 16 * (p * RI + ((lr >> 4) % RI)) + (lr & 15);
-                ok[it] = mrow[it] < a.M;
+                ok[it] = mrow[it] < a.M && !(EDBG & 1);
                 const char* src = smem + lr * PITCH + c8 * 32;
                 lo[it] = *(const f32x4*)src;
                 hi[it] = *(const f32x4*)(src + 16);
@@ -383,6 +385,239 @@ SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, cha
             }
         }
     }
+}
+
+// The same epilogue for PLAIN [M, ldc] outputs (no pixel shuffle / phase scatter), one compact instance per (epilogue, output type,
+// residual type).  Why: epilogue_generic_lds resolves those at run time inside fully unrolled passes and sweeps, so a big-tile kernel
+// carried 100-170 KB of epilogue code with the hot path threaded through all of it -- against a 64 KB instruction cache shared by
+// two CUs.  Measured on gemm_w4p_kernel (100 MHz stamps, profiles/r3_gemm_w4_ablations.txt section 7): the epilogue took 17.5 us
+// per 256 x 256 tile (24 % of a qkv tile), 1.9 us of it parking; with the stores compiled out (and the dead code with them) 1.9 us
+// in total.  Here the pass loop and the sweep loop are real loops (the accumulators are indexed statically inside a switch over
+// the pass), the variant is a template argument, and an instance is ~2-3 KB.  Same arithmetic in the same order as the generic
+// form -> bit-identical results.
+template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES, bool M32, int RI_FORCE, int SW_FORCE, int EDBG, int RES_REGS_,
+          int EPI, bool OUT_F32, bool RESID_F32, typename ACC>
+SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
+    constexpr int WAVES_N = BN / WN, FM = WM / 16, FN = WN / 16;
+    constexpr int WAVES_M = BM / WM;
+    constexpr int RI = RI_FORCE ? RI_FORCE : (FM % 4 == 0 ? 4 : 2);
+    constexpr int NPASS = FM / RI;
+    constexpr int PASS_ROWS = WAVES_M * RI * 16;
+    constexpr int PITCH = BN * 4 + 16;
+    constexpr int CH = BN / 8, ROWS_IT = NTHREADS / CH, ITERS = PASS_ROWS / ROWS_IT;
+    // (rows per sweep; the residual variants of a register-tight caller take two: their prefetch ring needs the room)
+    constexpr int SW = SW_FORCE ? SW_FORCE : (EPI == SVR_EPI_RESID_GATE && RES_REGS_ < 0 && ITERS % 2 == 0 ? 2 : (ITERS % 4 == 0 ? 4 : (ITERS % 2 == 0 ? 2 : 1)));
+    static_assert(PASS_ROWS * PITCH <= LDS_BYTES && FM % RI == 0 && PASS_ROWS % ROWS_IT == 0 && ITERS % SW == 0 && NPASS <= 4, "epilogue staging fits");
+    static_assert(!M32 || RI % 2 == 0, "whole 32-row fragments per pass");
+    constexpr bool SWIGLU = EPI == SVR_EPI_SWIGLU;
+    const int frow = lane & 15, ng = (lane >> 4) * 4;
+    const int wn0 = (wave % WAVES_N) * WN;
+    const int c8 = tid % CH, r_it = tid / CH;
+    const int n = n0 + c8 * 8;
+    const bool col_ok = n < a.N && !(SWIGLU && (c8 & 2));
+    float bias8[8], gate8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bias8[e] = 0.f; gate8[e] = 1.f; }
+    const bool with_gate = EPI == SVR_EPI_RESID_GATE && a.gate != nullptr;
+    const bool with_resid = EPI == SVR_EPI_RESID_GATE && a.resid != nullptr;
+    if (col_ok && !SWIGLU) {
+        if (a.bias) {
+            const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
+            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+            bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
+        if (with_gate) {
+            const float4 g0 = *(const float4*)(a.gate + n), g1 = *(const float4*)(a.gate + n + 4);
+            gate8[0] = g0.x; gate8[1] = g0.y; gate8[2] = g0.z; gate8[3] = g0.w;
+            gate8[4] = g1.x; gate8[5] = g1.y; gate8[6] = g1.z; gate8[7] = g1.w;
+        }
+    }
+    auto park = [&](auto pc) {                           // pass P: RI row fragments of every wave -> fp32 rows in LDS
+        constexpr int P = decltype(pc)::value;
+        if constexpr (P < NPASS) {
+            if constexpr (M32) {
+#pragma unroll
+                for (int ii = 0; ii < RI / 2; ++ii) {
+                    char* row = smem + ((wave / WAVES_N) * (RI * 16) + ii * 32 + (lane & 31)) * PITCH;
+#pragma unroll
+                    for (int j = 0; j < WN / 32; ++j) {
+                        const f32x16 v = acc[P * (RI / 2) + ii][j];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                            *(f32x4*)(row + (wn0 + 32 * j + 8 * g + 4 * (lane >> 5)) * 4) = o;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ii = 0; ii < RI; ++ii) {
+                    char* row = smem + (((wave / WAVES_N) * RI + ii) * 16 + frow) * PITCH;
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) *(f32x4*)(row + (wn0 + 16 * j + ng) * 4) = acc[P * RI + ii][j];
+                }
+            }
+        }
+    };
+    // Residual rows travel ahead of their use: a sweep that loads its own rows waits a full memory latency each time (measured: 16
+    // sweeps of ~1.2 us = 19 us per 256 x 256 tile against 5.6 us without a residual).  RES_REGS = the 16-byte register sets the
+    // caller can spare:
+    //   RES_REGS >= 0 (gemm_w4*_kernel): the rows of a pass are loaded before the tile is parked -- the pass barriers are s_barrier +
+    //     lgkmcnt only (__syncthreads() would wait for the loads) -- 19 -> 13 us.  (A ring ACROSS passes, slot reloaded with the
+    //     next pass's row when consumed, measured 18 us: vmcnt counts in order, so waiting for a load issued behind the previous
+    //     pass's stores waits for those stores.)
+    //   RES_REGS < 0 (gemm_kernel: two waves per SIMD, no registers to spare while accumulators are live): PF rows start behind the
+    //     parking writes of their own pass, and a slot is reloaded with row + PF when consumed.
+    constexpr bool RES = EPI == SVR_EPI_RESID_GATE;
+    constexpr int RES_REGS = RES_REGS_ < 0 ? -RES_REGS_ : RES_REGS_;
+    constexpr int RPR = RESID_F32 ? 2 : 1;                                  // 16-byte registers per row
+    constexpr int PF = RES ? (ITERS * RPR <= RES_REGS ? ITERS : (RES_REGS / RPR / SW) * SW) : 0;      // rows in flight (whole sweeps)
+    constexpr bool EARLY = RES && RES_REGS_ >= 0;
+    static_assert(!RES || (PF >= SW && ITERS % PF == 0), "residual prefetch depth");
+    uint4 raw[RES ? PF * RPR : 1];
+    auto load_row = [&](int pp, int it, int slot) {       // residual row `it` of this thread in pass pp -> raw[slot ..]
+        const int lr = it * ROWS_IT + r_it;
+        const int mr = m0 + (lr / (RI * 16)) * WM + 16 * (pp * RI + ((lr >> 4) % RI)) + (lr & 15);
+        const int64_t e8 = (int64_t)min(mr, a.M - 1) * a.ldr + n;             // (out-of-range rows read row M - 1, masked at the store)
+        if constexpr (RESID_F32) {
+            raw[2 * slot] = *(const uint4*)((const float*)a.resid + e8);
+            raw[2 * slot + 1] = *(const uint4*)((const float*)a.resid + e8 + 4);
+        } else {
+            raw[slot] = *(const uint4*)((const bf16_t*)a.resid + e8);
+        }
+    };
+    auto load_first = [&](int pp) {
+        if constexpr (RES) {
+            if (with_resid && col_ok) {
+#pragma unroll
+                for (int it = 0; it < PF; ++it) load_row(pp, it, it);
+            }
+        }
+    };
+    auto lds_barrier = [&]() {                            // orders LDS traffic only
+        if constexpr (EARLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
+    };
+    // (the passes are unrolled -- the accumulators want static indices; a switch over a run-time pass made hipcc index them through
+    // scratch -- and each carries its own copy of the ~100-instruction sweep loop)
+    auto pass = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p < NPASS) {
+        if constexpr (EARLY) load_first(p);
+        if (p > 0) lds_barrier();                       // the previous pass has been read out
+        park(pc);
+        if constexpr (RES && !EARLY) load_first(p);
+        lds_barrier();
+        if (!col_ok) return;
+#pragma unroll RES ? ITERS / SW : 1
+        for (int s0 = 0; s0 < ITERS; s0 += SW) {
+            int mrow[SW];
+            f32x4 lo[SW], hi[SW], ul[SW], uh[SW];
+#pragma unroll
+            for (int it = 0; it < SW; ++it) {
+                const int lr = (s0 + it) * ROWS_IT + r_it;  // parked row -> (wave row, fragment, row in fragment)
+                mrow[it] = m0 + (lr / (RI * 16)) * WM + 16 * (p * RI + ((lr >> 4) % RI)) + (lr & 15);
+                const char* src = smem + lr * PITCH + c8 * 32;
+                lo[it] = *(const f32x4*)src;
+                hi[it] = *(const f32x4*)(src + 16);
+                if constexpr (SWIGLU) { ul[it] = *(const f32x4*)(src + 64); uh[it] = *(const f32x4*)(src + 80); }
+            }
+            float r8[SW][8];
+            if constexpr (RES) {
+                if (with_resid) {
+#pragma unroll
+                    for (int it = 0; it < SW; ++it) {
+                        const int slot = (s0 + it) % PF;
+                        if constexpr (RESID_F32) {
+                            const uint4 x = raw[2 * slot], y = raw[2 * slot + 1];
+                            r8[it][0] = __uint_as_float(x.x); r8[it][1] = __uint_as_float(x.y); r8[it][2] = __uint_as_float(x.z); r8[it][3] = __uint_as_float(x.w);
+                            r8[it][4] = __uint_as_float(y.x); r8[it][5] = __uint_as_float(y.y); r8[it][6] = __uint_as_float(y.z); r8[it][7] = __uint_as_float(y.w);
+                        } else {
+                            unpack8(raw[slot], r8[it]);
+                        }
+                    }
+                    if constexpr (PF < ITERS) {      // the consumed slots take the rows PF further on
+                        if (s0 + PF < ITERS) {
+#pragma unroll
+                            for (int it = 0; it < SW; ++it) load_row(p, s0 + it + PF, (s0 + it) % PF);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < SW; ++it) {
+                float v[8] = {lo[it][0], lo[it][1], lo[it][2], lo[it][3], hi[it][0], hi[it][1], hi[it][2], hi[it][3]};
+                int64_t off;
+                if constexpr (SWIGLU) {
+                    const float u[8] = {ul[it][0], ul[it][1], ul[it][2], ul[it][3], uh[it][0], uh[it][1], uh[it][2], uh[it][3]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu(v[e]) * u[e];
+                    off = (int64_t)mrow[it] * a.ldc + (((n >> 5) << 4) + (n & 15));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+                    if constexpr (EPI == SVR_EPI_BIAS_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+                    } else if constexpr (EPI == SVR_EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+                    } else if constexpr (EPI == SVR_EPI_RESID_GATE) {
+                        if (with_gate) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] *= gate8[e];
+                        }
+                        if (with_resid) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += r8[it][e];
+                        }
+                    }
+                    off = (int64_t)mrow[it] * a.ldc + n;
+                }
+                if (mrow[it] >= a.M || (EDBG & 1)) continue;
+                if constexpr (OUT_F32) {
+                    float* cp = (float*)a.C + off;
+                    *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    *(uint4*)((bf16_t*)a.C + off) = pack8(v);
+                }
+            }
+        }
+        }
+    };
+    pass(std::integral_constant<int, 0>{});
+    pass(std::integral_constant<int, 1>{});
+    pass(std::integral_constant<int, 2>{});
+    pass(std::integral_constant<int, 3>{});
+}
+
+// the epilogue through LDS: plain outputs take their compact instance (one switch per tile), scattered outputs the generic form
+template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES, bool M32 = false, int RI_FORCE = 0, int SW_FORCE = 0, int EDBG = 0,
+          bool PLAIN_ONLY = false, int RES_REGS = -8, typename ACC>
+SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
+#define SVR_EPI_CASE(E, OF, RF) \
+    epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, E, OF, RF>(a, acc, smem, m0, n0, tid, lane, wave)
+    if (PLAIN_ONLY || (!a.ps.enabled && !a.phase.enabled)) {
+        const int of = a.out_f32 ? 1 : 0, rf = (a.epilogue == SVR_EPI_RESID_GATE && a.resid && a.resid_f32) ? 1 : 0;
+        switch (a.epilogue * 4 + of * 2 + rf) {
+            case SVR_EPI_BIAS * 4 + 0:       SVR_EPI_CASE(SVR_EPI_BIAS, false, false); return;
+            case SVR_EPI_BIAS * 4 + 2:       SVR_EPI_CASE(SVR_EPI_BIAS, true, false); return;
+            case SVR_EPI_BIAS_SILU * 4 + 0:  SVR_EPI_CASE(SVR_EPI_BIAS_SILU, false, false); return;
+            case SVR_EPI_BIAS_SILU * 4 + 2:  SVR_EPI_CASE(SVR_EPI_BIAS_SILU, true, false); return;
+            case SVR_EPI_BIAS_GELU * 4 + 0:  SVR_EPI_CASE(SVR_EPI_BIAS_GELU, false, false); return;
+            case SVR_EPI_BIAS_GELU * 4 + 2:  SVR_EPI_CASE(SVR_EPI_BIAS_GELU, true, false); return;
+            case SVR_EPI_SWIGLU * 4 + 0:     SVR_EPI_CASE(SVR_EPI_SWIGLU, false, false); return;
+            case SVR_EPI_SWIGLU * 4 + 2:     SVR_EPI_CASE(SVR_EPI_SWIGLU, true, false); return;
+            case SVR_EPI_RESID_GATE * 4 + 0: SVR_EPI_CASE(SVR_EPI_RESID_GATE, false, false); return;
+            case SVR_EPI_RESID_GATE * 4 + 1: SVR_EPI_CASE(SVR_EPI_RESID_GATE, false, true); return;
+            case SVR_EPI_RESID_GATE * 4 + 2: SVR_EPI_CASE(SVR_EPI_RESID_GATE, true, false); return;
+            default:                         SVR_EPI_CASE(SVR_EPI_RESID_GATE, true, true); return;
+        }
+    }
+#undef SVR_EPI_CASE
+    if constexpr (!PLAIN_ONLY)
+        epilogue_generic_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG>(a, acc, smem, m0, n0, tid, lane, wave);
 }
 
 // dynamic LDS of gemm_kernel: its two K-loop stages, or the epilogue's parking area if that is larger
@@ -752,10 +987,301 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const svr_gemm_a
     // (no LDS-DMA in flight: the tail tiles issue none and the last barrier waited vmcnt(0); the barrier orders the last look-ahead
     // reads of the other waves before the first epilogue pass overwrites the stages)
     __syncthreads();
-    if constexpr (!(ABL & 16)) epilogue_through_lds<W4_T, W4_T, 128, 128, W4_THREADS, W4_LDS, true>(a, acc, smem, m0, n0, tid, lane, wave);
+    if constexpr (!(ABL & 16)) epilogue_through_lds<W4_T, W4_T, 128, 128, W4_THREADS, W4_LDS, true, 0, 0, 0, true, 16>(a, acc, smem, m0, n0, tid, lane, wave);
     else if (a.M < 0) *(float*)a.C = acc[0][0][0];      // (keeps the accumulators alive)
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_w4p_kernel: PERSISTENT workgroups, operands staged through registers, one pipeline across output tiles.
+// Why (profiles/r3_gemm_w4_ablations.txt section 6, tools/kbench.py --only ksweep: time per round of tiles = (K / 64) c + o):
+//     gemm_kernel  c = 1.71 us, o = 13 us | gemm_w4_kernel  c = 1.50, o = 22 | vendor library  c = 1.21, o = 11
+// gemm_w4_kernel's K loop is the fastest of ours, and it throws that away between tiles: workgroup launch, a cold two-tile
+// prologue, and an epilogue nothing overlaps = 15 K tiles' worth per output tile (qkv has 40).  Here one workgroup per CU walks its
+// tiles (t += grid; XCD x takes the x-th 32-tile chunk of every round: 4 row panels x 8 column panels share its L2) and the operand
+// stream never stops: the loads run two K tiles ahead ACROSS tile boundaries, so a tile's epilogue runs with the next tile's first
+// K tile in LDS and its second in flight, and the next MFMA follows the last store.
+//   staging through registers (global_load_dwordx4 -> 64 VGPRs -> ds_write_b128; measured equal to LDS-DMA inside the K loop)
+//   is what makes that possible with two LDS stages: a K tile sits in registers for a whole K tile before it needs its stage.
+//   K tile f (stage s), registers holding K tile f + 1 at its start:
+//   steps 0, 1:  per piece: vmcnt(15) -> it has arrived; ds_write it into stage s ^ 1; load the same piece of K tile f + 2;
+//   step 3:      lgkmcnt(0) + THE barrier (every wave's writes of f + 1 are in LDS, its reads of stage s done); reads of f + 1 / step 0.
+//   tile end:    vmcnt(0); epilogue through the free stage + the 32 KiB between the stages (96 KiB: four passes of 64 rows);
+//                barrier; accumulators zeroed; step-0 fragments of the next tile re-read.
+// LDS: [stage 0: 64 KiB][32 KiB][stage 1: 64 KiB] = 160 KiB.  Same LDS layout inside a stage, fragment reads and MFMA order as
+// gemm_w4_kernel -> bit-identical results to it.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) uint32_t w4p_u32x4;
+SVR_DEVICE void w4p_gload(w4p_u32x4& r, const char* sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+}
+// A goes through a buffer descriptor {panel base, bytes to the end of A}: rows past M - 1 (ragged last row panel) are out of range and
+// read as zero, so the per-lane offsets are the same for every tile (a clamp per tile cost 16 register copies per K tile)
+SVR_DEVICE void w4p_bload(w4p_u32x4& r, const w4p_u32x4& rsrc, uint32_t voff, uint32_t soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int OFF> SVR_DEVICE void w4p_swrite(unsigned addr, const w4p_u32x4& r) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(r), "n"(OFF) : "memory");
+}
+template <int N> SVR_DEVICE void w4p_wait_piece(w4p_u32x4& r) {      // counted vmcnt naming the piece whose data must be there
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N));
+}
+constexpr int W4P_S1 = W4_STAGE + 32768;                   // byte offset of stage 1
+constexpr int W4P_LDS = W4P_S1 + W4_STAGE;                 // 160 KiB
+constexpr int W4P_EPI = W4P_S1;                            // the epilogue's parking area: the free stage + the gap (96 KiB)
+
+// TL (builds with -DSVR_ABLATIONS only): wave 0 stamps the 100 MHz clock at each tile's K-loop start / K-loop end / epilogue end
+template <bool TL, int EDBG = 0>
+__global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_args a, const int stagger_ticks, uint64_t* timeline) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_m = (a.M + W4_T - 1) / W4_T;
+    const int tiles_n = a.N / W4_T;
+    const int tiles = tiles_m * tiles_n;
+    const int nwg = gridDim.x;                             // (host: a multiple of 8, <= tiles)
+    constexpr int GM = 4;
+    const int group_size = GM * tiles_n;
+    auto tile_origin = [&](int t, int& m0, int& n0) {      // grouped order: 4 row panels x all column panels (as gemm_kernel)
+        const int group = t / group_size;
+        const int first_m = group * GM;
+        const int gm = min(tiles_m - first_m, GM);
+        m0 = (first_m + (t % group_size) % gm) * W4_T;
+        n0 = ((t % group_size) / gm) * W4_T;
+    };
+    int t = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);      // tile being computed
+    int m0, n0;
+    tile_origin(t, m0, n0);
+    // ---- stagger: every workgroup runs the same number of K tiles per output tile, so without this all 256 CUs reach their epilogues
+    // in the same microseconds, for the whole kernel: 32 MiB of stores at once and nothing computing (measured: 17-22 us per round of
+    // tiles, tools/kbench.py --only ksweep).  XCD x starts x / 8 of a tile late (its 32 workgroups stay in step: they share the K
+    // slices in its L2); an eighth of the chip is in its epilogue at any time.  Cost: 7 / 8 of one tile time per launch.
+    if (stagger_ticks > 0 && (blockIdx.x & 7) != 0) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+        const uint64_t wait = (uint64_t)(blockIdx.x & 7) * (uint64_t)stagger_ticks;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+
+    // ---- staging roles (as gemm_w4_kernel): piece q = rows q * 32 + wave * 8 + (lane >> 3); the lane at position p = lane & 7 of
+    // its row loads SOURCE chunk p ^ key(row) and stores it lane-linearly
+    const int srow = wave * 8 + (lane >> 3);
+    const int chunk_src = (lane & 7) ^ ((srow >> 1) & 7);
+    // the load cursor: K tile kl of tile tl (two K tiles ahead of the MFMAs, across tile boundaries); bases are wave-uniform
+    int tl = t, kl = 0;
+    w4p_u32x4 Arsrc;
+    uint32_t Akoff = 0;                                    // byte offset of K tile kl in a row of A
+    const char* Bbase;
+    uint32_t aoff[8], boffq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        aoff[q] = (uint32_t)((int64_t)(q * 32 + srow) * a.lda * 2) + chunk_src * 16;
+        boffq[q] = (uint32_t)((int64_t)(q * 32 + srow) * a.K * 2) + chunk_src * 16;
+    }
+    auto point_cursor = [&](int lm0, int ln0) {            // first K tile of the tile at (lm0, ln0)
+        const uint64_t base = (uint64_t)(uintptr_t)a.A + (uint64_t)lm0 * (uint64_t)a.lda * 2;
+        const uint64_t left = (uint64_t)(a.M - lm0) * (uint64_t)a.lda * 2;
+        Arsrc[0] = __builtin_amdgcn_readfirstlane((uint32_t)base);
+        Arsrc[1] = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32) & 0xffffu);
+        Arsrc[2] = __builtin_amdgcn_readfirstlane(left > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)left);
+        Arsrc[3] = 0x00020000u;
+        Akoff = 0;
+        Bbase = (const char*)a.W + (int64_t)ln0 * a.K * 2;
+    };
+    const int nk = a.K / BK;
+    auto advance_cursor = [&]() {                          // after the 16 loads of (tl, kl)
+        if (++kl < nk) {
+            Akoff += BK * 2; Bbase += BK * 2;
+        } else if (tl + nwg < tiles) {
+            tl += nwg; kl = 0;
+            int lm0, ln0;
+            tile_origin(tl, lm0, ln0);
+            point_cursor(lm0, ln0);
+        } else {
+            kl = nk - 1;                                   // no tile left: keep re-loading the last K tile (written to a stage nobody reads)
+        }
+    };
+    point_cursor(m0, n0);
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    // write addresses of this lane's chunk in piece 0 of A / B of the stage being FILLED (flipped per K tile); piece q at + q * 4096
+    unsigned wrA = lds0 + (unsigned)(wave * 1024 + lane * 16), wrB = wrA + W4_T * BK * 2;
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const unsigned key = (unsigned)((l31 >> 1) & 7);
+    const unsigned rA = lds0 + (unsigned)((wm * 128 + l31) * 128), rB = lds0 + (unsigned)(W4_T * BK * 2 + (wn * 128 + l31) * 128);
+    unsigned rdA[4], rdB[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const unsigned po = (((unsigned)(2 * ks + hi)) ^ key) << 4;
+        rdA[ks] = rA + po;
+        rdB[ks] = rB + po;
+    }
+
+    f32x16 acc[4][4];
+    bf16x8 AX[4], BX[4], AY[4], BY[4];
+    w4p_u32x4 sa[8], sb[8];                                // the staging registers: 8 pieces of A, 8 of B
+
+#define W4_RD(DST, BASE, I) w4_rd<(I) * 4096>(DST[I], BASE)
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define w4_mfma w4_mfma_t<true>
+#define W4_LDA(Q) w4p_bload(sa[Q], Arsrc, aoff[Q], Akoff)
+#define W4_LDB(Q) w4p_gload(sb[Q], Bbase, boffq[Q])
+#define W4_LOAD_ALL() do { W4_LDA(0); W4_LDB(0); W4_LDA(1); W4_LDB(1); W4_LDA(2); W4_LDB(2); W4_LDA(3); W4_LDB(3); \
+                           W4_LDA(4); W4_LDB(4); W4_LDA(5); W4_LDB(5); W4_LDA(6); W4_LDB(6); W4_LDA(7); W4_LDB(7); } while (0)
+#define W4_LANDED() asm volatile("s_waitcnt vmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sa[4]), "+v"(sa[5]), \
+                                 "+v"(sa[6]), "+v"(sa[7]), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), \
+                                 "+v"(sb[6]), "+v"(sb[7]))
+    // piece Q: its data (loaded one K tile ago; 15 younger loads may be in flight) -> LDS, then the same piece two K tiles ahead
+#define W4_MOVE_A(Q) do { w4p_wait_piece<15>(sa[Q]); w4p_swrite<(Q) * 4096>(wrA, sa[Q]); W4_FENCE(); W4_LDA(Q); } while (0)
+#define W4_MOVE_B(Q) do { w4p_wait_piece<15>(sb[Q]); w4p_swrite<(Q) * 4096>(wrB, sb[Q]); W4_FENCE(); W4_LDB(Q); } while (0)
+#define W4_READ_STEP0() do { W4_RD(BX, rdB[0], 0); W4_RD(BX, rdB[0], 1); W4_RD(BX, rdB[0], 2); W4_RD(BX, rdB[0], 3); \
+                             W4_RD(AX, rdA[0], 0); W4_RD(AX, rdA[0], 1); W4_RD(AX, rdA[0], 2); W4_RD(AX, rdA[0], 3); } while (0)
+
+    // ---- prologue (once per workgroup): K tile 0 -> registers -> stage 0; K tile 1 -> registers
+    W4_LOAD_ALL();
+    advance_cursor();
+    W4_FENCE();
+    W4_LANDED();
+    W4_FENCE();
+    w4p_swrite<0 * 4096>(wrA, sa[0]); w4p_swrite<0 * 4096>(wrB, sb[0]); w4p_swrite<1 * 4096>(wrA, sa[1]); w4p_swrite<1 * 4096>(wrB, sb[1]);
+    w4p_swrite<2 * 4096>(wrA, sa[2]); w4p_swrite<2 * 4096>(wrB, sb[2]); w4p_swrite<3 * 4096>(wrA, sa[3]); w4p_swrite<3 * 4096>(wrB, sb[3]);
+    w4p_swrite<4 * 4096>(wrA, sa[4]); w4p_swrite<4 * 4096>(wrB, sb[4]); w4p_swrite<5 * 4096>(wrA, sa[5]); w4p_swrite<5 * 4096>(wrB, sb[5]);
+    w4p_swrite<6 * 4096>(wrA, sa[6]); w4p_swrite<6 * 4096>(wrB, sb[6]); w4p_swrite<7 * 4096>(wrA, sa[7]); w4p_swrite<7 * 4096>(wrB, sb[7]);
+    W4_FENCE();
+    W4_LOAD_ALL();
+    advance_cursor();
+    wrA += W4P_S1; wrB += W4P_S1;                          // the loop fills stage 1 first
+    W4_FENCE();
+    w4_wait_lgkm_n<0>();                                   // this wave's writes of K tile 0 are in LDS
+    __builtin_amdgcn_s_barrier();                          // ... and everybody else's
+    W4_FENCE();
+    W4_READ_STEP0();
+    W4_FENCE();
+
+#define W4_STEP(AF, BF, S0, S1, S2, S3, S4, S5, S6, S7, S8, S9, S10, S11, S12, S13, S14, S15) \
+        w4_mfma(acc[0][0], BF[0], AF[0]); W4_FENCE(); S0;  W4_FENCE(); w4_mfma(acc[0][1], BF[1], AF[0]); W4_FENCE(); S1;  W4_FENCE(); \
+        w4_mfma(acc[0][2], BF[2], AF[0]); W4_FENCE(); S2;  W4_FENCE(); w4_mfma(acc[0][3], BF[3], AF[0]); W4_FENCE(); S3;  W4_FENCE(); \
+        w4_mfma(acc[1][0], BF[0], AF[1]); W4_FENCE(); S4;  W4_FENCE(); w4_mfma(acc[1][1], BF[1], AF[1]); W4_FENCE(); S5;  W4_FENCE(); \
+        w4_mfma(acc[1][2], BF[2], AF[1]); W4_FENCE(); S6;  W4_FENCE(); w4_mfma(acc[1][3], BF[3], AF[1]); W4_FENCE(); S7;  W4_FENCE(); \
+        w4_mfma(acc[2][0], BF[0], AF[2]); W4_FENCE(); S8;  W4_FENCE(); w4_mfma(acc[2][1], BF[1], AF[2]); W4_FENCE(); S9;  W4_FENCE(); \
+        w4_mfma(acc[2][2], BF[2], AF[2]); W4_FENCE(); S10; W4_FENCE(); w4_mfma(acc[2][3], BF[3], AF[2]); W4_FENCE(); S11; W4_FENCE(); \
+        w4_mfma(acc[3][0], BF[0], AF[3]); W4_FENCE(); S12; W4_FENCE(); w4_mfma(acc[3][1], BF[1], AF[3]); W4_FENCE(); S13; W4_FENCE(); \
+        w4_mfma(acc[3][2], BF[2], AF[3]); W4_FENCE(); S14; W4_FENCE(); w4_mfma(acc[3][3], BF[3], AF[3]); W4_FENCE(); S15; W4_FENCE()
+#define W4_NOP ((void)0)
+
+    int st = 0;                                            // the stage the MFMAs read
+    int tl_i = 0;
+    uint64_t cyc[5] = {0, 0, 0, 0, 0}, c_prev = 0;        // TL: shader cycles per K-tile phase, summed over a workgroup's K tiles
+    auto cstart = [&]() { if constexpr (TL) { c_prev = __builtin_amdgcn_s_memtime(); } };
+    auto clap = [&](int what) {
+        if constexpr (TL) { const uint64_t c = __builtin_amdgcn_s_memtime(); cyc[what] += c - c_prev; c_prev = c; }
+    };
+    auto stamp = [&](int what) {
+        if constexpr (TL) {
+            if (tid == 0 && tl_i < 64) timeline[((int64_t)blockIdx.x * 64 + tl_i) * 4 + what] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    for (;;) {                                             // the output tiles of this workgroup
+        stamp(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            // (the eight fragment reads of the next step ride behind the FIRST eight MFMAs of a step, so the youngest has eight MFMAs
+            // = 256 cycles to land before the step-boundary wait; the moves take the last eight slots of steps 0 and 1 -- their
+            // ds_writes are long complete at the barrier --, and the waits are counted: lgkmcnt(8) = everything but the eight
+            // ds_writes behind the reads)
+            // ---- step 0 (set X); reads of step 1 -> Y; pieces 0..3: registers -> the other stage, reloaded two K tiles ahead
+            w4_wait_lgkm_n<0>();
+            cstart();
+            W4_STEP(AX, BX,
+                    W4_RD(BY, rdB[1], 0), W4_RD(BY, rdB[1], 1), W4_RD(BY, rdB[1], 2), W4_RD(BY, rdB[1], 3),
+                    W4_RD(AY, rdA[1], 0), W4_RD(AY, rdA[1], 1), W4_RD(AY, rdA[1], 2), W4_RD(AY, rdA[1], 3),
+                    W4_MOVE_A(0), W4_MOVE_B(0), W4_MOVE_A(1), W4_MOVE_B(1), W4_MOVE_A(2), W4_MOVE_B(2), W4_MOVE_A(3), W4_MOVE_B(3));
+            // ---- step 1 (set Y); reads of step 2 -> X; pieces 4..7
+            w4_wait_lgkm_n<8>();
+            clap(0);
+            W4_STEP(AY, BY,
+                    W4_RD(BX, rdB[2], 0), W4_RD(BX, rdB[2], 1), W4_RD(BX, rdB[2], 2), W4_RD(BX, rdB[2], 3),
+                    W4_RD(AX, rdA[2], 0), W4_RD(AX, rdA[2], 1), W4_RD(AX, rdA[2], 2), W4_RD(AX, rdA[2], 3),
+                    W4_MOVE_A(4), W4_MOVE_B(4), W4_MOVE_A(5), W4_MOVE_B(5), W4_MOVE_A(6), W4_MOVE_B(6), W4_MOVE_A(7), W4_MOVE_B(7));
+            // ---- step 2 (set X); reads of step 3 -> Y: the last reads of this stage
+            w4_wait_lgkm_n<8>();
+            clap(1);
+            W4_STEP(AX, BX,
+                    W4_RD(BY, rdB[3], 0), W4_RD(BY, rdB[3], 1), W4_RD(BY, rdB[3], 2), W4_RD(BY, rdB[3], 3),
+                    W4_RD(AY, rdA[3], 0), W4_RD(AY, rdA[3], 1), W4_RD(AY, rdA[3], 2), W4_RD(AY, rdA[3], 3),
+                    W4_NOP, W4_NOP, W4_NOP, W4_NOP, W4_NOP, W4_NOP, W4_NOP, W4_NOP);
+            // ---- the barrier of the K tile: this wave's reads of stage st and its writes of the next K tile are complete (lgkmcnt counts both)
+            w4_wait_lgkm_n<0>();
+            clap(2);
+            __builtin_amdgcn_s_barrier();
+            clap(3);
+            W4_FENCE();
+            {
+                const unsigned d = st ? (unsigned)-W4P_S1 : (unsigned)W4P_S1;      // reads flip to the other stage, writes to this one
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { rdA[ks] += d; rdB[ks] += d; }
+                wrA -= d; wrB -= d;
+                st ^= 1;
+            }
+            advance_cursor();
+            // ---- step 3 (set Y); reads of the next K tile / step 0 -> X (other stage; at a tile's end they are re-read after the epilogue)
+            // (the barrier has just lined the four waves up: eight reads per wave in eight consecutive slots would ask the LDS for its whole
+            // 128 B/clk at once -- measured 786 cycles for this step against 492 for step 2 -- so the later fragments are spaced out)
+            W4_STEP(AY, BY,
+                    W4_RD(BX, rdB[0], 0), W4_RD(BX, rdB[0], 1), W4_RD(BX, rdB[0], 2), W4_RD(BX, rdB[0], 3),
+                    W4_RD(AX, rdA[0], 0), W4_NOP, W4_RD(AX, rdA[0], 1), W4_NOP, W4_RD(AX, rdA[0], 2), W4_NOP, W4_RD(AX, rdA[0], 3), W4_NOP,
+                    W4_NOP, W4_NOP, W4_NOP, W4_NOP);
+            if constexpr (TL) { w4_wait_lgkm_n<0>(); clap(4); }
+        }
+        // ---- tile end.  Stage st holds the next tile's K tile 0, the registers its K tile 1 (in flight); stage st ^ 1 + the gap are free
+        // (every wave passed the last barrier after its last read of it).
+        stamp(1);
+        W4_FENCE();
+        W4_LANDED();                                       // (the compiler may move the staging registers from here on: their data is there)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs retire before the accumulators are read
+        epilogue_through_lds<W4_T, W4_T, 128, 128, W4_THREADS, W4P_EPI, true, 2, 2, EDBG, true, 16>(a, acc, smem + (st ? 0 : W4_STAGE), m0, n0, tid, lane, wave);
+        if constexpr (TL) stamp(2);
+        // hipcc's own wait for the epilogue's loads and stores, HERE (a builtin: its waitcnt pass sees it; an asm wait it does not).
+        // Without it the pass carried "registers with loads pending" from the epilogue into the K loop's header -- the fragment
+        // registers are the epilogue's load destinations -- and put s_waitcnt vmcnt(0) behind the first MFMA of EVERY K tile,
+        // i.e. every K tile waited for all sixteen staged loads it had just issued (K loop 1.70 us per K tile instead of 1.47).
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), expcnt / lgkmcnt untouched
+        if constexpr (TL) { stamp(3); ++tl_i; }
+        t += nwg;
+        if (t >= tiles) break;
+        tile_origin(t, m0, n0);
+        __syncthreads();                                   // the parked tile has been read out: the free stage may be filled again
+        W4_FENCE();
+        W4_READ_STEP0();
+        W4_FENCE();
+    }
+    if constexpr (TL) {
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) timeline[(int64_t)gridDim.x * 64 * 4 + (int64_t)blockIdx.x * 5 + q] = cyc[q];
+        }
+    }
+#undef W4_RD
+#undef W4_FENCE
+#undef w4_mfma
+#undef W4_LDA
+#undef W4_LDB
+#undef W4_LOAD_ALL
+#undef W4_LANDED
+#undef W4_MOVE_A
+#undef W4_MOVE_B
+#undef W4_READ_STEP0
+#undef W4_STEP
+#undef W4_NOP
+}
+
+int g_gemm_stagger = 150;   // svr_set_option("gemm_stagger"): 100 MHz ticks per K tile assumed by gemm_w4p_kernel's start stagger (0: off)
 int g_gemm_w4 = 0;     // svr_set_option("gemm_w4"): 1 big plain GEMMs on gemm_w4_kernel | 0 (default) everything on gemm_kernel: the two
                        // measure within +-4 % of each other (profiles/r3_gemm_w4_ablations.txt says why)
 template <int ABL> static int launch_gemm_w4_t(const svr_gemm_args& a, hipStream_t s) {
@@ -770,6 +1296,78 @@ template <int ABL> static int launch_gemm_w4_t(const svr_gemm_args& a, hipStream
 }
 extern int g_pipe_abl;
 static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
+    if (g_gemm_w4 == 2) {                                 // persistent workgroups, operands staged through registers
+        const int tiles = ((a.M + W4_T - 1) / W4_T) * (a.N / W4_T);
+        static uint64_t lds_attr_done2 = 0;
+        const int e = set_max_dynamic_lds((const void*)gemm_w4p_kernel<false>, W4P_LDS, lds_attr_done2);
+        if (e != 0) return e;
+        const int grid = std::min(device_cu_count(), tiles) & ~7;       // one workgroup per CU; a multiple of the XCD count
+        // (stagger per XCD = 1 / 8 of an output tile's time: K / 64 K tiles of ~1.5 us = 150 ticks of the 100 MHz clock)
+        const int stagger = grid * 2 <= tiles ? (int)((int64_t)(a.K / BK) * g_gemm_stagger / 8) : 0;
+#ifdef SVR_ABLATIONS
+        if (g_pipe_abl >= 100 && g_pipe_abl <= 104) {     // timeline of the first 64 tiles of every workgroup -> stderr (synchronises);
+                                                          // 101: no global stores | 102: no parking writes | 104: no readout (results invalid)
+            static uint64_t* d_tl = nullptr;
+            const size_t n = (size_t)grid * 64 * 4 + (size_t)grid * 5;
+            if (!d_tl && hipMalloc(&d_tl, (256 * 64 * 4 + 256 * 5) * 8) != hipSuccess) return (int)hipErrorOutOfMemory;
+            (void)hipMemsetAsync(d_tl, 0, n * 8, s);
+            static uint64_t lds_attr_done3[4] = {0, 0, 0, 0};
+            auto go = [&](auto kern, uint64_t& done) {
+                const int e3 = set_max_dynamic_lds((const void*)kern, W4P_LDS, done);
+                if (e3 != 0) return e3;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, stagger, d_tl);
+                return 0;
+            };
+            int e3 = 0;
+            switch (g_pipe_abl) {
+                case 101: e3 = go(gemm_w4p_kernel<true, 1>, lds_attr_done3[1]); break;
+                case 102: e3 = go(gemm_w4p_kernel<true, 2>, lds_attr_done3[2]); break;
+                case 104: e3 = go(gemm_w4p_kernel<true, 4>, lds_attr_done3[3]); break;
+                default:  e3 = go(gemm_w4p_kernel<true, 0>, lds_attr_done3[0]); break;
+            }
+            if (e3 != 0) return e3;
+            std::vector<uint64_t> h(n);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h.data(), d_tl, n * 8, hipMemcpyDeviceToHost);
+            uint64_t t00 = ~0ull;
+            for (int w = 0; w < grid; ++w) if (h[(size_t)w * 256]) t00 = std::min(t00, h[(size_t)w * 256]);
+            fprintf(stderr, "[w4p timeline] M %d N %d K %d grid %d; ticks of 10 ns; per workgroup: tile: start(rel) kloop epilogue-issue store-drain\n", a.M, a.N, a.K, grid);
+            for (int w : {0, 1, 2, 7, 8, 9, 128, 255}) {
+                if (w >= grid) continue;
+                fprintf(stderr, "  wg %3d (xcd %d):", w, w & 7);
+                for (int i = 0; i < 6; ++i) {
+                    const uint64_t* r = &h[((size_t)w * 64 + i) * 4];
+                    if (!r[0]) break;
+                    fprintf(stderr, "  %lld %lld %lld %lld |", (long long)(r[0] - t00), (long long)(r[1] - r[0]), (long long)(r[2] - r[1]), (long long)(r[3] - r[2]));
+                }
+                fprintf(stderr, "\n");
+            }
+            for (int i : {1, 5, 20, 40}) {                 // spread of the epilogue starts of tile i over the workgroups, per XCD mean
+                double mean[8] = {0}; int cnt[8] = {0};
+                double ksum = 0, esum = 0, dsum = 0; int c2 = 0;
+                for (int w = 0; w < grid; ++w) {
+                    const uint64_t* r = &h[((size_t)w * 64 + i) * 4];
+                    if (!r[0] || !r[3]) continue;
+                    mean[w & 7] += (double)(r[1] - t00); ++cnt[w & 7];
+                    ksum += (double)(r[1] - r[0]); esum += (double)(r[2] - r[1]); dsum += (double)(r[3] - r[2]); ++c2;
+                }
+                fprintf(stderr, "  tile %2d: mean kloop %.0f epilogue issue %.0f drain %.0f; epilogue start per XCD:", i, c2 ? ksum / c2 : 0., c2 ? esum / c2 : 0., c2 ? dsum / c2 : 0.);
+                for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f", cnt[x] ? mean[x] / cnt[x] : 0.);
+                fprintf(stderr, "\n");
+            }
+            {                                              // shader cycles per K tile and phase (wave 0 of every workgroup)
+                double c5[5] = {0, 0, 0, 0, 0};
+                for (int w = 0; w < grid; ++w) for (int q = 0; q < 5; ++q) c5[q] += (double)h[(size_t)grid * 256 + (size_t)w * 5 + q];
+                const double kts = (double)tiles * (a.K / BK);
+                fprintf(stderr, "  shader cycles per K tile: step0 %.0f step1 %.0f step2 %.0f barrier %.0f step3 %.0f (MFMA time of a step: 512)\n",
+                        c5[0] / kts, c5[1] / kts, c5[2] / kts, c5[3] / kts, c5[4] / kts);
+            }
+            return (int)hipGetLastError();
+        }
+#endif
+        hipLaunchKernelGGL(gemm_w4p_kernel<false>, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, stagger, (uint64_t*)nullptr);
+        return (int)hipGetLastError();
+    }
 #ifdef SVR_ABLATIONS
     switch (g_pipe_abl) {
         // (profiles/r3_gemm_w4_ablations.txt also lists 2 = no fragment reads, 4 = no barriers, 7 = 1 + 2 + 4: measured, dropped from

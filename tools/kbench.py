@@ -98,6 +98,41 @@ def main():
             sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, epilogue=epi, **kw), args.reps)
             report(name, sec, flops=2.0 * M * N * K)
             del a, w, c, kw
+    if "ksweep" in only:
+        # per-K-tile cost c and per-output-tile overhead o of the big-GEMM main loops: M x N = 4096 tiles of 256 x 256 (16 full rounds of
+        # 256 CUs), bias epilogue, K swept; time per round = (K / 64) c + o.  The vendor library on the same shapes for calibration.
+        import torch.nn.functional as F
+        M, N = 65536, 4096
+        for K in (512, 1024, 2048, 4096, 8192):
+            a = rnd(M, K)
+            wt = torch.randn(N, K, generator=g, device=dev) / math.sqrt(K)
+            w = packing.pack_matrix(wt, dev)
+            c = ops.empty(M, N)
+            b = torch.zeros(N, dtype=torch.float32, device=dev)
+            rounds = (M // 256) * (N // 256) / 256
+            for opt, label in ((0, "gemm_kernel"), (1, "gemm_w4"), (2, "gemm_w4p")):
+                ops.set_option("gemm_w4", opt)
+                sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, bias=b), args.reps)
+                report(f"ksweep {label} K={K}", sec, flops=2.0 * M * N * K)
+                out[-1]["us_per_round"] = round(sec * 1e6 / rounds, 2)
+            ops.set_option("gemm_w4", 0)
+            wb = wt.to(BF16)
+            sec = timeit(lambda: F.linear(a, wb), args.reps)
+            report(f"ksweep hipBLASLt K={K}", sec, flops=2.0 * M * N * K)
+            out[-1]["us_per_round"] = round(sec * 1e6 / rounds, 2)
+            del a, w, c, wb, wt
+        fit = {}
+        for r in out:
+            if r["kernel"].startswith("ksweep"):
+                _, label, k = r["kernel"].split()
+                fit.setdefault(label, []).append((int(k[2:]) // 64, r["us"] / 16.0))
+        for label, pts in fit.items():
+            n = len(pts)
+            sx, sy = sum(p[0] for p in pts), sum(p[1] for p in pts)
+            sxx, sxy = sum(p[0] * p[0] for p in pts), sum(p[0] * p[1] for p in pts)
+            cc = (n * sxy - sx * sy) / (n * sxx - sx * sx)
+            print(json.dumps({"fit": label, "us_per_k_tile": round(cc, 4), "us_per_output_tile": round((sy - cc * sx) / n, 3),
+                              "k_loop_tflops": round(2.0 * 256 * 256 * 64 * 256 / cc / 1e6, 1)}), flush=True)
     if "blaslt" in only:
         # calibration only (never on the product path): the vendor library's GEMM (hipBLASLt behind torch) on the same four shapes, same box
         import torch.nn.functional as F
