@@ -234,7 +234,7 @@ SVR_DEVICE void epilogue_store8(const svr_gemm_args& a, const float (&acc8)[8], 
 // epilogue's 8-byte scattered stores, 16 rows x 32 bytes per instruction, were most of the kernel's time.)
 // Round 3: the store side runs in branch-free sweeps of four rows per thread -- their LDS reads, then their residual loads,
 // are all in flight before the first store -- and a pass parks four row fragments per wave where LDS allows it (half the
-// barriers).  Measured on gemm_w4_kernel (one workgroup per CU: nothing else covers a tile's epilogue), the row-at-a-time
+// barriers).  Measured on the four-wave kernel (one workgroup per CU: nothing else covers a tile's epilogue), the row-at-a-time
 // form cost 16-40 % of the kernel (profiles/r3_gemm_w4_ablations.txt).
 template <int BM, int BN, int WM, int WN> constexpr int epilogue_lds_bytes() {
     return (BM / WM) * ((WM / 16) % 4 == 0 ? 4 : 2) * 16 * (BN * 4 + 16);
@@ -396,7 +396,7 @@ SVR_DEVICE void epilogue_generic_lds(const svr_gemm_args& a, const ACC& acc, cha
 // the pass), the variant is a template argument, and an instance is ~2-3 KB.  Same arithmetic in the same order as the generic
 // form -> bit-identical results.
 template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES, bool M32, int RI_FORCE, int SW_FORCE, int EDBG, int RES_REGS_,
-          int EPI, bool OUT_F32, bool RESID_F32, typename ACC>
+          int EPI, bool OUT_F32, bool RESID_F32, bool PS, typename ACC>
 SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
     constexpr int WAVES_N = BN / WN, FM = WM / 16, FN = WN / 16;
     constexpr int WAVES_M = BM / WM;
@@ -432,6 +432,13 @@ SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char*
             gate8[4] = g1.x; gate8[5] = g1.y; gate8[6] = g1.z; gate8[7] = g1.w;
         }
     }
+    int ps_z = 0, ps_xy = 0, ps_c = 0;                   // pixel shuffle: this thread's 8 columns = channels ps_c .. + 7 of sub-position (xy, z)
+    if constexpr (PS) {
+        const int blk = n / a.ps.C;
+        ps_c = n - blk * a.ps.C;
+        ps_z = blk % a.ps.rz;
+        ps_xy = blk / a.ps.rz;
+    }
     auto park = [&](auto pc) {                           // pass P: RI row fragments of every wave -> fp32 rows in LDS
         constexpr int P = decltype(pc)::value;
         if constexpr (P < NPASS) {
@@ -462,7 +469,7 @@ SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char*
     // Residual rows travel ahead of their use: a sweep that loads its own rows waits a full memory latency each time (measured: 16
     // sweeps of ~1.2 us = 19 us per 256 x 256 tile against 5.6 us without a residual).  RES_REGS = the 16-byte register sets the
     // caller can spare:
-    //   RES_REGS >= 0 (gemm_w4*_kernel): the rows of a pass are loaded before the tile is parked -- the pass barriers are s_barrier +
+    //   RES_REGS >= 0 (gemm_w4p_kernel): the rows of a pass are loaded before the tile is parked -- the pass barriers are s_barrier +
     //     lgkmcnt only (__syncthreads() would wait for the loads) -- 19 -> 13 us.  (A ring ACROSS passes, slot reloaded with the
     //     next pass's row when consumed, measured 18 us: vmcnt counts in order, so waiting for a load issued behind the previous
     //     pass's stores waits for those stores.)
@@ -572,7 +579,20 @@ SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char*
                             for (int e = 0; e < 8; ++e) v[e] += r8[it][e];
                         }
                     }
-                    off = (int64_t)mrow[it] * a.ldc + n;
+                    if constexpr (PS) {                     // pixel-shuffle scatter (the upsamplers): same index arithmetic as epilogue_store8
+                        const int m = mrow[it];
+                        const int pw = m % a.ps.W, r2 = m / a.ps.W;
+                        const int ph = r2 % a.ps.H, pf = r2 / a.ps.H;
+                        int fo = pf * a.ps.rz + ps_z;
+                        if (a.ps.drop_first) {
+                            if (fo == 1) continue;          // duplicated head frame (remove_head)
+                            if (fo > 1) fo -= 1;
+                        }
+                        const int yo = ph * 2 + (ps_xy >> 1), xo = pw * 2 + (ps_xy & 1);
+                        off = (((int64_t)fo * (2 * a.ps.H) + yo) * (2 * a.ps.W) + xo) * a.ps.C + ps_c;
+                    } else {
+                        off = (int64_t)mrow[it] * a.ldc + n;
+                    }
                 }
                 if (mrow[it] >= a.M || (EDBG & 1)) continue;
                 if constexpr (OUT_F32) {
@@ -597,7 +617,7 @@ template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES, bool M32 
           bool PLAIN_ONLY = false, int RES_REGS = -8, typename ACC>
 SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
 #define SVR_EPI_CASE(E, OF, RF) \
-    epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, E, OF, RF>(a, acc, smem, m0, n0, tid, lane, wave)
+    epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, E, OF, RF, false>(a, acc, smem, m0, n0, tid, lane, wave)
     if (PLAIN_ONLY || (!a.ps.enabled && !a.phase.enabled)) {
         const int of = a.out_f32 ? 1 : 0, rf = (a.epilogue == SVR_EPI_RESID_GATE && a.resid && a.resid_f32) ? 1 : 0;
         switch (a.epilogue * 4 + of * 2 + rf) {
@@ -613,6 +633,14 @@ SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, cha
             case SVR_EPI_RESID_GATE * 4 + 1: SVR_EPI_CASE(SVR_EPI_RESID_GATE, false, true); return;
             case SVR_EPI_RESID_GATE * 4 + 2: SVR_EPI_CASE(SVR_EPI_RESID_GATE, true, false); return;
             default:                         SVR_EPI_CASE(SVR_EPI_RESID_GATE, true, true); return;
+        }
+    }
+    if constexpr (!PLAIN_ONLY) {
+        // the pixel-shuffle upsamplers (2 .. 8 K tiles per output tile: the epilogue IS the kernel): bias epilogue, whole 8-channel chunks
+        if (a.ps.enabled && !a.phase.enabled && a.epilogue == SVR_EPI_BIAS && (a.ps.C % 8) == 0) {
+            if (a.out_f32) epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, SVR_EPI_BIAS, true, false, true>(a, acc, smem, m0, n0, tid, lane, wave);
+            else epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, SVR_EPI_BIAS, false, false, true>(a, acc, smem, m0, n0, tid, lane, wave);
+            return;
         }
     }
 #undef SVR_EPI_CASE
@@ -785,32 +813,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// gemm_w4_kernel (round 3): the plain GEMMs of the NaDiT (M = 291 600 tokens at BASELINE config 3) in the shape of the vendor
-// library's kernel for them (hipBLASLt MT256x256x64, 4 waves of 8 x 8 fragments, direct-to-LDS, PGR2 -- read from its kernel
-// name and metadata; 1.36-1.49 PFLOP/s where gemm_kernel reaches 0.94-1.23 on the same box): 256 x 256 x 64 tiles, FOUR waves
-// of 128 x 128 (256 accumulators per lane: one wave per SIMD), both operands by 16-byte LDS-DMA into two 64 KiB stages.
-// History of this kernel (profiles/r3_gemm_w4_ablations.txt): with v_mfma_f32_16x16x32 it tied gemm_kernel in three schedules,
-// and its in-place ablations showed the costs ADD UP instead of overlapping -- MFMAs 1.0, LDS-DMA pieces 0.44, fragment reads
-// 0.06, epilogue 0.3-0.47 of the matrix time: with one wave per SIMD an LDS-DMA piece blocks the wave's issue for ~56 cycles
-// (MI355X_MICROARCH.md) and a 16-cycle MFMA in flight cannot cover that.  Hence v_mfma_f32_32x32x16 here (half as many, twice
-// as long matrix instructions: a piece now hides behind two of them, a fragment read behind one), as in the conv kernels:
-//   K tile t (stage s = t & 1) = four k16 steps of 16 MFMAs; fragment sets X (steps 0, 2) and Y (steps 1, 3), 32 VGPRs each;
-//   step k:  lgkmcnt(0) -> its fragments (read during step k - 1) are there; 16 MFMAs; the 8 fragment reads of step k + 1 and
-//            8 LDS-DMA pieces ride in the slots between them, never two pieces in a row;
-//   step 0:  pieces 8..15 of K tile t + 1 -> stage s ^ 1;
-//   step 3:  first vmcnt(0) + THE barrier of the tile: every wave has read stage s for the last time (step 3's fragments were
-//            read during step 2) and K tile t + 1 has landed in stage s ^ 1; then the reads of its step 0 and pieces 0..7 of
-//            K tile t + 2 -> stage s.
-// Fragment reads and MFMAs are inline asm ("+a" pins the 256 accumulators to AGPRs for the whole loop: with the builtin hipcc
-// split them between the register files and moved ~370 registers per K tile); every consumer sits behind a counted wait.
-// LDS rows are 128 B; chunk c of row r sits at position c ^ ((r >> 1) & 7) (source-side XOR: LDS-DMA destinations are
-// lane-linear), which makes the 32-row fragment reads of ds_read_b128 bank-conflict free in all four of its lane groups.
-// Different MFMA shape = different fp32 summation order than gemm_kernel: equal to the fp32 restatement within the same
-// tolerances, not bit-identical to the eight-wave kernel.
-// ------------------------------------------------------------------------------------------------
+// ---- shared pieces of the four-wave kernel below: 256 x 256 tile, 64 KiB per K-tile stage, inline-asm fragment reads / MFMAs / waits
 constexpr int W4_THREADS = 256, W4_T = 256, W4_STAGE = 2 * W4_T * BK * 2;                            // 64 KiB per stage
-constexpr int W4_LDS = 2 * W4_STAGE > epilogue_lds_bytes<W4_T, W4_T, 128, 128>() ? 2 * W4_STAGE : epilogue_lds_bytes<W4_T, W4_T, 128, 128>();
 
 template <int OFF> SVR_DEVICE void w4_rd(bf16x8& r, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r) : "v"(addr), "n"(OFF) : "memory");
@@ -822,193 +826,34 @@ template <bool ON = true> SVR_DEVICE void w4_mfma_t(f32x16& c, const bf16x8& w, 
 template <int N> SVR_DEVICE void w4_wait_lgkm_n() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N> SVR_DEVICE void w4_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// ABL (builds with -DSVR_ABLATIONS only; results invalid): 1 no LDS-DMA in the K loop, 2 no fragment reads in the K loop, 4 no
-// barriers in the K loop, 8 no MFMAs, 16 no epilogue
-template <int ABL>
-__global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4_kernel(const svr_gemm_args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    // ---- tile id: XCD-contiguous bands, then grouped (4 row panels x all column panels) order (as gemm_kernel)
-    const int tiles_m = (a.M + W4_T - 1) / W4_T;
-    const int tiles_n = a.N / W4_T;
-    int t;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, j = bid >> 3, q = nwg >> 3, r = nwg & 7;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    constexpr int GM = 4;
-    const int group_size = GM * tiles_n;
-    const int group = t / group_size;
-    const int first_m = group * GM;
-    const int gm = min(tiles_m - first_m, GM);
-    const int tm = first_m + (t % group_size) % gm;
-    const int tn = (t % group_size) / gm;
-    const int m0 = tm * W4_T, n0 = tn * W4_T;
-
-    // ---- staging roles: piece q (0..7) of an operand = rows q * 32 + wave * 8 + (lane >> 3), position (lane & 7) of the row's eight
-    // 16-byte chunks; the lane at position p fetches SOURCE chunk p ^ key(row), key = (row >> 1) & 7
-    const int srow = wave * 8 + (lane >> 3);
-    const int chunk_src = (lane & 7) ^ ((srow >> 1) & 7);
-    const char* const Abase = (const char*)a.A + (int64_t)m0 * a.lda * 2;
-    const char* const Bbase = (const char*)a.W + (int64_t)n0 * a.K * 2;
-    uint32_t aoff[8];                                      // byte offset of this thread's chunk in piece q of A, rows clamped to M - 1
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-        aoff[q] = (uint32_t)((int64_t)(min(m0 + q * 32 + srow, a.M - 1) - m0) * a.lda * 2) + chunk_src * 16;
-    const uint32_t boff = (uint32_t)((int64_t)srow * a.K * 2) + chunk_src * 16;
-    const uint32_t bstep = (uint32_t)(32 * a.K * 2);       // W is padded to whole 128-row panels and N % 256 == 0: no clamp
-    char* const dstA = smem + wave * 1024;                 // + stage * W4_STAGE + q * 4096
-    char* const dstB = dstA + W4_T * BK * 2;
-    auto dmaA = [&](auto qc, int kt, int st) {             // piece q of A, K tile kt -> stage st
-        constexpr int Q = decltype(qc)::value;
-        glds16(Abase + aoff[Q] + (int64_t)kt * (BK * 2), dstA + st * W4_STAGE + Q * 4096);
-    };
-    auto dmaB = [&](auto qc, int kt, int st) {
-        constexpr int Q = decltype(qc)::value;
-        glds16(Bbase + (boff + Q * bstep) + (int64_t)kt * (BK * 2), dstB + st * W4_STAGE + Q * 4096);
-    };
-
-    // ---- compute roles: wave (wm, wn) owns rows wm * 128 .., columns wn * 128 ..; a 32x32x16 operand fragment = 32 rows x 16 k:
-    // lane l supplies row (l & 31), k 8 (l >> 5) .. + 7 = chunk 2 ks + (l >> 5) of the row, at position chunk ^ key
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned key = (unsigned)((l31 >> 1) & 7);
-    const unsigned rA = lds0 + (unsigned)((wm * 128 + l31) * 128), rB = lds0 + (unsigned)(W4_T * BK * 2 + (wn * 128 + l31) * 128);
-    // read addresses [k16 step] of the CURRENT stage (flipped to the other stage by an add / sub once per K tile); the fragment index
-    // (32 rows = 4096 bytes) is an immediate offset
-    unsigned rdA[4], rdB[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const unsigned po = (((unsigned)(2 * ks + hi)) ^ key) << 4;
-        rdA[ks] = rA + po;
-        rdB[ks] = rB + po;
-    }
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    bf16x8 AX[4], BX[4], AY[4], BY[4];
-
-#define W4_IN_PROLOGUE true
-#define W4_RD(DST, BASE, I) do { if constexpr (!(ABL & 2) || W4_IN_PROLOGUE) w4_rd<(I) * 4096>(DST[I], BASE); } while (0)
-#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define w4_mfma w4_mfma_t<!(ABL & 8)>
-#define W4_Q(Q) std::integral_constant<int, Q>{}
-
-    const int nk = a.K / BK;
-    // ---- prologue: K tile 0 and the first half of K tile 1 on their way; fragments of tile 0 / step 0 being read
-    dmaA(W4_Q(0), 0, 0); dmaB(W4_Q(0), 0, 0); dmaA(W4_Q(1), 0, 0); dmaB(W4_Q(1), 0, 0);
-    dmaA(W4_Q(2), 0, 0); dmaB(W4_Q(2), 0, 0); dmaA(W4_Q(3), 0, 0); dmaB(W4_Q(3), 0, 0);
-    dmaA(W4_Q(4), 0, 0); dmaB(W4_Q(4), 0, 0); dmaA(W4_Q(5), 0, 0); dmaB(W4_Q(5), 0, 0);
-    dmaA(W4_Q(6), 0, 0); dmaB(W4_Q(6), 0, 0); dmaA(W4_Q(7), 0, 0); dmaB(W4_Q(7), 0, 0);
-    dmaA(W4_Q(0), 1, 1); dmaB(W4_Q(0), 1, 1); dmaA(W4_Q(1), 1, 1); dmaB(W4_Q(1), 1, 1);
-    dmaA(W4_Q(2), 1, 1); dmaB(W4_Q(2), 1, 1); dmaA(W4_Q(3), 1, 1); dmaB(W4_Q(3), 1, 1);
-    W4_FENCE();
-    w4_wait_vmcnt<8>();                                    // K tile 0 has landed (the eight pieces of tile 1 may still be in flight)
-    __builtin_amdgcn_s_barrier();
-    W4_FENCE();
-    W4_RD(BX, rdB[0], 0); W4_RD(BX, rdB[0], 1); W4_RD(BX, rdB[0], 2); W4_RD(BX, rdB[0], 3);
-    W4_RD(AX, rdA[0], 0); W4_RD(AX, rdA[0], 1); W4_RD(AX, rdA[0], 2); W4_RD(AX, rdA[0], 3);
-    W4_FENCE();
-#undef W4_IN_PROLOGUE
-#define W4_IN_PROLOGUE false
-
-// one k16 step: 16 MFMAs of fragment sets (AF, BF); SIDEn = the side operation riding behind MFMA n (a statement or nothing)
-#define W4_STEP(AF, BF, S0, S1, S2, S3, S4, S5, S6, S7, S8, S9, S10, S11, S12, S13, S14, S15) \
-        w4_mfma(acc[0][0], BF[0], AF[0]); W4_FENCE(); S0;  W4_FENCE(); w4_mfma(acc[0][1], BF[1], AF[0]); W4_FENCE(); S1;  W4_FENCE(); \
-        w4_mfma(acc[0][2], BF[2], AF[0]); W4_FENCE(); S2;  W4_FENCE(); w4_mfma(acc[0][3], BF[3], AF[0]); W4_FENCE(); S3;  W4_FENCE(); \
-        w4_mfma(acc[1][0], BF[0], AF[1]); W4_FENCE(); S4;  W4_FENCE(); w4_mfma(acc[1][1], BF[1], AF[1]); W4_FENCE(); S5;  W4_FENCE(); \
-        w4_mfma(acc[1][2], BF[2], AF[1]); W4_FENCE(); S6;  W4_FENCE(); w4_mfma(acc[1][3], BF[3], AF[1]); W4_FENCE(); S7;  W4_FENCE(); \
-        w4_mfma(acc[2][0], BF[0], AF[2]); W4_FENCE(); S8;  W4_FENCE(); w4_mfma(acc[2][1], BF[1], AF[2]); W4_FENCE(); S9;  W4_FENCE(); \
-        w4_mfma(acc[2][2], BF[2], AF[2]); W4_FENCE(); S10; W4_FENCE(); w4_mfma(acc[2][3], BF[3], AF[2]); W4_FENCE(); S11; W4_FENCE(); \
-        w4_mfma(acc[3][0], BF[0], AF[3]); W4_FENCE(); S12; W4_FENCE(); w4_mfma(acc[3][1], BF[1], AF[3]); W4_FENCE(); S13; W4_FENCE(); \
-        w4_mfma(acc[3][2], BF[2], AF[3]); W4_FENCE(); S14; W4_FENCE(); w4_mfma(acc[3][3], BF[3], AF[3]); W4_FENCE(); S15; W4_FENCE()
-#define W4_NOP ((void)0)
-
-    // ONE loop body for every K tile (a peeled tail makes hipcc shuffle the accumulators between register files at its entry): the
-    // stage is a run-time bit, the tail tiles skip their DMA pieces behind scalar branches, the last tile's look-ahead reads fetch
-    // stale bytes nobody uses.
-    for (int kt = 0; kt < nk; ++kt) {
-        const int st = kt & 1;
-        const bool next = kt + 1 < nk && !(ABL & 1), more = kt + 2 < nk && !(ABL & 1);
-        // ---- step 0 (set X); reads of step 1 -> Y; pieces 4..7 of K tile kt + 1 -> the other stage (freed at the last barrier)
-        w4_wait_lgkm_n<0>();
-        W4_STEP(AX, BX,
-                W4_RD(BY, rdB[1], 0), if (next) dmaA(W4_Q(4), kt + 1, st ^ 1), W4_RD(BY, rdB[1], 1), if (next) dmaB(W4_Q(4), kt + 1, st ^ 1),
-                W4_RD(BY, rdB[1], 2), if (next) dmaA(W4_Q(5), kt + 1, st ^ 1), W4_RD(BY, rdB[1], 3), if (next) dmaB(W4_Q(5), kt + 1, st ^ 1),
-                W4_RD(AY, rdA[1], 0), if (next) dmaA(W4_Q(6), kt + 1, st ^ 1), W4_RD(AY, rdA[1], 1), if (next) dmaB(W4_Q(6), kt + 1, st ^ 1),
-                W4_RD(AY, rdA[1], 2), if (next) dmaA(W4_Q(7), kt + 1, st ^ 1), W4_RD(AY, rdA[1], 3), if (next) dmaB(W4_Q(7), kt + 1, st ^ 1));
-        // ---- step 1 (set Y); reads of step 2 -> X
-        w4_wait_lgkm_n<0>();
-        W4_STEP(AY, BY,
-                W4_RD(BX, rdB[2], 0), W4_NOP, W4_RD(BX, rdB[2], 1), W4_NOP, W4_RD(BX, rdB[2], 2), W4_NOP, W4_RD(BX, rdB[2], 3), W4_NOP,
-                W4_RD(AX, rdA[2], 0), W4_NOP, W4_RD(AX, rdA[2], 1), W4_NOP, W4_RD(AX, rdA[2], 2), W4_NOP, W4_RD(AX, rdA[2], 3), W4_NOP);
-        // ---- step 2 (set X); reads of step 3 -> Y: the last reads of this stage
-        w4_wait_lgkm_n<0>();
-        W4_STEP(AX, BX,
-                W4_RD(BY, rdB[3], 0), W4_NOP, W4_RD(BY, rdB[3], 1), W4_NOP, W4_RD(BY, rdB[3], 2), W4_NOP, W4_RD(BY, rdB[3], 3), W4_NOP,
-                W4_RD(AY, rdA[3], 0), W4_NOP, W4_RD(AY, rdA[3], 1), W4_NOP, W4_RD(AY, rdA[3], 2), W4_NOP, W4_RD(AY, rdA[3], 3), W4_NOP);
-        // ---- the barrier of the tile: this wave's reads of stage st are complete (lgkmcnt) and its pieces of K tile kt + 1 have landed
-        // (vmcnt: the youngest were issued two steps ago); past it that holds for every wave
-        w4_wait_lgkm_n<0>();
-        w4_wait_vmcnt<0>();
-        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
-        W4_FENCE();
-        {
-            const unsigned d = st ? (unsigned)-W4_STAGE : (unsigned)W4_STAGE;      // flip the read addresses to the other stage
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { rdA[ks] += d; rdB[ks] += d; }
-        }
-        // ---- step 3 (set Y); reads of K tile kt + 1 / step 0 -> X (other stage); pieces 0..3 of K tile kt + 2 -> this stage
-        W4_STEP(AY, BY,
-                W4_RD(BX, rdB[0], 0), if (more) dmaA(W4_Q(0), kt + 2, st), W4_RD(BX, rdB[0], 1), if (more) dmaB(W4_Q(0), kt + 2, st),
-                W4_RD(BX, rdB[0], 2), if (more) dmaA(W4_Q(1), kt + 2, st), W4_RD(BX, rdB[0], 3), if (more) dmaB(W4_Q(1), kt + 2, st),
-                W4_RD(AX, rdA[0], 0), if (more) dmaA(W4_Q(2), kt + 2, st), W4_RD(AX, rdA[0], 1), if (more) dmaB(W4_Q(2), kt + 2, st),
-                W4_RD(AX, rdA[0], 2), if (more) dmaA(W4_Q(3), kt + 2, st), W4_RD(AX, rdA[0], 3), if (more) dmaB(W4_Q(3), kt + 2, st));
-    }
-    w4_wait_lgkm_n<0>();
-#undef W4_RD
-#undef W4_FENCE
-#undef w4_mfma
-#undef W4_Q
-#undef W4_STEP
-#undef W4_NOP
-#undef W4_IN_PROLOGUE
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs retire before the accumulators are read
-    // (no LDS-DMA in flight: the tail tiles issue none and the last barrier waited vmcnt(0); the barrier orders the last look-ahead
-    // reads of the other waves before the first epilogue pass overwrites the stages)
-    __syncthreads();
-    if constexpr (!(ABL & 16)) epilogue_through_lds<W4_T, W4_T, 128, 128, W4_THREADS, W4_LDS, true, 0, 0, 0, true, 16>(a, acc, smem, m0, n0, tid, lane, wave);
-    else if (a.M < 0) *(float*)a.C = acc[0][0][0];      // (keeps the accumulators alive)
-}
-
 // ------------------------------------------------------------------------------------------------
-// gemm_w4p_kernel: PERSISTENT workgroups, operands staged through registers, one pipeline across output tiles.
-// Why (profiles/r3_gemm_w4_ablations.txt section 6, tools/kbench.py --only ksweep: time per round of tiles = (K / 64) c + o):
-//     gemm_kernel  c = 1.71 us, o = 13 us | gemm_w4_kernel  c = 1.50, o = 22 | vendor library  c = 1.21, o = 11
-// gemm_w4_kernel's K loop is the fastest of ours, and it throws that away between tiles: workgroup launch, a cold two-tile
-// prologue, and an epilogue nothing overlaps = 15 K tiles' worth per output tile (qkv has 40).  Here one workgroup per CU walks its
-// tiles (t += grid; XCD x takes the x-th 32-tile chunk of every round: 4 row panels x 8 column panels share its L2) and the operand
-// stream never stops: the loads run two K tiles ahead ACROSS tile boundaries, so a tile's epilogue runs with the next tile's first
-// K tile in LDS and its second in flight, and the next MFMA follows the last store.
-//   staging through registers (global_load_dwordx4 -> 64 VGPRs -> ds_write_b128; measured equal to LDS-DMA inside the K loop)
-//   is what makes that possible with two LDS stages: a K tile sits in registers for a whole K tile before it needs its stage.
-//   K tile f (stage s), registers holding K tile f + 1 at its start:
-//   steps 0, 1:  per piece: vmcnt(15) -> it has arrived; ds_write it into stage s ^ 1; load the same piece of K tile f + 2;
+// gemm_w4p_kernel (round 3; opt-in, svr_set_option("gemm_w4", 1)): the plain GEMMs of the NaDiT (M = 291 600 tokens at BASELINE
+// config 3) in the shape of the vendor library's kernel for them -- 256 x 256 x 64 tiles, FOUR waves of 128 x 128, 256 accumulators
+// per lane pinned to AGPRs, one wave per SIMD -- as PERSISTENT workgroups with the operands staged through registers and one
+// pipeline across output tiles.  History (profiles/r3_gemm_w4_ablations.txt): five non-persistent versions of this shape (16x16x32 and
+// 32x32x16 MFMAs, operands by LDS-DMA or through registers) all measured within +-4 % of the eight-wave gemm_kernel; what the
+// measurements of THIS kernel found is in the sections named below.
+//   tools/kbench.py --only ksweep (time per round of tiles = (K / 64) c + o):
+//     gemm_kernel  c = 1.6 us, o = 11 us | this kernel  c = 1.57, o = 11 | vendor library  c = 1.25, o = 9
+//   One workgroup per CU walks its tiles (t += grid; XCD x takes the x-th 32-tile chunk of every round: 4 row panels x 8 column
+//   panels share its L2) and the operand stream never stops: the loads run two K tiles ahead ACROSS tile boundaries, so a tile's
+//   epilogue runs with the next tile's first K tile in LDS and its second in flight, and the next MFMA follows the last store.
+//   Staging through registers (global / buffer_load_dwordx4 -> 64 VGPRs -> ds_write_b128; measured equal to LDS-DMA inside the K
+//   loop: ~29 cycles per KiB piece either way) is what makes that possible with two LDS stages: a K tile sits in registers for a
+//   whole K tile before it needs its stage.
+//   K tile f (stage s), registers holding K tile f + 1 at its start; four k16 steps of 16 v_mfma_f32_32x32x16, fragment sets X / Y:
+//   steps 0, 1:  reads of the next step in the first eight slots; then per piece: vmcnt(15) -> it has arrived; ds_write it into stage
+//                s ^ 1; load the same piece of K tile f + 2;
 //   step 3:      lgkmcnt(0) + THE barrier (every wave's writes of f + 1 are in LDS, its reads of stage s done); reads of f + 1 / step 0.
 //   tile end:    vmcnt(0); epilogue through the free stage + the 32 KiB between the stages (96 KiB: four passes of 64 rows);
 //                barrier; accumulators zeroed; step-0 fragments of the next tile re-read.
-// LDS: [stage 0: 64 KiB][32 KiB][stage 1: 64 KiB] = 160 KiB.  Same LDS layout inside a stage, fragment reads and MFMA order as
-// gemm_w4_kernel -> bit-identical results to it.
+//   Step-level cycle accounting (measurement build, section 8): a step with fragment reads only runs at the MFMA rate (492 / 512);
+//   eight moves add ~230 cycles to a step; the barrier ~40 + ~160 of re-alignment; VALU / scalar work in front of a step's first
+//   MFMA is paid in full (the stage flip and the load cursor cost 156 + 92 there and nothing in the step's free slots).
+// LDS: [stage 0: 64 KiB][32 KiB][stage 1: 64 KiB] = 160 KiB.  LDS rows are 128 B; chunk c of row r sits at position
+// c ^ ((r >> 1) & 7) (source-side XOR), which makes the 32-row fragment reads of ds_read_b128 bank-conflict free.  Different MFMA
+// shape = different fp32 summation order than gemm_kernel: equal to the fp32 restatement within the same tolerances, not
+// bit-identical to the eight-wave kernel.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) uint32_t w4p_u32x4;
 SVR_DEVICE void w4p_gload(w4p_u32x4& r, const char* sbase, uint32_t voff) {
@@ -1031,7 +876,7 @@ constexpr int W4P_EPI = W4P_S1;                            // the epilogue's par
 
 // TL (builds with -DSVR_ABLATIONS only): wave 0 stamps the 100 MHz clock at each tile's K-loop start / K-loop end / epilogue end
 template <bool TL, int EDBG = 0>
-__global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_args a, const int stagger_ticks, uint64_t* timeline) {
+__global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_args a, uint64_t* timeline) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1052,17 +897,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_
     int t = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);      // tile being computed
     int m0, n0;
     tile_origin(t, m0, n0);
-    // ---- stagger: every workgroup runs the same number of K tiles per output tile, so without this all 256 CUs reach their epilogues
-    // in the same microseconds, for the whole kernel: 32 MiB of stores at once and nothing computing (measured: 17-22 us per round of
-    // tiles, tools/kbench.py --only ksweep).  XCD x starts x / 8 of a tile late (its 32 workgroups stay in step: they share the K
-    // slices in its L2); an eighth of the chip is in its epilogue at any time.  Cost: 7 / 8 of one tile time per launch.
-    if (stagger_ticks > 0 && (blockIdx.x & 7) != 0) {
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
-        const uint64_t wait = (uint64_t)(blockIdx.x & 7) * (uint64_t)stagger_ticks;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
-
-    // ---- staging roles (as gemm_w4_kernel): piece q = rows q * 32 + wave * 8 + (lane >> 3); the lane at position p = lane & 7 of
+    // ---- staging roles : piece q = rows q * 32 + wave * 8 + (lane >> 3); the lane at position p = lane & 7 of
     // its row loads SOURCE chunk p ^ key(row) and stores it lane-linearly
     const int srow = wave * 8 + (lane >> 3);
     const int chunk_src = (lane & 7) ^ ((srow >> 1) & 7);
@@ -1088,16 +923,20 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_
         Bbase = (const char*)a.W + (int64_t)ln0 * a.K * 2;
     };
     const int nk = a.K / BK;
-    auto advance_cursor = [&]() {                          // after the 16 loads of (tl, kl)
-        if (++kl < nk) {
-            Akoff += BK * 2; Bbase += BK * 2;
-        } else if (tl + nwg < tiles) {
-            tl += nwg; kl = 0;
-            int lm0, ln0;
-            tile_origin(tl, lm0, ln0);
-            point_cursor(lm0, ln0);
-        } else {
-            kl = nk - 1;                                   // no tile left: keep re-loading the last K tile (written to a stage nobody reads)
+    auto advance_cursor = [&]() {                          // after the 16 loads of (tl, kl); the common case is branch-free scalar code
+        ++kl;
+        const bool same = kl < nk;
+        Akoff = same ? Akoff + BK * 2 : Akoff;
+        Bbase = same ? Bbase + BK * 2 : Bbase;
+        if (__builtin_expect(!same, 0)) {
+            if (tl + nwg < tiles) {
+                tl += nwg; kl = 0;
+                int lm0, ln0;
+                tile_origin(tl, lm0, ln0);
+                point_cursor(lm0, ln0);
+            } else {
+                kl = nk - 1;                               // no tile left: keep re-loading the last K tile (written to a stage nobody reads)
+            }
         }
     };
     point_cursor(m0, n0);
@@ -1219,24 +1058,23 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_
             // ---- the barrier of the K tile: this wave's reads of stage st and its writes of the next K tile are complete (lgkmcnt counts both)
             w4_wait_lgkm_n<0>();
             clap(2);
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(EDBG & 8)) __builtin_amdgcn_s_barrier();
             clap(3);
             W4_FENCE();
-            {
-                const unsigned d = st ? (unsigned)-W4P_S1 : (unsigned)W4P_S1;      // reads flip to the other stage, writes to this one
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) { rdA[ks] += d; rdB[ks] += d; }
-                wrA -= d; wrB -= d;
-                st ^= 1;
-            }
-            advance_cursor();
+            // The stage flip (ten VALU adds on address registers) and the load cursor (scalar code) cost 156 + 92 cycles per K tile when
+            // they sat here, in front of the step's first MFMA with the matrix pipe idle behind the barrier (measured by leaving each
+            // out).  Only the two addresses the step's own reads use are flipped here; the rest ride in its free slots behind MFMAs.
+            const unsigned d = st ? (unsigned)-W4P_S1 : (unsigned)W4P_S1;      // reads flip to the other stage, writes to this one
+            if constexpr (!(EDBG & 16)) { rdA[0] += d; rdB[0] += d; }
+#define W4_FLIP2(x, y) do { if constexpr (!(EDBG & 16)) { x += d; y += d; } } while (0)
             // ---- step 3 (set Y); reads of the next K tile / step 0 -> X (other stage; at a tile's end they are re-read after the epilogue)
-            // (the barrier has just lined the four waves up: eight reads per wave in eight consecutive slots would ask the LDS for its whole
-            // 128 B/clk at once -- measured 786 cycles for this step against 492 for step 2 -- so the later fragments are spaced out)
             W4_STEP(AY, BY,
                     W4_RD(BX, rdB[0], 0), W4_RD(BX, rdB[0], 1), W4_RD(BX, rdB[0], 2), W4_RD(BX, rdB[0], 3),
-                    W4_RD(AX, rdA[0], 0), W4_NOP, W4_RD(AX, rdA[0], 1), W4_NOP, W4_RD(AX, rdA[0], 2), W4_NOP, W4_RD(AX, rdA[0], 3), W4_NOP,
-                    W4_NOP, W4_NOP, W4_NOP, W4_NOP);
+                    W4_RD(AX, rdA[0], 0), W4_RD(AX, rdA[0], 1), W4_RD(AX, rdA[0], 2), W4_RD(AX, rdA[0], 3),
+                    W4_FLIP2(rdA[1], rdB[1]), W4_FLIP2(rdA[2], rdB[2]), W4_FLIP2(rdA[3], rdB[3]),
+                    do { if constexpr (!(EDBG & 16)) { wrA -= d; wrB -= d; st ^= 1; } } while (0),
+                    do { if constexpr (!(EDBG & 32)) advance_cursor(); } while (0), W4_NOP, W4_NOP, W4_NOP);
+#undef W4_FLIP2
             if constexpr (TL) { w4_wait_lgkm_n<0>(); clap(4); }
         }
         // ---- tile end.  Stage st holds the next tile's K tile 0, the registers its K tile 1 (in flight); stage st ^ 1 + the gap are free
@@ -1281,41 +1119,30 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_
 #undef W4_NOP
 }
 
-int g_gemm_stagger = 150;   // svr_set_option("gemm_stagger"): 100 MHz ticks per K tile assumed by gemm_w4p_kernel's start stagger (0: off)
-int g_gemm_w4 = 0;     // svr_set_option("gemm_w4"): 1 big plain GEMMs on gemm_w4_kernel | 0 (default) everything on gemm_kernel: the two
-                       // measure within +-4 % of each other (profiles/r3_gemm_w4_ablations.txt says why)
-template <int ABL> static int launch_gemm_w4_t(const svr_gemm_args& a, hipStream_t s) {
-    const int tiles = ((a.M + W4_T - 1) / W4_T) * (a.N / W4_T);
-    static uint64_t lds_attr_done = 0;
-    {
-        const int e = set_max_dynamic_lds((const void*)gemm_w4_kernel<ABL>, W4_LDS, lds_attr_done);
-        if (e != 0) return e;
-    }
-    hipLaunchKernelGGL(gemm_w4_kernel<ABL>, dim3(tiles), dim3(W4_THREADS), W4_LDS, s, a);
-    return (int)hipGetLastError();
-}
-extern int g_pipe_abl;
+extern int g_pipe_abl;  // (defined below)
+int g_gemm_w4 = 0;     // svr_set_option("gemm_w4"): 1 big plain GEMMs on gemm_w4p_kernel | 0 (default) everything on gemm_kernel: the two
+                       // measure within +-3 % of each other (profiles/r3_gemm_w4_ablations.txt says why)
 static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
-    if (g_gemm_w4 == 2) {                                 // persistent workgroups, operands staged through registers
+    {
+        // (a start stagger of 1 / 8 tile per XCD -- so that an eighth of the chip is in its epilogue at any time -- measured nothing: the
+        // XCDs drift apart by a whole tile period within twenty tiles on their own, profiles/r3_gemm_w4_ablations.txt section 7)
         const int tiles = ((a.M + W4_T - 1) / W4_T) * (a.N / W4_T);
         static uint64_t lds_attr_done2 = 0;
         const int e = set_max_dynamic_lds((const void*)gemm_w4p_kernel<false>, W4P_LDS, lds_attr_done2);
         if (e != 0) return e;
         const int grid = std::min(device_cu_count(), tiles) & ~7;       // one workgroup per CU; a multiple of the XCD count
-        // (stagger per XCD = 1 / 8 of an output tile's time: K / 64 K tiles of ~1.5 us = 150 ticks of the 100 MHz clock)
-        const int stagger = grid * 2 <= tiles ? (int)((int64_t)(a.K / BK) * g_gemm_stagger / 8) : 0;
 #ifdef SVR_ABLATIONS
-        if (g_pipe_abl >= 100 && g_pipe_abl <= 104) {     // timeline of the first 64 tiles of every workgroup -> stderr (synchronises);
+        if (g_pipe_abl >= 100 && g_pipe_abl <= 132) {     // timeline of the first 64 tiles of every workgroup -> stderr (synchronises);
                                                           // 101: no global stores | 102: no parking writes | 104: no readout (results invalid)
             static uint64_t* d_tl = nullptr;
             const size_t n = (size_t)grid * 64 * 4 + (size_t)grid * 5;
             if (!d_tl && hipMalloc(&d_tl, (256 * 64 * 4 + 256 * 5) * 8) != hipSuccess) return (int)hipErrorOutOfMemory;
             (void)hipMemsetAsync(d_tl, 0, n * 8, s);
-            static uint64_t lds_attr_done3[4] = {0, 0, 0, 0};
+            static uint64_t lds_attr_done3[7] = {0, 0, 0, 0, 0, 0, 0};
             auto go = [&](auto kern, uint64_t& done) {
                 const int e3 = set_max_dynamic_lds((const void*)kern, W4P_LDS, done);
                 if (e3 != 0) return e3;
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, stagger, d_tl);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, d_tl);
                 return 0;
             };
             int e3 = 0;
@@ -1323,6 +1150,9 @@ static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
                 case 101: e3 = go(gemm_w4p_kernel<true, 1>, lds_attr_done3[1]); break;
                 case 102: e3 = go(gemm_w4p_kernel<true, 2>, lds_attr_done3[2]); break;
                 case 104: e3 = go(gemm_w4p_kernel<true, 4>, lds_attr_done3[3]); break;
+                case 108: e3 = go(gemm_w4p_kernel<true, 8>, lds_attr_done3[4]); break;       // no K-loop barrier
+                case 116: e3 = go(gemm_w4p_kernel<true, 16>, lds_attr_done3[5]); break;      // no stage flip
+                case 132: e3 = go(gemm_w4p_kernel<true, 32>, lds_attr_done3[6]); break;      // no load-cursor advance
                 default:  e3 = go(gemm_w4p_kernel<true, 0>, lds_attr_done3[0]); break;
             }
             if (e3 != 0) return e3;
@@ -1365,21 +1195,9 @@ static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
             return (int)hipGetLastError();
         }
 #endif
-        hipLaunchKernelGGL(gemm_w4p_kernel<false>, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, stagger, (uint64_t*)nullptr);
+        hipLaunchKernelGGL(gemm_w4p_kernel<false>, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, (uint64_t*)nullptr);
         return (int)hipGetLastError();
     }
-#ifdef SVR_ABLATIONS
-    switch (g_pipe_abl) {
-        // (profiles/r3_gemm_w4_ablations.txt also lists 2 = no fragment reads, 4 = no barriers, 7 = 1 + 2 + 4: measured, dropped from
-        // the build to keep its compile time down)
-        case 1: return launch_gemm_w4_t<1>(a, s);
-        case 8: return launch_gemm_w4_t<8>(a, s);
-        case 16: return launch_gemm_w4_t<16>(a, s);
-        case 23: return launch_gemm_w4_t<23>(a, s);
-        default: break;
-    }
-#endif
-    return launch_gemm_w4_t<0>(a, s);
 }
 
 template <int BM, int BN, int WM, int WN, bool CONV, bool EPI_LDS = false>
@@ -1428,7 +1246,7 @@ static bool gemm_epi_lds(const svr_gemm_args& a) {
     if (g_gemm_epi == 1 || !gemm_epi_lds_aligned(a)) return false;
     return g_gemm_epi == 2 || a.epilogue != SVR_EPI_SWIGLU || a.K <= GEMM_EPI_LDS_MAX_K_SWIGLU;
 }
-// what gemm_w4_kernel serves: plain GEMMs with whole 256-column tiles, at least two K tiles, 16-byte aligned rows, the
+// what gemm_w4p_kernel serves: plain GEMMs with whole 256-column tiles, at least two K tiles, 16-byte aligned rows, the
 // row-contiguous epilogue's alignment, and enough tiles to fill the chip (one workgroup per CU)
 static bool gemm_w4_eligible(const svr_gemm_args& a) {
     return g_gemm_w4 && !a.conv.enabled && !a.ps.enabled && !a.phase.enabled && (a.N % 256) == 0 && a.K >= 2 * BK &&
