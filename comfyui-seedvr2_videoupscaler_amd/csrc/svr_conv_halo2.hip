@@ -926,6 +926,7 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
         case 16: return launch_conv_halo2_t<16, 3, 16>(a, s);       // no halo staging in the K loop
         case 1: return launch_conv_halo2_t<16, 3, 1>(a, s);         // no weight loads
         case 64: return launch_conv_halo2_t<16, 3, 64>(a, s);       // no fragment reads
+        case 4: return launch_conv_halo2_t<16, 3, 4>(a, s);         // no global stores (the epilogue's read-out side is dead code then)
         default: break;
     }
 #endif
