@@ -92,6 +92,11 @@ static inline int set_max_dynamic_lds(const void* kern, int bytes, uint64_t& don
     return 0;
 }
 
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier).  __syncthreads() also carries a memory fence, for
+// which hipcc waits vmcnt(0): between the passes of an LDS-staged epilogue that is a wait for the previous pass's global stores
+// (and for any residual loads already on their way) that nothing needs -- the stores only have to leave before the kernel ends.
+SVR_DEVICE void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // compute units of the current device (persistent kernels launch one workgroup per CU); cached per device
 static inline int device_cu_count() {
     static int cached[64] = {0};

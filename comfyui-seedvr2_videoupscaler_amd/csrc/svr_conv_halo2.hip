@@ -747,7 +747,7 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
                 }
             }
             SVR_EP_STAMP(1 + 3 * pass)                     // LDS writes issued
-            __syncthreads();
+            if constexpr ((DBG & 512) != 0) __syncthreads(); else lds_barrier();      // (512: round 2's barriers, for the A/B)
             SVR_EP_STAMP(2 + 3 * pass)                     // barrier passed
             // store side, branch-free sweeps of four iterations so their LDS reads and residual loads are in flight
             // together (out-of-image voxels read a clamped address and are masked at the store)
@@ -845,7 +845,7 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             }
             }
             SVR_EP_STAMP(3 + 3 * pass)                     // stores issued
-            if (pass + 1 < NPASS) __syncthreads();
+            if (pass + 1 < NPASS) { if constexpr ((DBG & 512) != 0) __syncthreads(); else lds_barrier(); }
         }
     };
     // (measurement builds' DBG variants: the round-2 option sets only -- they are never launched with a wide trunk)
@@ -927,6 +927,7 @@ static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
         case 1: return launch_conv_halo2_t<16, 3, 1>(a, s);         // no weight loads
         case 64: return launch_conv_halo2_t<16, 3, 64>(a, s);       // no fragment reads
         case 4: return launch_conv_halo2_t<16, 3, 4>(a, s);         // no global stores (the epilogue's read-out side is dead code then)
+        case 512: return launch_conv_halo2_t<16, 3, 512>(a, s);     // epilogue pass barriers as __syncthreads() (wait for the stores)
         default: break;
     }
 #endif

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 lo[4], hi_[4];
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
                 }
             }
         }
-        if (pass + 1 < MTW / 2) __syncthreads();
+        if (pass + 1 < MTW / 2) lds_barrier();
     }
     };
     if (a.out_f32) ep_body(std::true_type{}); else ep_body(std::false_type{});

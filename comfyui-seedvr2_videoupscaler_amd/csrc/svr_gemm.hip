@@ -469,8 +469,8 @@ SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char*
     // Residual rows travel ahead of their use: a sweep that loads its own rows waits a full memory latency each time (measured: 16
     // sweeps of ~1.2 us = 19 us per 256 x 256 tile against 5.6 us without a residual).  RES_REGS = the 16-byte register sets the
     // caller can spare:
-    //   RES_REGS >= 0 (gemm_w4p_kernel): the rows of a pass are loaded before the tile is parked -- the pass barriers are s_barrier +
-    //     lgkmcnt only (__syncthreads() would wait for the loads) -- 19 -> 13 us.  (A ring ACROSS passes, slot reloaded with the
+    //   RES_REGS >= 0 (gemm_w4p_kernel): the rows of a pass are loaded before the tile is parked -- the pass barriers are lds_barrier()
+    //     (svr_common.h: __syncthreads() would wait for the loads, and for the previous pass's stores) -- 19 -> 13 us.  (A ring ACROSS passes, slot reloaded with the
     //     next pass's row when consumed, measured 18 us: vmcnt counts in order, so waiting for a load issued behind the previous
     //     pass's stores waits for those stores.)
     //   RES_REGS < 0 (gemm_kernel: two waves per SIMD, no registers to spare while accumulators are live): PF rows start behind the
@@ -500,10 +500,6 @@ SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char*
                 for (int it = 0; it < PF; ++it) load_row(pp, it, it);
             }
         }
-    };
-    auto lds_barrier = [&]() {                            // orders LDS traffic only
-        if constexpr (EARLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else __syncthreads();
     };
     // (the passes are unrolled -- the accumulators want static indices; a switch over a run-time pass made hipcc index them through
     // scratch -- and each carries its own copy of the ~100-instruction sweep loop)
