@@ -823,7 +823,7 @@ template <int N> SVR_DEVICE void w4_wait_lgkm_n() { asm volatile("s_waitcnt lgkm
 template <int N> SVR_DEVICE void w4_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ------------------------------------------------------------------------------------------------
-// gemm_w4p_kernel (round 3; opt-in, svr_set_option("gemm_w4", 1)): the plain GEMMs of the NaDiT (M = 291 600 tokens at BASELINE
+// gemm_w4p_kernel (round 3; svr_set_option("gemm_w4"): default for eligible plain GEMMs except SwiGLU): the plain GEMMs of the NaDiT (M = 291 600 tokens at BASELINE
 // config 3) in the shape of the vendor library's kernel for them -- 256 x 256 x 64 tiles, FOUR waves of 128 x 128, 256 accumulators
 // per lane pinned to AGPRs, one wave per SIMD -- as PERSISTENT workgroups with the operands staged through registers and one
 // pipeline across output tiles.  History (profiles/r3_gemm_w4_ablations.txt): five non-persistent versions of this shape (16x16x32 and
@@ -1116,8 +1116,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_
 }
 
 extern int g_pipe_abl;  // (defined below)
-int g_gemm_w4 = 0;     // svr_set_option("gemm_w4"): 1 big plain GEMMs on gemm_w4p_kernel | 0 (default) everything on gemm_kernel: the two
-                       // measure within +-3 % of each other (profiles/r3_gemm_w4_ablations.txt says why)
+int g_gemm_w4 = 1;     // svr_set_option("gemm_w4"): 1 (default) big plain GEMMs except SwiGLU on gemm_w4p_kernel | 2 SwiGLU as well | 0 everything on
+                       // gemm_kernel.  Same box, the forms the NaDiT issues (profiles/r3_gemm_w4_ablations.txt section 9): qkv -2.3 %,
+                       // attn-out / mlp-out into the fp32 stream -5.3 % / -6.5 %, mlp-in SwiGLU +0.3 % (gemm_kernel's direct epilogue)
 static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
     {
         // (a start stagger of 1 / 8 tile per XCD -- so that an eighth of the chip is in its epilogue at any time -- measured nothing: the
@@ -1245,7 +1246,8 @@ static bool gemm_epi_lds(const svr_gemm_args& a) {
 // what gemm_w4p_kernel serves: plain GEMMs with whole 256-column tiles, at least two K tiles, 16-byte aligned rows, the
 // row-contiguous epilogue's alignment, and enough tiles to fill the chip (one workgroup per CU)
 static bool gemm_w4_eligible(const svr_gemm_args& a) {
-    return g_gemm_w4 && !a.conv.enabled && !a.ps.enabled && !a.phase.enabled && (a.N % 256) == 0 && a.K >= 2 * BK &&
+    return g_gemm_w4 && (g_gemm_w4 == 2 || a.epilogue != SVR_EPI_SWIGLU) && !a.conv.enabled && !a.ps.enabled && !a.phase.enabled &&
+           (a.N % 256) == 0 && a.K >= 2 * BK &&
            (a.lda % 8) == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0 && gemm_epi_lds_aligned(a) &&
            (int64_t)a.lda * 2 * 255 < ((int64_t)1 << 31) && (int64_t)a.K * 2 * 255 < ((int64_t)1 << 31) &&
            (int64_t)((a.M + 255) / 256) * (a.N / 256) >= 256;

@@ -97,6 +97,12 @@ def main():
                 kw = dict(gate=torch.ones(N, dtype=torch.float32, device=dev), resid=rnd(M, N))
             sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, epilogue=epi, **kw), args.reps)
             report(name, sec, flops=2.0 * M * N * K)
+            if epi == ops_mod.EPI_RESID_GATE:
+                # the form the NaDiT engine issues (dit.py, wide residual stream): hid fp32, updated in place
+                hid = torch.rand(M, N, generator=g, device=dev, dtype=torch.float32) * 2 - 1
+                sec = timeit(lambda: ops.gemm(a, w, hid, N=N, K=K, epilogue=epi, gate=kw["gate"], resid=hid, out_f32=True), args.reps)
+                report(name.replace("(+gate,resid)", "(+gate, fp32 stream in place)"), sec, flops=2.0 * M * N * K)
+                del hid
             del a, w, c, kw
     if "ksweep" in only:
         # per-K-tile cost c and per-output-tile overhead o of the big-GEMM main loops: M x N = 4096 tiles of 256 x 256 (16 full rounds of
@@ -110,12 +116,12 @@ def main():
             c = ops.empty(M, N)
             b = torch.zeros(N, dtype=torch.float32, device=dev)
             rounds = (M // 256) * (N // 256) / 256
-            for opt, label in ((0, "gemm_kernel"), (1, "gemm_w4p")):
+            for opt, label in ((0, "gemm_kernel"), (2, "gemm_w4p")):
                 ops.set_option("gemm_w4", opt)
                 sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, bias=b), args.reps)
                 report(f"ksweep {label} K={K}", sec, flops=2.0 * M * N * K)
                 out[-1]["us_per_round"] = round(sec * 1e6 / rounds, 2)
-            ops.set_option("gemm_w4", 0)
+            ops.set_option("gemm_w4", 1)
             wb = wt.to(BF16)
             sec = timeit(lambda: F.linear(a, wb), args.reps)
             report(f"ksweep hipBLASLt K={K}", sec, flops=2.0 * M * N * K)
