@@ -809,6 +809,52 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
     }
 }
 
+// SwiGLU epilogue of the four-wave kernel (bf16 output): the gate and the "in" value of a hidden column sit in the SAME lane of a 32x32
+// accumulator tile (W rows are interleaved gate | in in blocks of 16: columns 8 g + 4 (l >> 5) + e with g = 0, 1 are gates, g = 2, 3 their
+// "in" partners), so silu(gate) * in is formed in registers -- the arithmetic of epilogue_plain_lds<SVR_EPI_SWIGLU>, on the same fp32
+// values -- and the bf16 RESULT is parked: 256 rows x 128 hidden columns x 2 B = 64 KiB (+ pad) in ONE pass instead of four passes of
+// fp32 (the generic form parks both halves in fp32 and lets half the threads idle on the way out).  Leaves row-contiguous, 16 bytes
+// per thread.  Bit-identical to the generic form.
+SVR_DEVICE float agpr_read(float a_elem) { float x; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a_elem)); return x; }
+template <int NTHREADS, int LDS_BYTES, int EDBG, typename ACC>
+SVR_DEVICE void epilogue_swiglu_bf16_m32(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
+    constexpr int PITCH = 128 * 2 + 16;                   // 128 hidden columns of bf16 + 16 B pad
+    static_assert(256 * PITCH <= LDS_BYTES && NTHREADS == 256, "one pass");
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        char* row = smem + (wm * 128 + i * 32 + l31) * PITCH + (wn * 64 + 4 * hi) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // (the accumulators live in AGPRs -- the K loop's inline-asm MFMAs pin them there -- and are fetched HERE, one element at a time:
+            // left to itself hipcc copied all 256 to VGPRs at the top of the epilogue and spilled them)
+#define fetch(idx) agpr_read(acc[i][j][idx])
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = silu(fetch(4 * g + e)) * fetch(4 * (g + 2) + e);
+                uint2 pk;
+                pk.x = pack2bf(o[0], o[1]);
+                pk.y = pack2bf(o[2], o[3]);
+                *(uint2*)(row + (16 * j + 8 * g) * 2) = pk;
+            }
+#undef fetch
+            __builtin_amdgcn_sched_barrier(0);            // (one accumulator tile at a time: hipcc otherwise interleaves all 16 and spills)
+        }
+    }
+    lds_barrier();
+    const int c8 = tid & 15, r0 = tid >> 4;               // 16 chunks of 8 hidden columns per row, 16 rows per iteration
+    const int64_t hid0 = (n0 >> 1) + c8 * 8;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int r = it * 16 + r0;
+        const uint4 pk = *(const uint4*)(smem + r * PITCH + c8 * 16);
+        if (m0 + r < a.M && !(EDBG & 1)) *(uint4*)((bf16_t*)a.C + (int64_t)(m0 + r) * a.ldc + hid0) = pk;
+    }
+}
+
 // ---- shared pieces of the four-wave kernel below: 256 x 256 tile, 64 KiB per K-tile stage, inline-asm fragment reads / MFMAs / waits
 constexpr int W4_THREADS = 256, W4_T = 256, W4_STAGE = 2 * W4_T * BK * 2;                            // 64 KiB per stage
 
@@ -823,7 +869,7 @@ template <int N> SVR_DEVICE void w4_wait_lgkm_n() { asm volatile("s_waitcnt lgkm
 template <int N> SVR_DEVICE void w4_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ------------------------------------------------------------------------------------------------
-// gemm_w4p_kernel (round 3; svr_set_option("gemm_w4"): default for eligible plain GEMMs except SwiGLU): the plain GEMMs of the NaDiT (M = 291 600 tokens at BASELINE
+// gemm_w4p_kernel (round 3; svr_set_option("gemm_w4"): default for eligible plain GEMMs): the plain GEMMs of the NaDiT (M = 291 600 tokens at BASELINE
 // config 3) in the shape of the vendor library's kernel for them -- 256 x 256 x 64 tiles, FOUR waves of 128 x 128, 256 accumulators
 // per lane pinned to AGPRs, one wave per SIMD -- as PERSISTENT workgroups with the operands staged through registers and one
 // pipeline across output tiles.  History (profiles/r3_gemm_w4_ablations.txt): five non-persistent versions of this shape (16x16x32 and
@@ -854,6 +900,11 @@ template <int N> SVR_DEVICE void w4_wait_vmcnt() { asm volatile("s_waitcnt vmcnt
 typedef __attribute__((ext_vector_type(4))) uint32_t w4p_u32x4;
 SVR_DEVICE void w4p_gload(w4p_u32x4& r, const char* sbase, uint32_t voff) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+}
+SVR_DEVICE const char* w4p_uniform(const char* p) {      // a wave-uniform pointer, said so (an "s" operand hipcc holds in VGPRs does not assemble)
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
 // A goes through a buffer descriptor {panel base, bytes to the end of A}: rows past M - 1 (ragged last row panel) are out of range and
 // read as zero, so the per-lane offsets are the same for every tile (a clamp per tile cost 16 register copies per K tile)
@@ -916,14 +967,14 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_
         Arsrc[2] = __builtin_amdgcn_readfirstlane(left > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)left);
         Arsrc[3] = 0x00020000u;
         Akoff = 0;
-        Bbase = (const char*)a.W + (int64_t)ln0 * a.K * 2;
+        Bbase = w4p_uniform((const char*)a.W + (int64_t)ln0 * a.K * 2);
     };
     const int nk = a.K / BK;
     auto advance_cursor = [&]() {                          // after the 16 loads of (tl, kl); the common case is branch-free scalar code
         ++kl;
         const bool same = kl < nk;
         Akoff = same ? Akoff + BK * 2 : Akoff;
-        Bbase = same ? Bbase + BK * 2 : Bbase;
+        Bbase = w4p_uniform(same ? Bbase + BK * 2 : Bbase);
         if (__builtin_expect(!same, 0)) {
             if (tl + nwg < tiles) {
                 tl += nwg; kl = 0;
@@ -1069,7 +1120,10 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_
                     W4_RD(AX, rdA[0], 0), W4_RD(AX, rdA[0], 1), W4_RD(AX, rdA[0], 2), W4_RD(AX, rdA[0], 3),
                     W4_FLIP2(rdA[1], rdB[1]), W4_FLIP2(rdA[2], rdB[2]), W4_FLIP2(rdA[3], rdB[3]),
                     do { if constexpr (!(EDBG & 16)) { wrA -= d; wrB -= d; st ^= 1; } } while (0),
-                    do { if constexpr (!(EDBG & 32)) advance_cursor(); } while (0), W4_NOP, W4_NOP, W4_NOP);
+                    do { if constexpr (!(EDBG & 32)) advance_cursor(); } while (0), W4_NOP, W4_NOP,
+                    // (last K tile of a tile: the staged loads land INSIDE the loop, so that any register copies hipcc places on the loop's exit
+                    // edge -- live-range splits around the epilogue -- already see their data; W4_LANDED below then only names the registers)
+                    do { if (kt + 1 == nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0));
 #undef W4_FLIP2
             if constexpr (TL) { w4_wait_lgkm_n<0>(); clap(4); }
         }
@@ -1079,7 +1133,10 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_
         W4_FENCE();
         W4_LANDED();                                       // (the compiler may move the staging registers from here on: their data is there)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs retire before the accumulators are read
-        epilogue_through_lds<W4_T, W4_T, 128, 128, W4_THREADS, W4P_EPI, true, 2, 2, EDBG, true, 16>(a, acc, smem + (st ? 0 : W4_STAGE), m0, n0, tid, lane, wave);
+        if (a.epilogue == SVR_EPI_SWIGLU && !a.out_f32)
+            epilogue_swiglu_bf16_m32<W4_THREADS, W4P_EPI, EDBG>(a, acc, smem + (st ? 0 : W4_STAGE), m0, n0, tid, lane, wave);
+        else
+            epilogue_through_lds<W4_T, W4_T, 128, 128, W4_THREADS, W4P_EPI, true, 2, 2, EDBG, true, 16>(a, acc, smem + (st ? 0 : W4_STAGE), m0, n0, tid, lane, wave);
         if constexpr (TL) stamp(2);
         // hipcc's own wait for the epilogue's loads and stores, HERE (a builtin: its waitcnt pass sees it; an asm wait it does not).
         // Without it the pass carried "registers with loads pending" from the epilogue into the K loop's header -- the fragment
@@ -1116,9 +1173,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_
 }
 
 extern int g_pipe_abl;  // (defined below)
-int g_gemm_w4 = 1;     // svr_set_option("gemm_w4"): 1 (default) big plain GEMMs except SwiGLU on gemm_w4p_kernel | 2 SwiGLU as well | 0 everything on
-                       // gemm_kernel.  Same box, the forms the NaDiT issues (profiles/r3_gemm_w4_ablations.txt section 9): qkv -2.3 %,
-                       // attn-out / mlp-out into the fp32 stream -5.3 % / -6.5 %, mlp-in SwiGLU +0.3 % (gemm_kernel's direct epilogue)
+int g_gemm_w4 = 1;     // svr_set_option("gemm_w4"): 1 (default) big plain GEMMs on gemm_w4p_kernel | 0 everything on gemm_kernel.  Same box, the
+                       // forms the NaDiT issues (profiles/r3_gemm_w4_ablations.txt section 9): qkv -2.3 %, attn-out / mlp-out into the fp32
+                       // stream -5.3 % / -6.5 %, mlp-in SwiGLU -3 % (one-pass bf16 epilogue)
 static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
     {
         // (a start stagger of 1 / 8 tile per XCD -- so that an eighth of the chip is in its epilogue at any time -- measured nothing: the
@@ -1246,7 +1303,7 @@ static bool gemm_epi_lds(const svr_gemm_args& a) {
 // what gemm_w4p_kernel serves: plain GEMMs with whole 256-column tiles, at least two K tiles, 16-byte aligned rows, the
 // row-contiguous epilogue's alignment, and enough tiles to fill the chip (one workgroup per CU)
 static bool gemm_w4_eligible(const svr_gemm_args& a) {
-    return g_gemm_w4 && (g_gemm_w4 == 2 || a.epilogue != SVR_EPI_SWIGLU) && !a.conv.enabled && !a.ps.enabled && !a.phase.enabled &&
+    return g_gemm_w4 && !a.conv.enabled && !a.ps.enabled && !a.phase.enabled &&
            (a.N % 256) == 0 && a.K >= 2 * BK &&
            (a.lda % 8) == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0 && gemm_epi_lds_aligned(a) &&
            (int64_t)a.lda * 2 * 255 < ((int64_t)1 << 31) && (int64_t)a.K * 2 * 255 < ((int64_t)1 << 31) &&
