@@ -387,6 +387,9 @@ SVR_DEVICE void epilogue_generic_lds(const svr_gemm_args& a, const ACC& acc, cha
     }
 }
 
+template <int OFF> SVR_DEVICE void agpr_park(unsigned lds_addr, const f32x4& v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(lds_addr), "a"(v), "n"(OFF) : "memory");
+}
 // The same epilogue for PLAIN [M, ldc] outputs (no pixel shuffle / phase scatter), one compact instance per (epilogue, output type,
 // residual type).  Why: epilogue_generic_lds resolves those at run time inside fully unrolled passes and sweeps, so a big-tile kernel
 // carried 100-170 KB of epilogue code with the hot path threaded through all of it -- against a 64 KB instruction cache shared by
@@ -396,7 +399,7 @@ SVR_DEVICE void epilogue_generic_lds(const svr_gemm_args& a, const ACC& acc, cha
 // the pass), the variant is a template argument, and an instance is ~2-3 KB.  Same arithmetic in the same order as the generic
 // form -> bit-identical results.
 template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES, bool M32, int RI_FORCE, int SW_FORCE, int EDBG, int RES_REGS_,
-          int EPI, bool OUT_F32, bool RESID_F32, bool PS, typename ACC>
+          int EPI, bool OUT_F32, bool RESID_F32, bool PS, bool AGPR, typename ACC>
 SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
     constexpr int WAVES_N = BN / WN, FM = WM / 16, FN = WN / 16;
     constexpr int WAVES_M = BM / WM;
@@ -460,8 +463,22 @@ SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char*
 #pragma unroll
                 for (int ii = 0; ii < RI; ++ii) {
                     char* row = smem + (((wave / WAVES_N) * RI + ii) * 16 + frow) * PITCH;
+                    if constexpr (AGPR) {                 // accumulators pinned to AGPRs by the caller's inline-asm MFMAs: parked straight from
+                        // there (left to itself hipcc copies all of them to VGPRs first and spills; ds_write takes AGPR data on gfx90a+)
+                        const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(row + (wn0 + ng) * 4);
+                        auto park_j = [&](auto jc) {
+                            constexpr int J = decltype(jc)::value;
+                            if constexpr (J < FN) agpr_park<J * 64>(la, acc[P * RI + ii][J]);
+                        };
+                        park_j(std::integral_constant<int, 0>{}); park_j(std::integral_constant<int, 1>{});
+                        park_j(std::integral_constant<int, 2>{}); park_j(std::integral_constant<int, 3>{});
+                        park_j(std::integral_constant<int, 4>{}); park_j(std::integral_constant<int, 5>{});
+                        park_j(std::integral_constant<int, 6>{}); park_j(std::integral_constant<int, 7>{});
+                        static_assert(FN <= 8, "park_j list");
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) *(f32x4*)(row + (wn0 + 16 * j + ng) * 4) = acc[P * RI + ii][j];
+                        for (int j = 0; j < FN; ++j) *(f32x4*)(row + (wn0 + 16 * j + ng) * 4) = acc[P * RI + ii][j];
+                    }
                 }
             }
         }
@@ -610,10 +627,10 @@ SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char*
 
 // the epilogue through LDS: plain outputs take their compact instance (one switch per tile), scattered outputs the generic form
 template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES, bool M32 = false, int RI_FORCE = 0, int SW_FORCE = 0, int EDBG = 0,
-          bool PLAIN_ONLY = false, int RES_REGS = -8, typename ACC>
+          bool PLAIN_ONLY = false, int RES_REGS = -8, bool AGPR = false, typename ACC>
 SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
 #define SVR_EPI_CASE(E, OF, RF) \
-    epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, E, OF, RF, false>(a, acc, smem, m0, n0, tid, lane, wave)
+    epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, E, OF, RF, false, AGPR>(a, acc, smem, m0, n0, tid, lane, wave)
     if (PLAIN_ONLY || (!a.ps.enabled && !a.phase.enabled)) {
         const int of = a.out_f32 ? 1 : 0, rf = (a.epilogue == SVR_EPI_RESID_GATE && a.resid && a.resid_f32) ? 1 : 0;
         switch (a.epilogue * 4 + of * 2 + rf) {
@@ -634,8 +651,8 @@ SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, cha
     if constexpr (!PLAIN_ONLY) {
         // the pixel-shuffle upsamplers (2 .. 8 K tiles per output tile: the epilogue IS the kernel): bias epilogue, whole 8-channel chunks
         if (a.ps.enabled && !a.phase.enabled && a.epilogue == SVR_EPI_BIAS && (a.ps.C % 8) == 0) {
-            if (a.out_f32) epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, SVR_EPI_BIAS, true, false, true>(a, acc, smem, m0, n0, tid, lane, wave);
-            else epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, SVR_EPI_BIAS, false, false, true>(a, acc, smem, m0, n0, tid, lane, wave);
+            if (a.out_f32) epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, SVR_EPI_BIAS, true, false, true, AGPR>(a, acc, smem, m0, n0, tid, lane, wave);
+            else epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, SVR_EPI_BIAS, false, false, true, AGPR>(a, acc, smem, m0, n0, tid, lane, wave);
             return;
         }
     }
@@ -809,13 +826,14 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
     }
 }
 
+SVR_DEVICE float agpr_read(float a_elem) { float x; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a_elem)); return x; }
+#ifdef SVR_ABLATIONS      // (the 32x32x16 kernel and its epilogue live on in the measurement build: it carries the timeline instrumentation)
 // SwiGLU epilogue of the four-wave kernel (bf16 output): the gate and the "in" value of a hidden column sit in the SAME lane of a 32x32
 // accumulator tile (W rows are interleaved gate | in in blocks of 16: columns 8 g + 4 (l >> 5) + e with g = 0, 1 are gates, g = 2, 3 their
 // "in" partners), so silu(gate) * in is formed in registers -- the arithmetic of epilogue_plain_lds<SVR_EPI_SWIGLU>, on the same fp32
 // values -- and the bf16 RESULT is parked: 256 rows x 128 hidden columns x 2 B = 64 KiB (+ pad) in ONE pass instead of four passes of
 // fp32 (the generic form parks both halves in fp32 and lets half the threads idle on the way out).  Leaves row-contiguous, 16 bytes
 // per thread.  Bit-identical to the generic form.
-SVR_DEVICE float agpr_read(float a_elem) { float x; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a_elem)); return x; }
 template <int NTHREADS, int LDS_BYTES, int EDBG, typename ACC>
 SVR_DEVICE void epilogue_swiglu_bf16_m32(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
     constexpr int PITCH = 128 * 2 + 16;                   // 128 hidden columns of bf16 + 16 B pad
@@ -855,6 +873,7 @@ SVR_DEVICE void epilogue_swiglu_bf16_m32(const svr_gemm_args& a, const ACC& acc,
     }
 }
 
+#endif
 // ---- shared pieces of the four-wave kernel below: 256 x 256 tile, 64 KiB per K-tile stage, inline-asm fragment reads / MFMAs / waits
 constexpr int W4_THREADS = 256, W4_T = 256, W4_STAGE = 2 * W4_T * BK * 2;                            // 64 KiB per stage
 
@@ -921,6 +940,7 @@ constexpr int W4P_S1 = W4_STAGE + 32768;                   // byte offset of sta
 constexpr int W4P_LDS = W4P_S1 + W4_STAGE;                 // 160 KiB
 constexpr int W4P_EPI = W4P_S1;                            // the epilogue's parking area: the free stage + the gap (96 KiB)
 
+#ifdef SVR_ABLATIONS
 // TL (builds with -DSVR_ABLATIONS only): wave 0 stamps the 100 MHz clock at each tile's K-loop start / K-loop end / epilogue end
 template <bool TL, int EDBG = 0>
 __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_args a, uint64_t* timeline) {
@@ -1172,20 +1192,285 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_
 #undef W4_NOP
 }
 
+#endif
+// ------------------------------------------------------------------------------------------------
+// gemm_w4q_kernel: gemm_w4p_kernel's structure (persistent workgroups, operands through registers, loads two K tiles ahead across
+// tile boundaries) on v_mfma_f32_16x16x32_bf16 -- the vendor library's instruction: 128 matrix instructions of 16 cycles per K tile
+// instead of 64 of 32, so that each of the K tile's 32 fragment reads and 16 moves gets a slot of its own behind an MFMA, and
+// fragments of 16 rows (8 A + 8 B per k32 half, two register sets X / Y = 128 VGPRs).
+//   K tile f (stage s), registers holding K tile f + 1 at its start; two k32 halves of 64 MFMAs (i outer: A[i] x B[0..7]):
+//   half 0 (set X):  slots 0..7 nothing but MFMAs, lgkmcnt(0) at slot 8 (the last X reads were issued 12 slots before the half);
+//                    Y reads (k32 half 1 of stage s) in the even slots 8..38; moves 0..7 in the odd slots 9..23;
+//   half 1 (set Y):  moves 8..15 in the even slots 0..14; slot 20: lgkmcnt(0) + THE barrier (every wave's writes of K tile f + 1 are
+//                    in LDS, its reads of stage s done); X reads of K tile f + 1 in the even slots 22..52; flips and cursor behind.
+// Same LDS layout (128-byte rows, source-side XOR, key = (row >> 1) & 7: conflict-free for 16-row fragments as well), stages,
+// staging roles and epilogues (through LDS, 16x16 accumulator tiles) as gemm_w4p_kernel.
+// ------------------------------------------------------------------------------------------------
+SVR_DEVICE void w4q_mfma(f32x4& c, const bf16x8& w, const bf16x8& x) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(x));
+}
+// SwiGLU epilogue for 16x16 accumulator tiles (bf16 output): gate block 2 b and "in" block 2 b + 1 of a hidden 16-column block sit in the
+// same lane positions of acc[i][2 b] / acc[i][2 b + 1]; the bf16 result is parked in one pass (see epilogue_swiglu_bf16_m32)
+template <int NTHREADS, int LDS_BYTES, typename ACC>
+SVR_DEVICE void epilogue_swiglu_bf16_m16(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
+    constexpr int PITCH = 128 * 2 + 16;
+    static_assert(256 * PITCH <= LDS_BYTES && NTHREADS == 256, "one pass");
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        char* row = smem + (wm * 128 + i * 16 + l15) * PITCH + (wn * 64 + 4 * kq) * 2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = silu(acc[i][2 * b][e]) * acc[i][2 * b + 1][e];
+            uint2 pk;
+            pk.x = pack2bf(o[0], o[1]);
+            pk.y = pack2bf(o[2], o[3]);
+            *(uint2*)(row + (16 * b) * 2) = pk;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    lds_barrier();
+    const int c8 = tid & 15, r0 = tid >> 4;
+    const int64_t hid0 = (n0 >> 1) + c8 * 8;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int r = it * 16 + r0;
+        const uint4 pk = *(const uint4*)(smem + r * PITCH + c8 * 16);
+        if (m0 + r < a.M) *(uint4*)((bf16_t*)a.C + (int64_t)(m0 + r) * a.ldc + hid0) = pk;
+    }
+}
+
+__global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const svr_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_m = (a.M + W4_T - 1) / W4_T;
+    const int tiles_n = a.N / W4_T;
+    const int tiles = tiles_m * tiles_n;
+    const int nwg = gridDim.x;
+    constexpr int GM = 4;
+    const int group_size = GM * tiles_n;
+    auto tile_origin = [&](int t, int& m0, int& n0) {
+        const int group = t / group_size;
+        const int first_m = group * GM;
+        const int gm = min(tiles_m - first_m, GM);
+        m0 = __builtin_amdgcn_readfirstlane((first_m + (t % group_size) % gm) * W4_T);      // (uniform, said so: the division runs on the VALU)
+        n0 = __builtin_amdgcn_readfirstlane(((t % group_size) / gm) * W4_T);
+    };
+    int t = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+    int m0, n0;
+    tile_origin(t, m0, n0);
+    const int srow = wave * 8 + (lane >> 3);
+    const int chunk_src = (lane & 7) ^ ((srow >> 1) & 7);
+    int tl = t, kl = 0;
+    w4p_u32x4 Arsrc, Brsrc;                              // both operands through buffer descriptors: {panel base, bytes left}
+    uint32_t Akoff = 0;                                   // byte offset of K tile kl in a row (A and B alike)
+    // (A: one per-lane offset; the piece's 32-row block is a scalar added to the buffer load's soffset.  B: per-piece offsets)
+    const uint32_t aoff0 = (uint32_t)((int64_t)srow * a.lda * 2) + chunk_src * 16;
+    const uint32_t arowblk = (uint32_t)(32 * a.lda * 2);
+    const uint32_t boff0 = (uint32_t)((int64_t)srow * a.K * 2) + chunk_src * 16;
+    const uint32_t browblk = (uint32_t)(32 * a.K * 2);
+    auto point_cursor = [&](int lm0, int ln0) {
+        const uint64_t base = (uint64_t)(uintptr_t)a.A + (uint64_t)lm0 * (uint64_t)a.lda * 2;
+        const uint64_t left = (uint64_t)(a.M - lm0) * (uint64_t)a.lda * 2;
+        Arsrc[0] = __builtin_amdgcn_readfirstlane((uint32_t)base);
+        Arsrc[1] = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32) & 0xffffu);
+        Arsrc[2] = __builtin_amdgcn_readfirstlane(left > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)left);
+        Arsrc[3] = 0x00020000u;
+        Akoff = 0;
+        const uint64_t bb = (uint64_t)(uintptr_t)a.W + (uint64_t)ln0 * (uint64_t)a.K * 2;
+        Brsrc[0] = __builtin_amdgcn_readfirstlane((uint32_t)bb);
+        Brsrc[1] = __builtin_amdgcn_readfirstlane((uint32_t)(bb >> 32) & 0xffffu);
+        Brsrc[2] = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)W4_T * (uint64_t)a.K * 2));      // (W is padded to whole panels: never out of range)
+        Brsrc[3] = 0x00020000u;
+    };
+    const int nk = a.K / BK;
+    auto advance_cursor = [&]() {
+        ++kl;
+        const bool same = kl < nk;
+        Akoff = same ? Akoff + BK * 2 : Akoff;
+        if (__builtin_expect(!same, 0)) {
+            if (tl + nwg < tiles) {
+                tl += nwg; kl = 0;
+                int lm0, ln0;
+                tile_origin(tl, lm0, ln0);
+                point_cursor(lm0, ln0);
+            } else {
+                kl = nk - 1;
+            }
+        }
+    };
+    point_cursor(m0, n0);
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned wrA = lds0 + (unsigned)(wave * 1024 + lane * 16), wrB = wrA + W4_T * BK * 2;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const unsigned key = (unsigned)((l15 >> 1) & 7);
+    const unsigned rA = lds0 + (unsigned)((wm * 128 + l15) * 128), rB = lds0 + (unsigned)(W4_T * BK * 2 + (wn * 128 + l15) * 128);
+    unsigned rdA[2], rdB[2];                               // [k32 half] of the CURRENT stage; fragment i (16 rows = 2048 bytes) is an immediate
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const unsigned po = (((unsigned)(4 * kh + kq)) ^ key) << 4;
+        rdA[kh] = rA + po;
+        rdB[kh] = rB + po;
+    }
+    f32x4 acc[8][8];
+    bf16x8 AX[8], BX[8], AY[8], BY[8];
+    w4p_u32x4 sa[8], sb[8];
+
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define W4_LDA(Q) w4p_bload(sa[Q], Arsrc, aoff0, Akoff + (Q) * arowblk)
+#define W4_LDB(Q) w4p_bload(sb[Q], Brsrc, boff0, Akoff + (Q) * browblk)
+#define W4_LOAD_ALL() do { W4_LDA(0); W4_LDB(0); W4_LDA(1); W4_LDB(1); W4_LDA(2); W4_LDB(2); W4_LDA(3); W4_LDB(3); \
+                           W4_LDA(4); W4_LDB(4); W4_LDA(5); W4_LDB(5); W4_LDA(6); W4_LDB(6); W4_LDA(7); W4_LDB(7); } while (0)
+#define W4_LANDED() asm volatile("s_waitcnt vmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sa[4]), "+v"(sa[5]), \
+                                 "+v"(sa[6]), "+v"(sa[7]), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), \
+                                 "+v"(sb[6]), "+v"(sb[7]))
+    // move M (0..15): pieces in the order A0 B0 A1 B1 ...
+    auto move = [&](auto mc) {
+        constexpr int M = decltype(mc)::value, Q = M >> 1;
+        if constexpr ((M & 1) == 0) { w4p_wait_piece<15>(sa[Q]); w4p_swrite<Q * 4096>(wrA, sa[Q]); W4_FENCE(); W4_LDA(Q); }
+        else { w4p_wait_piece<15>(sb[Q]); w4p_swrite<Q * 4096>(wrB, sb[Q]); W4_FENCE(); W4_LDB(Q); }
+    };
+    // fragment read R (0..15) of a set: B0..B7 then A0..A7
+    auto read_x = [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        if constexpr (R < 8) w4_rd<R * 2048>(BX[R], rdB[0]); else w4_rd<(R - 8) * 2048>(AX[R - 8], rdA[0]);
+    };
+    auto read_y = [&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        if constexpr (R < 8) w4_rd<R * 2048>(BY[R], rdB[1]); else w4_rd<(R - 8) * 2048>(AY[R - 8], rdA[1]);
+    };
+#define W4Q_C(v) std::integral_constant<int, (v)>{}
+#define W4Q_READ_X_ALL() do { read_x(W4Q_C(0)); read_x(W4Q_C(1)); read_x(W4Q_C(2)); read_x(W4Q_C(3)); read_x(W4Q_C(4)); read_x(W4Q_C(5)); \
+        read_x(W4Q_C(6)); read_x(W4Q_C(7)); read_x(W4Q_C(8)); read_x(W4Q_C(9)); read_x(W4Q_C(10)); read_x(W4Q_C(11)); read_x(W4Q_C(12)); \
+        read_x(W4Q_C(13)); read_x(W4Q_C(14)); read_x(W4Q_C(15)); } while (0)
+
+    // ---- prologue (once per workgroup): K tile 0 -> registers -> stage 0; K tile 1 -> registers
+    W4_LOAD_ALL();
+    advance_cursor();
+    W4_FENCE();
+    W4_LANDED();
+    W4_FENCE();
+    w4p_swrite<0 * 4096>(wrA, sa[0]); w4p_swrite<0 * 4096>(wrB, sb[0]); w4p_swrite<1 * 4096>(wrA, sa[1]); w4p_swrite<1 * 4096>(wrB, sb[1]);
+    w4p_swrite<2 * 4096>(wrA, sa[2]); w4p_swrite<2 * 4096>(wrB, sb[2]); w4p_swrite<3 * 4096>(wrA, sa[3]); w4p_swrite<3 * 4096>(wrB, sb[3]);
+    w4p_swrite<4 * 4096>(wrA, sa[4]); w4p_swrite<4 * 4096>(wrB, sb[4]); w4p_swrite<5 * 4096>(wrA, sa[5]); w4p_swrite<5 * 4096>(wrB, sb[5]);
+    w4p_swrite<6 * 4096>(wrA, sa[6]); w4p_swrite<6 * 4096>(wrB, sb[6]); w4p_swrite<7 * 4096>(wrA, sa[7]); w4p_swrite<7 * 4096>(wrB, sb[7]);
+    W4_FENCE();
+    W4_LOAD_ALL();
+    advance_cursor();
+    wrA += W4P_S1; wrB += W4P_S1;
+    W4_FENCE();
+    w4_wait_lgkm_n<0>();
+    __builtin_amdgcn_s_barrier();
+    W4_FENCE();
+    W4Q_READ_X_ALL();
+    W4_FENCE();
+
+    int st = 0;
+    int kt = 0;                                           // K tile of the current output tile (run-time; the slot code below is one body)
+    // one slot = one MFMA + at most one side operation
+    auto slot0 = [&](auto sc) {                           // half 0: set X
+        constexpr int S = decltype(sc)::value, I = S >> 3, J = S & 7;
+        if constexpr (S == 8) { w4_wait_lgkm_n<0>(); W4_FENCE(); }
+        w4q_mfma(acc[I][J], BX[J], AX[I]);
+        W4_FENCE();
+        if constexpr (S >= 8 && S <= 38 && (S & 1) == 0) read_y(W4Q_C((S - 8) / 2));
+        if constexpr (S >= 9 && S <= 23 && (S & 1) == 1) move(W4Q_C((S - 9) / 2));
+        W4_FENCE();
+    };
+    auto slot1 = [&](auto sc) {                           // half 1: set Y
+        constexpr int S = decltype(sc)::value, I = S >> 3, J = S & 7;
+        if constexpr (S == 20) {                          // THE barrier of the K tile
+            w4_wait_lgkm_n<0>();
+            __builtin_amdgcn_s_barrier();
+            W4_FENCE();
+            const unsigned d = st ? (unsigned)-W4P_S1 : (unsigned)W4P_S1;
+            rdA[0] += d; rdB[0] += d;                     // the X reads below come from the other stage
+            W4_FENCE();
+        }
+        w4q_mfma(acc[I][J], BY[J], AY[I]);
+        W4_FENCE();
+        if constexpr (S <= 14 && (S & 1) == 0) move(W4Q_C(8 + S / 2));
+        if constexpr (S >= 22 && S <= 52 && (S & 1) == 0) read_x(W4Q_C((S - 22) / 2));
+        if constexpr (S == 54) {
+            const unsigned d = st ? (unsigned)-W4P_S1 : (unsigned)W4P_S1;
+            rdA[1] += d; rdB[1] += d; wrA -= d; wrB -= d;
+            st ^= 1;
+        }
+        if constexpr (S == 56) advance_cursor();
+        if constexpr (S == 62) { if (kt + 1 == nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        W4_FENCE();
+    };
+#define W4Q_8(F, B) F(W4Q_C(B)); F(W4Q_C(B + 1)); F(W4Q_C(B + 2)); F(W4Q_C(B + 3)); F(W4Q_C(B + 4)); F(W4Q_C(B + 5)); F(W4Q_C(B + 6)); F(W4Q_C(B + 7))
+#define W4Q_64(F) W4Q_8(F, 0); W4Q_8(F, 8); W4Q_8(F, 16); W4Q_8(F, 24); W4Q_8(F, 32); W4Q_8(F, 40); W4Q_8(F, 48); W4Q_8(F, 56)
+
+    for (;;) {                                            // the output tiles of this workgroup
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (kt = 0; kt < nk; ++kt) {
+            w4_wait_lgkm_n<3>();                          // B0..7, A0..4 of set X are there (A5..7 may still be on their way: slot 8 waits)
+            W4_FENCE();
+            W4Q_64(slot0);
+            w4_wait_lgkm_n<0>();
+            W4_FENCE();
+            W4Q_64(slot1);
+        }
+        W4_FENCE();
+        W4_LANDED();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        {
+            // (an opaque copy of the thread index: hipcc otherwise hoists the epilogues' per-thread addresses out of the tile loop and carries
+            // them -- spilled -- across the K loop; lane and wave are re-derived from it)
+            int lane_e;                                     // (rebuilt here, by an asm hipcc cannot hoist: no register kept for it across the K loop)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+            const int wave_e = wave, tid_e = wave * 64 + lane_e;
+            if (a.epilogue == SVR_EPI_SWIGLU && !a.out_f32)
+                epilogue_swiglu_bf16_m16<W4_THREADS, W4P_EPI>(a, acc, smem + (st ? 0 : W4_STAGE), m0, n0, tid_e, lane_e, wave_e);
+            else
+                epilogue_through_lds<W4_T, W4_T, 128, 128, W4_THREADS, W4P_EPI, false, 2, 2, 0, true, 16, false>(a, acc, smem + (st ? 0 : W4_STAGE), m0, n0, tid_e, lane_e, wave_e);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // (hipcc's own vmcnt(0): see gemm_w4p_kernel)
+        t += nwg;
+        if (t >= tiles) break;
+        tile_origin(t, m0, n0);
+        __syncthreads();
+        W4_FENCE();
+        W4Q_READ_X_ALL();
+        W4_FENCE();
+    }
+#undef W4_FENCE
+#undef W4_LDA
+#undef W4_LDB
+#undef W4_LOAD_ALL
+#undef W4_LANDED
+#undef W4Q_C
+#undef W4Q_READ_X_ALL
+#undef W4Q_8
+#undef W4Q_64
+}
+
 extern int g_pipe_abl;  // (defined below)
-int g_gemm_w4 = 1;     // svr_set_option("gemm_w4"): 1 (default) big plain GEMMs on gemm_w4p_kernel | 0 everything on gemm_kernel.  Same box, the
-                       // forms the NaDiT issues (profiles/r3_gemm_w4_ablations.txt section 9): qkv -2.3 %, attn-out / mlp-out into the fp32
-                       // stream -5.3 % / -6.5 %, mlp-in SwiGLU -3 % (one-pass bf16 epilogue)
+int g_gemm_w4 = 1;     // svr_set_option("gemm_w4"): 1 (default) big plain GEMMs on gemm_w4q_kernel | 0 everything on gemm_kernel | 2 (measurement
+                       // build only) gemm_w4p_kernel.  Same box, the forms the NaDiT issues (profiles/r3_gemm_w4_ablations.txt sections 9, 10):
+                       // against gemm_kernel qkv -6.5 %, attn-out / mlp-out into the fp32 stream -10 % / -12 %, mlp-in SwiGLU -7 %
 static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
-    {
-        // (a start stagger of 1 / 8 tile per XCD -- so that an eighth of the chip is in its epilogue at any time -- measured nothing: the
-        // XCDs drift apart by a whole tile period within twenty tiles on their own, profiles/r3_gemm_w4_ablations.txt section 7)
-        const int tiles = ((a.M + W4_T - 1) / W4_T) * (a.N / W4_T);
+    // (a start stagger of 1 / 8 tile per XCD -- so that an eighth of the chip is in its epilogue at any time -- measured nothing: the
+    // XCDs drift apart by a whole tile period within twenty tiles on their own, profiles/r3_gemm_w4_ablations.txt section 7)
+    const int tiles = ((a.M + W4_T - 1) / W4_T) * (a.N / W4_T);
+    const int grid = std::min(device_cu_count(), tiles) & ~7;       // one workgroup per CU; a multiple of the XCD count
+#ifdef SVR_ABLATIONS
+    if (g_gemm_w4 == 2) {                                 // the 32x32x16 predecessor with its timeline instrumentation (measurement build)
         static uint64_t lds_attr_done2 = 0;
         const int e = set_max_dynamic_lds((const void*)gemm_w4p_kernel<false>, W4P_LDS, lds_attr_done2);
         if (e != 0) return e;
-        const int grid = std::min(device_cu_count(), tiles) & ~7;       // one workgroup per CU; a multiple of the XCD count
-#ifdef SVR_ABLATIONS
         if (g_pipe_abl >= 100 && g_pipe_abl <= 132) {     // timeline of the first 64 tiles of every workgroup -> stderr (synchronises);
                                                           // 101: no global stores | 102: no parking writes | 104: no readout (results invalid)
             static uint64_t* d_tl = nullptr;
@@ -1248,10 +1533,15 @@ static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
             }
             return (int)hipGetLastError();
         }
-#endif
         hipLaunchKernelGGL(gemm_w4p_kernel<false>, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, (uint64_t*)nullptr);
         return (int)hipGetLastError();
     }
+#endif
+    static uint64_t lds_attr_done_q = 0;
+    const int eq = set_max_dynamic_lds((const void*)gemm_w4q_kernel, W4P_LDS, lds_attr_done_q);
+    if (eq != 0) return eq;
+    hipLaunchKernelGGL(gemm_w4q_kernel, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a);
+    return (int)hipGetLastError();
 }
 
 template <int BM, int BN, int WM, int WN, bool CONV, bool EPI_LDS = false>
@@ -1300,7 +1590,7 @@ static bool gemm_epi_lds(const svr_gemm_args& a) {
     if (g_gemm_epi == 1 || !gemm_epi_lds_aligned(a)) return false;
     return g_gemm_epi == 2 || a.epilogue != SVR_EPI_SWIGLU || a.K <= GEMM_EPI_LDS_MAX_K_SWIGLU;
 }
-// what gemm_w4p_kernel serves: plain GEMMs with whole 256-column tiles, at least two K tiles, 16-byte aligned rows, the
+// what gemm_w4q_kernel serves: plain GEMMs with whole 256-column tiles, at least two K tiles, 16-byte aligned rows, the
 // row-contiguous epilogue's alignment, and enough tiles to fill the chip (one workgroup per CU)
 static bool gemm_w4_eligible(const svr_gemm_args& a) {
     return g_gemm_w4 && !a.conv.enabled && !a.ps.enabled && !a.phase.enabled &&

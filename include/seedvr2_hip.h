@@ -206,7 +206,7 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * "conv_sub" 1 (default) (kt, 2, 2)-tap convs with W_frag run on the sub-pixel conv kernel | 0 on the generic kernel,
  * "conv_lds" dynamic LDS bytes to request for the halo kernel (> 80 KiB forces one workgroup per CU),
  * "gemm_w4" 1 (default) plain GEMMs with N % 256 == 0 and >= 256 tiles on the persistent four-wave kernel (256 accumulators per
- * wave, the vendor library's tile shape) | 0 on the eight-wave kernel like everything else,
+ * wave, the vendor library's tile shape and MFMA) | 0 on the eight-wave kernel like everything else,
  * "gemm_epi" epilogue of the GEMM kernel: 0 auto | 1 stores straight from the accumulators | 2 through LDS wherever possible,
  * "attn_impl" 0 auto (second-generation window kernel for head_dim 128 / windows <= 2048 rows) | 1 first kernel everywhere,
  * "attn_variant" build variant of the second-generation window kernel (0 default = 8 waves; 1 / 3 / 4: see svr_attn_win.hip),

@@ -145,10 +145,10 @@ def test_gemm_swiglu(hip, ref, gemm_epi):
     assert rel_err(w2, want) < 1e-5
 
 
-@pytest.fixture(params=[0, 1], ids=["gemm_8waves", "gemm_w4p"])
+@pytest.fixture(params=[0, 1], ids=["gemm_8waves", "gemm_w4q"])
 def gemm_big(request, hip):
     """The two main loops for the NaDiT's big plain GEMMs (N % 256 == 0, >= 256 tiles): gemm_kernel (eight waves, 16x16x32 MFMAs) and
-    gemm_w4p_kernel (persistent workgroups of four waves of 128 x 128, 32x32x16 MFMAs, hand-scheduled; svr_set_option("gemm_w4"))."""
+    gemm_w4q_kernel (persistent workgroups of four waves of 128 x 128, 16x16x32 MFMAs, hand-scheduled; svr_set_option("gemm_w4"))."""
     hip.set_option("gemm_w4", request.param)
     yield request.param
     hip.set_option("gemm_w4", GEMM_W4_DEFAULT)

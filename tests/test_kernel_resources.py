@@ -56,7 +56,7 @@ def test_hand_scheduled_kernels_do_not_spill_and_keep_their_occupancy(device_asm
     assert four_rows and four_rows[0]["max_flat_workgroup_size"] == 256
     assert any("conv_halo2_kernelILi16ELi3ELi0E" in k for k in halo)
     # the four-wave GEMM: 256 accumulators pinned to AGPRs by its inline-asm MFMAs, fragments in < 256 VGPRs, one wave per SIMD
-    w4 = [v for k, v in meta.items() if "gemm_w4p_kernelILb0ELi0E" in k]
+    w4 = [v for k, v in meta.items() if "gemm_w4q_kernel" in k]
     assert w4 and w4[0]["vgpr_spill_count"] == 0 and w4[0]["private_segment_fixed_size"] == 0 and 256 < w4[0]["vgpr_count"] <= 512
 
 

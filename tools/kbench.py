@@ -116,7 +116,7 @@ def main():
             c = ops.empty(M, N)
             b = torch.zeros(N, dtype=torch.float32, device=dev)
             rounds = (M // 256) * (N // 256) / 256
-            for opt, label in ((0, "gemm_kernel"), (1, "gemm_w4p")):
+            for opt, label in ((0, "gemm_kernel"), (1, "gemm_w4q")):
                 ops.set_option("gemm_w4", opt)
                 sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, bias=b), args.reps)
                 report(f"ksweep {label} K={K}", sec, flops=2.0 * M * N * K)
