@@ -1200,8 +1200,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_
 // fragments of 16 rows (8 A + 8 B per k32 half, two register sets X / Y = 128 VGPRs).
 //   K tile f (stage s), registers holding K tile f + 1 at its start; two k32 halves of 64 MFMAs (i outer: A[i] x B[0..7]):
 //   half 0 (set X):  slots 0..7 nothing but MFMAs, lgkmcnt(0) at slot 8 (the last X reads were issued 12 slots before the half);
-//                    Y reads (k32 half 1 of stage s) in the even slots 8..38; moves 0..7 in the odd slots 9..23;
-//   half 1 (set Y):  moves 8..15 in the even slots 0..14; slot 20: lgkmcnt(0) + THE barrier (every wave's writes of K tile f + 1 are
+//                    Y reads (k32 half 1 of stage s) in the even slots 8..38; moves 0..7 in the odd slots 9..39 (a move is two
+//                    slots: wait + ds_write, then the reload);
+//   half 1 (set Y):  moves 8..15 in slots 0..15; slot 20: lgkmcnt(0) + THE barrier (every wave's writes of K tile f + 1 are
 //                    in LDS, its reads of stage s done); X reads of K tile f + 1 in the even slots 22..52; flips and cursor behind.
 // Same LDS layout (128-byte rows, source-side XOR, key = (row >> 1) & 7: conflict-free for 16-row fragments as well), stages,
 // staging roles and epilogues (through LDS, 16x16 accumulator tiles) as gemm_w4p_kernel.
@@ -1332,10 +1333,15 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const svr_gemm_
                                  "+v"(sa[6]), "+v"(sa[7]), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), \
                                  "+v"(sb[6]), "+v"(sb[7]))
     // move M (0..15): pieces in the order A0 B0 A1 B1 ...
-    auto move = [&](auto mc) {
+    // (a move is two slots: the wait + ds_write of a piece behind one MFMA, its reload behind the next)
+    auto move_w = [&](auto mc) {
         constexpr int M = decltype(mc)::value, Q = M >> 1;
-        if constexpr ((M & 1) == 0) { w4p_wait_piece<15>(sa[Q]); w4p_swrite<Q * 4096>(wrA, sa[Q]); W4_FENCE(); W4_LDA(Q); }
-        else { w4p_wait_piece<15>(sb[Q]); w4p_swrite<Q * 4096>(wrB, sb[Q]); W4_FENCE(); W4_LDB(Q); }
+        if constexpr ((M & 1) == 0) { w4p_wait_piece<15>(sa[Q]); w4p_swrite<Q * 4096>(wrA, sa[Q]); }
+        else { w4p_wait_piece<15>(sb[Q]); w4p_swrite<Q * 4096>(wrB, sb[Q]); }
+    };
+    auto move_l = [&](auto mc) {
+        constexpr int M = decltype(mc)::value, Q = M >> 1;
+        if constexpr ((M & 1) == 0) W4_LDA(Q); else W4_LDB(Q);
     };
     // fragment read R (0..15) of a set: B0..B7 then A0..A7
     auto read_x = [&](auto rc) {
@@ -1381,7 +1387,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const svr_gemm_
         w4q_mfma(acc[I][J], BX[J], AX[I]);
         W4_FENCE();
         if constexpr (S >= 8 && S <= 38 && (S & 1) == 0) read_y(W4Q_C((S - 8) / 2));
-        if constexpr (S >= 9 && S <= 23 && (S & 1) == 1) move(W4Q_C((S - 9) / 2));
+        if constexpr (S >= 9 && S <= 39 && (S & 3) == 1) move_w(W4Q_C((S - 9) / 4));
+        if constexpr (S >= 11 && S <= 39 && (S & 3) == 3) move_l(W4Q_C((S - 11) / 4));
         W4_FENCE();
     };
     auto slot1 = [&](auto sc) {                           // half 1: set Y
@@ -1396,7 +1403,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const svr_gemm_
         }
         w4q_mfma(acc[I][J], BY[J], AY[I]);
         W4_FENCE();
-        if constexpr (S <= 14 && (S & 1) == 0) move(W4Q_C(8 + S / 2));
+        if constexpr (S <= 15 && (S & 1) == 0) move_w(W4Q_C(8 + S / 2));
+        if constexpr (S <= 15 && (S & 1) == 1) move_l(W4Q_C(8 + S / 2));
         if constexpr (S >= 22 && S <= 52 && (S & 1) == 0) read_x(W4Q_C((S - 22) / 2));
         if constexpr (S == 54) {
             const unsigned d = st ? (unsigned)-W4P_S1 : (unsigned)W4P_S1;
