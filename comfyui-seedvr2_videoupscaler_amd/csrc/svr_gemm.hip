@@ -1494,12 +1494,10 @@ static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
             };
             int e3 = 0;
             switch (g_pipe_abl) {
-                case 101: e3 = go(gemm_w4p_kernel<true, 1>, lds_attr_done3[1]); break;
-                case 102: e3 = go(gemm_w4p_kernel<true, 2>, lds_attr_done3[2]); break;
-                case 104: e3 = go(gemm_w4p_kernel<true, 4>, lds_attr_done3[3]); break;
+                // (102 no parking writes, 104 no read-out, 116 no stage flip, 132 no load cursor: measured -- profiles/r3_gemm_w4_ablations.txt
+                // sections 7, 8 -- and dropped from the build again, ~15 s of compile time each; the template bits are still there)
+                case 101: e3 = go(gemm_w4p_kernel<true, 1>, lds_attr_done3[1]); break;       // no global stores
                 case 108: e3 = go(gemm_w4p_kernel<true, 8>, lds_attr_done3[4]); break;       // no K-loop barrier
-                case 116: e3 = go(gemm_w4p_kernel<true, 16>, lds_attr_done3[5]); break;      // no stage flip
-                case 132: e3 = go(gemm_w4p_kernel<true, 32>, lds_attr_done3[6]); break;      // no load-cursor advance
                 default:  e3 = go(gemm_w4p_kernel<true, 0>, lds_attr_done3[0]); break;
             }
             if (e3 != 0) return e3;
