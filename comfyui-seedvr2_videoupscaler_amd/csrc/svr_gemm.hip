@@ -888,7 +888,8 @@ template <int N> SVR_DEVICE void w4_wait_lgkm_n() { asm volatile("s_waitcnt lgkm
 template <int N> SVR_DEVICE void w4_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ------------------------------------------------------------------------------------------------
-// gemm_w4p_kernel (round 3; svr_set_option("gemm_w4"): default for eligible plain GEMMs): the plain GEMMs of the NaDiT (M = 291 600 tokens at BASELINE
+// gemm_w4p_kernel (round 3; MEASUREMENT BUILD ONLY since gemm_w4q_kernel below took over as the default -- it carries the timeline
+// instrumentation; svr_set_option("gemm_w4", 2)): the plain GEMMs of the NaDiT (M = 291 600 tokens at BASELINE
 // config 3) in the shape of the vendor library's kernel for them -- 256 x 256 x 64 tiles, FOUR waves of 128 x 128, 256 accumulators
 // per lane pinned to AGPRs, one wave per SIMD -- as PERSISTENT workgroups with the operands staged through registers and one
 // pipeline across output tiles.  History (profiles/r3_gemm_w4_ablations.txt): five non-persistent versions of this shape (16x16x32 and
