@@ -1245,7 +1245,15 @@ SVR_DEVICE void epilogue_swiglu_bf16_m16(const svr_gemm_args& a, const ACC& acc,
     }
 }
 
-__global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const svr_gemm_args a) {
+// TL (measurement build): wave 0 sums shader-clock counts (s_memtime) per K-tile phase: 0 = half 0 slots 0..7 (MFMAs only), 1 = half 0
+// slots 8..63 (reads + moves), 2 = half 1 slots 0..19 (moves), 3 = the barrier, 4 = half 1 slots 20..63 (reads, flips, cursor)
+// half 0 of gemm_w4q_kernel: the slot of Y read r (0..15): 8, 11, 15, 18, 22, 25, ... (alternately 3 and 4 slots apart), last at 60
+constexpr int w4q_read_index(int slot) {
+    for (int r = 0; r < 16; ++r) if (8 + (r >> 1) * 7 + (r & 1) * 3 == slot) return r;
+    return -1;
+}
+template <bool TL = false>
+__global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const svr_gemm_args a, uint64_t* timeline = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1381,22 +1389,36 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const svr_gemm_
 
     int st = 0;
     int kt = 0;                                           // K tile of the current output tile (run-time; the slot code below is one body)
+    uint64_t cyc[5] = {0, 0, 0, 0, 0}, c_prev = 0;
+    auto cstart = [&]() { if constexpr (TL) { c_prev = __builtin_amdgcn_s_memtime(); } };
+    auto clap = [&](int what) {
+        if constexpr (TL) { w4_wait_lgkm_n<0>(); const uint64_t c = __builtin_amdgcn_s_memtime(); cyc[what] += c - c_prev; c_prev = c; }
+    };
     // one slot = one MFMA + at most one side operation
     auto slot0 = [&](auto sc) {                           // half 0: set X
         constexpr int S = decltype(sc)::value, I = S >> 3, J = S & 7;
-        if constexpr (S == 8) { w4_wait_lgkm_n<0>(); W4_FENCE(); }
+        if constexpr (S == 8) { w4_wait_lgkm_n<0>(); W4_FENCE(); clap(0); }
         w4q_mfma(acc[I][J], BX[J], AX[I]);
         W4_FENCE();
-        if constexpr (S >= 8 && S <= 38 && (S & 1) == 0) read_y(W4Q_C((S - 8) / 2));
-        if constexpr (S >= 9 && S <= 39 && (S & 3) == 1) move_w(W4Q_C((S - 9) / 4));
-        if constexpr (S >= 11 && S <= 39 && (S & 3) == 3) move_l(W4Q_C((S - 11) / 4));
+        // (LDS ops evenly over slots 8..60 -- 16 reads + 8 writes in 53 slots: with the reads in every other slot of 8..38 and the writes
+        // between them the four waves asked the LDS for 188 B/clk in that stretch, against its 128; phase counts, section 11)
+        constexpr int RIDX = w4q_read_index(S), WIDX = (S >= 9 && S <= 58 && (S - 9) % 7 == 0) ? (S - 9) / 7 : -1,
+                      LIDX = (S >= 10 && S <= 59 && (S - 10) % 7 == 0) ? (S - 10) / 7 : -1;
+        if constexpr (RIDX >= 0) read_y(W4Q_C(RIDX));
+        if constexpr (WIDX >= 0) move_w(W4Q_C(WIDX));
+        if constexpr (LIDX >= 0) move_l(W4Q_C(LIDX));
         W4_FENCE();
     };
     auto slot1 = [&](auto sc) {                           // half 1: set Y
         constexpr int S = decltype(sc)::value, I = S >> 3, J = S & 7;
+        // (set Y's A fragments were read late in half 0, in the order they are needed; the ops issued since -- counted -- may be outstanding)
+        if constexpr (S == 8) { w4_wait_lgkm_n<13>(); W4_FENCE(); }
+        if constexpr (S == 16) { w4_wait_lgkm_n<15>(); W4_FENCE(); }
         if constexpr (S == 20) {                          // THE barrier of the K tile
             w4_wait_lgkm_n<0>();
+            clap(2);
             __builtin_amdgcn_s_barrier();
+            clap(3);
             W4_FENCE();
             const unsigned d = st ? (unsigned)-W4P_S1 : (unsigned)W4P_S1;
             rdA[0] += d; rdB[0] += d;                     // the X reads below come from the other stage
@@ -1427,10 +1449,13 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const svr_gemm_
         for (kt = 0; kt < nk; ++kt) {
             w4_wait_lgkm_n<3>();                          // B0..7, A0..4 of set X are there (A5..7 may still be on their way: slot 8 waits)
             W4_FENCE();
+            cstart();
             W4Q_64(slot0);
-            w4_wait_lgkm_n<0>();
+            w4_wait_lgkm_n<11>();                         // B0..7 and A0 of set Y (A1..7 and four ds_writes were issued after A0's read)
             W4_FENCE();
+            clap(1);
             W4Q_64(slot1);
+            clap(4);
         }
         W4_FENCE();
         W4_LANDED();
@@ -1454,6 +1479,12 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const svr_gemm_
         W4_FENCE();
         W4Q_READ_X_ALL();
         W4_FENCE();
+    }
+    if constexpr (TL) {
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) timeline[(int64_t)blockIdx.x * 5 + q] = cyc[q];
+        }
     }
 #undef W4_FENCE
 #undef W4_LDA
@@ -1544,10 +1575,30 @@ static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
         return (int)hipGetLastError();
     }
 #endif
+#ifdef SVR_ABLATIONS
+    if (g_pipe_abl == 200) {                              // phase-level shader-clock counts of the default kernel -> stderr (synchronises)
+        static uint64_t* d_c = nullptr;
+        static uint64_t lds_attr_done_t = 0;
+        if (!d_c && hipMalloc(&d_c, 256 * 5 * 8) != hipSuccess) return (int)hipErrorOutOfMemory;
+        const int et = set_max_dynamic_lds((const void*)gemm_w4q_kernel<true>, W4P_LDS, lds_attr_done_t);
+        if (et != 0) return et;
+        (void)hipMemsetAsync(d_c, 0, 256 * 5 * 8, s);
+        hipLaunchKernelGGL(gemm_w4q_kernel<true>, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, d_c);
+        std::vector<uint64_t> h((size_t)grid * 5);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), d_c, h.size() * 8, hipMemcpyDeviceToHost);
+        double c5[5] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < grid; ++w) for (int q = 0; q < 5; ++q) c5[q] += (double)h[(size_t)w * 5 + q];
+        const double kts = (double)tiles * (a.K / BK);
+        fprintf(stderr, "[w4q] M %d N %d K %d: counts per K tile: half0 slots 0-7 %.0f (MFMA time 128) | half0 slots 8-63 %.0f (896) | half1 slots 0-19 "
+                        "%.0f (320) | barrier %.0f | half1 slots 20-63 %.0f (704)\n", a.M, a.N, a.K, c5[0] / kts, c5[1] / kts, c5[2] / kts, c5[3] / kts, c5[4] / kts);
+        return (int)hipGetLastError();
+    }
+#endif
     static uint64_t lds_attr_done_q = 0;
-    const int eq = set_max_dynamic_lds((const void*)gemm_w4q_kernel, W4P_LDS, lds_attr_done_q);
+    const int eq = set_max_dynamic_lds((const void*)gemm_w4q_kernel<false>, W4P_LDS, lds_attr_done_q);
     if (eq != 0) return eq;
-    hipLaunchKernelGGL(gemm_w4q_kernel, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a);
+    hipLaunchKernelGGL(gemm_w4q_kernel<false>, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, (uint64_t*)nullptr);
     return (int)hipGetLastError();
 }
 
