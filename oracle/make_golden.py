@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--only", default="", help="'r2': only the round-2 fixtures; 'r2-dit' / 'r2-vae17' / 'r2-vae1024': one of them; "
                                                "'r3-dit32' / 'r3-dit7b' / 'r3-refbf16': the round-3 fixtures")
     args = ap.parse_args()
+    if args.only.startswith("r4"):
+        return main_r4(args.only)
     if args.only.startswith("r3"):
         return main_r3(args.only)
     if args.only:
@@ -183,18 +185,30 @@ def pipeline_noise(lat):
     return torch.randn(lat.shape, generator=gg), torch.randn(lat.shape, generator=gg)
 
 
-def reference_pipeline_components(rl, config, weights, txt, dtype=torch.float32):
+# Round 4: the same chain at PRODUCTION width and depth -- the reference's 32-layer SeedVR2-3B NaDiT and its full-width VAE
+# (128, 256, 512, 512), VAE tiled 64 / 16 px in encode and decode (per-tile GroupNorm statistics and attention, cosine seams).
+PIPE_PROD = dict(frames=9, hw=(48, 80), resolution=96, batch_size=5, temporal_overlap=2, uniform_batch_size=True,
+                 seed_images=5, seed_dit=1234, seed_vae=1235, vae_channels=(128, 256, 512, 512), dit="DIT_3B",
+                 vae_tile=(64, 64), vae_tile_overlap=(16, 16))
+
+
+def reference_pipeline_components(rl, config, weights, txt, dtype=torch.float32, case=None):
     """pipeline_oracle.Components built from the REFERENCE: its NaDiT and VAE classes, and its glue function text.
     ``dtype`` bfloat16: models and the tensors handed to them in bf16 (the reference's production regime)."""
     from oracle import pipeline_oracle as po
+    case = PIPE_CASE if case is None else case
     glue = rl.reference_glue()
-    dcfg = config.DIT_TINY
-    vcfg = config.VAEConfig(block_out_channels=PIPE_CASE["vae_channels"])
-    dsd = weights.synth_dit_state_dict(dcfg, seed=PIPE_CASE["seed_dit"])
-    vsd = weights.synth_vae_state_dict(vcfg, seed=PIPE_CASE["seed_vae"])
-    dit = rl.build_reference_dit(dcfg.as_dict(), {k: v.to(dtype) for k, v in dsd.items()})
+    dcfg = getattr(config, case.get("dit", "DIT_TINY"))
+    vcfg = config.VAEConfig(block_out_channels=case["vae_channels"])
+    dsd = weights.synth_dit_state_dict(dcfg, seed=case["seed_dit"])
+    for k in list(dsd):                                 # (in place: the 3B state dict is 13.6 GB in fp32)
+        dsd[k] = dsd[k].to(dtype)
+    vsd = weights.synth_vae_state_dict(vcfg, seed=case["seed_vae"])
+    dit = rl.build_reference_dit(dcfg.as_dict(), dsd)
     vae = rl.build_reference_vae({k: v.to(dtype) for k, v in vsd.items()}, block_out_channels=vcfg.block_out_channels)
-    res = PIPE_CASE["resolution"]
+    tile = (dict(tiled=True, tile_size=tuple(case["vae_tile"]), tile_overlap=tuple(case["vae_tile_overlap"]))
+            if case.get("vae_tile") else {})
+    res = case["resolution"]
     resize, pad16 = glue["SideResize"](size=res, max_size=0), glue["DivisiblePad"]((16, 16))
 
     class _Dbg:
@@ -211,13 +225,13 @@ def reference_pipeline_components(rl, config, weights, txt, dtype=torch.float32)
 
     def vae_encode(x_cthw):                            # infer.py:117-199
         with torch.no_grad():
-            lat = vae.encode(x_cthw[None].to(dtype)).latent[0]
+            lat = vae.encode(x_cthw[None].to(dtype), **tile).latent[0]
         return (lat.permute(1, 2, 3, 0) - vcfg.shifting_factor) * vcfg.scaling_factor
 
     def vae_decode(lat_thwc):                          # infer.py:203-278
         z = (lat_thwc / vcfg.scaling_factor + vcfg.shifting_factor).permute(3, 0, 1, 2)[None]
         with torch.no_grad():
-            return vae.decode(z.to(dtype)).sample[0].float()
+            return vae.decode(z.to(dtype), **tile).sample[0].float()
 
     def dit_fn(vid, text):
         T, H, W, C = vid.shape
@@ -349,6 +363,55 @@ def main_r3(which):
         res["pipeline_small"] = out.to(bf)
         print("refbf16 pipeline_small", tuple(out.shape))
         torch.save(res, os.path.join(GOLD, "refbf16.pt"))
+
+
+def main_r4(which):
+    from oracle import reference_loader as rl
+    assert rl.available(), "needs /root/reference"
+    config = importlib.import_module(PKG + ".config")
+    weights = importlib.import_module(PKG + ".weights")
+    if which in ("r4", "r4-prod"):
+        from oracle import pipeline_oracle as po
+        pc = PIPE_PROD
+        images = torch.rand(pc["frames"], pc["hw"][0], pc["hw"][1], 3, generator=torch.Generator().manual_seed(pc["seed_images"]))
+        text = weights.synth_text_embedding()
+        t0 = time.time()
+        comps = reference_pipeline_components(rl, config, weights, text, case=pc)
+        print("pipeline_prod reference models built %.0fs" % (time.time() - t0))
+        t0 = time.time()
+        out = po.upscale(images, text.float(), comps, pc["batch_size"], pc["temporal_overlap"], pc["uniform_batch_size"])
+        print("pipeline_prod fp32 %.0fs" % (time.time() - t0), tuple(out.shape), float(out.mean()), float(out.std()))
+        del comps
+        t0 = time.time()
+        comps = reference_pipeline_components(rl, config, weights, text, dtype=torch.bfloat16, case=pc)
+        out_bf = po.upscale(images, text, comps, pc["batch_size"], pc["temporal_overlap"], pc["uniform_batch_size"],
+                            compute_dtype=torch.bfloat16)
+        mse = float((out_bf.double() - out.double()).pow(2).mean())
+        import math
+        print("pipeline_prod reference-bf16 twin %.0fs: %.2f dB vs its fp32 self" % (time.time() - t0, 10 * math.log10(1.0 / mse)))
+        del comps
+        torch.save({"out": out.clone(), "out_refbf16": out_bf.to(torch.bfloat16).clone(), **{k: v for k, v in pc.items()}},
+                   os.path.join(GOLD, "pipeline_prod.pt"))
+    if which in ("r4", "r4-dit7b36"):
+        # the FULL-DEPTH SeedVR2-7B (36 layers, 3072 wide, 8.2e9 parameters = 33 GB in fp32) at BASELINE config 1's shape
+        txt = torch.load(os.path.join(GOLD, "text_pos_emb.pt"), weights_only=True)
+        cfg = config.DIT_7B
+        t0 = time.time()
+        sd = weights.synth_dit_state_dict(cfg)
+        for k in list(sd):
+            sd[k] = sd[k].float()
+        print("7B weights %.0fs" % (time.time() - t0))
+        vid = dit_inputs(1, 32, 32, seed=50)
+        ref = rl.build_reference_dit(cfg.as_dict(), sd)
+        del sd
+        t0 = time.time()
+        with torch.no_grad():
+            out = ref(vid=vid.float().reshape(-1, 33), txt=txt.float(), vid_shape=torch.tensor([[1, 32, 32]]),
+                      txt_shape=torch.tensor([[txt.shape[0]]]), timestep=torch.tensor([1000.0])).vid_sample
+        out = out.reshape(1, 32, 32, -1).contiguous()
+        print("dit7b_36l_cfg1 reference fp32 forward %.0fs" % (time.time() - t0), tuple(out.shape), float(out.std()))
+        torch.save({"out": out, "latent": (1, 32, 32), "seed_input": 50, "seed_weights": weights.SEED_WEIGHTS},
+                   os.path.join(GOLD, "dit7b_36l_cfg1.pt"))
 
 
 if __name__ == "__main__":

@@ -1,6 +1,8 @@
-"""Import the reference's own model code, UNMODIFIED, from /root/reference
-(test infrastructure only; /root/reference exists in the build container, not
-on the GPU box -- callers must check ``available()`` first).
+"""Import the reference's own model code, UNMODIFIED (test infrastructure only; callers must check ``available()`` first):
+  * from the checkout at /root/reference where it is mounted (the build container), or
+  * from ``oracle/_ref`` -- the same modules byte-compiled by the committed recipe oracle/build_ref.py (no source text; it
+    travels to the GPU box with the snapshot), which is how the GPU node times and tests against the reference itself.
+``SEEDVR2_REFERENCE_ROOT`` overrides both.
 
 Reference entry points wrapped here:
   NaDiT                         src/models/dit_3b/nadit.py:39
@@ -11,11 +13,38 @@ import io
 import os
 import sys
 
-REFERENCE_ROOT = os.environ.get("SEEDVR2_REFERENCE_ROOT", "/root/reference")
+_COMPILED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+
+
+def _compiled_ok() -> bool:
+    """oracle/_ref exists and was compiled by THIS interpreter version (bytecode is version-bound)."""
+    import json
+    try:
+        with open(os.path.join(_COMPILED, "MANIFEST.json")) as f:
+            return json.load(f).get("interpreter") == "cpython-%d.%d" % sys.version_info[:2]
+    except (OSError, ValueError):
+        return False
+
+
+def _resolve_root() -> str:
+    env = os.environ.get("SEEDVR2_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isdir("/root/reference/src/models/dit_3b"):
+        return "/root/reference"
+    return _COMPILED if _compiled_ok() else "/root/reference"
+
+
+REFERENCE_ROOT = _resolve_root()
 
 
 def available() -> bool:
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "src", "models", "dit_3b"))
+
+
+def kind() -> str:
+    """"source": the checkout; "compiled": oracle/_ref (the same code, byte-compiled by oracle/build_ref.py)."""
+    return "source" if os.path.exists(os.path.join(REFERENCE_ROOT, "src", "models", "dit_3b", "nadit.py")) else "compiled"
 
 
 def _prepare():
@@ -132,6 +161,18 @@ def build_reference_vae(state_dict=None, dtype=None, block_out_channels=None, sl
 # (unmodified text, selected by name with ``ast``) into a namespace that only provides what they touch.
 def _extract(path: str, names, namespace: dict) -> dict:
     import ast
+    if not os.path.exists(os.path.join(REFERENCE_ROOT, path)):
+        # oracle/_ref: the definitions' code objects, compiled from the unmodified AST by oracle/build_ref.py
+        import marshal
+        with open(os.path.join(REFERENCE_ROOT, "defs", path.replace("/", "__") + ".marshal"), "rb") as f:
+            table = marshal.load(f)
+        missing = set(names) - set(table)
+        if missing:
+            raise ImportError(f"{path}: {sorted(missing)} not found")
+        for name, code in table.items():               # (file order, as the source branch below)
+            if name in names:
+                exec(code, namespace)
+        return namespace
     src = open(os.path.join(REFERENCE_ROOT, path)).read()
     tree = ast.parse(src)
     picked = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]

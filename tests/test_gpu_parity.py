@@ -1,14 +1,16 @@
-"""-m gpu: end-to-end parity of the HIP engines against (a) the committed golden outputs of the
-reference implementation (tests/golden, produced by oracle/make_golden.py) and (b) the in-repo CPU
-oracle run live on the same seeded inputs.
+"""-m gpu: end-to-end parity of the HIP engines against (a) the committed golden outputs of the REFERENCE implementation
+(tests/golden, produced by oracle/make_golden.py from the imported reference in fp32) and (b) the in-repo CPU oracle run live
+on the same seeded inputs.  Every test goes ctypes -> C ABI -> HIP kernels (``HipOps``); the oracle is only the checker.
 
-Tolerances (stated contract): the reference's own bf16 path differs from its
-fp32 self by rel-err 1.66e-2 (DiT-3B) and 1.6e-2 / 2.3e-2 (VAE encode / decode), so "1e-3 end to end"
-is below the storage-format noise floor.  We require, against the fp32 reference outputs:
-  * DiT: rel-err <= 2.0e-2 and PSNR >= 50 dB;   * VAE: rel-err <= 2.5e-2 and PSNR >= 50 dB
-with PSNR measured against the reference output's own range (max - min) for latents / DiT predictions, and
-against the NOMINAL range 2.0 of clamped [-1, 1] frames for decoded pixels (``psnr_nominal``).
-Round-2 tests (production width, multi-window, multi-tile, real tile size) assert measured x 1.5.
+Tolerances (the stated contract, SURVEY.md 8(c)(4) / DESIGN.md section 4; storage = bf16 MFMA operands + fp32 residual trunk /
+stream).  A single bf16 rounding of a perfect result is 1.7e-3 L2 rel-err, so "1e-3" is enforced per kernel with an fp32
+store (tests/test_gpu_kernels.py); end to end the asserts sit AT THE BAR of the north star:
+  * decoded frames: PSNR >= 50.0 dB against the reference's fp32 output at the NOMINAL peak (2.0 for [-1, 1] frames, 1.0 for
+    [0, 1] frames: ``psnr_nominal`` / ``_psnr_unit``) -- vae_tiled17, vae_tile1024, pipeline_small, pipeline_prod;
+  * DiT predictions: rel-err <= 1e-2 at full depth (measured 4.6e-3 at 32 layers), PSNR against the output's own range;
+  * wherever the fixture holds the REFERENCE's own bf16 run on the same inputs (refbf16.pt, pipeline_prod.pt): engine error
+    <= reference-bf16 error -- never worse than what the reference does in its production dtype.
+Measured values are printed by each test; the committed numbers live in DESIGN.md section 4.
 """
 import math
 import os
@@ -49,7 +51,7 @@ def test_dit_tiny_vs_reference_golden(hip):
     g, txt = _golden("dit_tiny.pt"), _golden("text_pos_emb.pt")
     eng = dit.NaDiTEngine(config.DIT_TINY, weights.synth_dit_state_dict(config.DIT_TINY, seed=g["seed_weights"]), hip)
     out = eng.forward(g["vid"].cuda(), txt.cuda(), 1000.0).float().cpu()
-    assert rel_err(out, g["out"]) < 2.0e-2 and psnr(out, g["out"]) > 50
+    assert rel_err(out, g["out"]) < 8e-3 and psnr(out, g["out"]) > 60      # measured 2.8e-3 / 70 dB
 
 
 def test_dit_7b_family_vs_reference_golden(hip):
@@ -62,7 +64,7 @@ def test_dit_7b_family_vs_reference_golden(hip):
     out = eng.forward(g["vid"].cuda(), txt.cuda(), 1000.0).float().cpu()
     e, p = rel_err(out, g["out"]), psnr(out, g["out"])
     print(f"DiT-7B family (tiny): rel-err {e:.3e}, PSNR {p:.1f} dB")
-    assert e < 2.0e-2 and p > 50
+    assert e < 8e-3 and p > 60                          # measured 2.7e-3 / 70 dB
 
 
 _ENGINES = {}
@@ -100,7 +102,55 @@ def test_dit_3b_full_depth_multiwindow_vs_reference_golden(hip):
     e, p = rel_err(out, g["out"]), psnr(out, g["out"])
     print(f"DiT-3B, 32 layers, 48 windows per layer pair (9x30x54 tokens): rel-err {e:.3e}, PSNR {p:.1f} dB")
     assert e < 1.0e-2 and p > 55
+
+
+def test_pipeline_production_width_and_depth_vs_reference_golden(hip):
+    """The WHOLE chain at production width and depth (round 4): the reference's own four phases
+    (generation_phases.py:171,542,807,1060, restated by oracle/pipeline_oracle.py and pinned to the phase text by
+    tests/test_reference_phases_dropin.py) over its 32-layer SeedVR2-3B NaDiT (dit_3b/nadit.py:190) and its full-width VAE
+    (attn_video_vae.py:1660; 128-256-512-512) -- 9 frames 48x80 -> 96x160, batches of 5 with uniform padding and a 2-frame
+    overlap blend, VAE tiled 64 / 16 px in encode and decode (per-tile GroupNorm statistics and attention, cosine seams), LAB
+    colour fix; golden in fp32 plus the reference's own bf16 run of the same chain (oracle/make_golden.py --only r4-prod)."""
+    from oracle import make_golden as mg
+    config, weights, vae, runner, pipeline = (sub(n) for n in ("config", "weights", "vae", "runner", "pipeline"))
+    g = _golden("pipeline_prod.pt")
+    dcfg, vcfg = getattr(config, g["dit"]), config.VAEConfig(block_out_channels=tuple(g["vae_channels"]))
+    assert dcfg is config.DIT_3B and vcfg.block_out_channels == config.VAE_V3.block_out_channels
+    r = runner.VideoDiffusionInfer(runner.default_config(dcfg, vcfg), encode_tiled=True, decode_tiled=True,
+                                   encode_tile_size=tuple(g["vae_tile"]), encode_tile_overlap=tuple(g["vae_tile_overlap"]),
+                                   decode_tile_size=tuple(g["vae_tile"]), decode_tile_overlap=tuple(g["vae_tile_overlap"]))
+    r.dit = _dit3b_engine(hip, g["seed_dit"])
+    r.vae = vae.VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, seed=g["seed_vae"]), hip)
+    images = torch.rand(g["frames"], g["hw"][0], g["hw"][1], 3, generator=torch.Generator().manual_seed(g["seed_images"]))
+    out = pipeline.upscale(images.cuda(), r, weights.synth_text_embedding().cuda(), resolution=g["resolution"],
+                           batch_size=g["batch_size"], uniform_batch_size=g["uniform_batch_size"],
+                           temporal_overlap=g["temporal_overlap"], color_correction="lab",
+                           noise_provider=mg.pipeline_noise).float().cpu()
+    assert out.shape == g["out"].shape
+    p, e = _psnr_unit(out, g["out"]), rel_err(out, g["out"])
+    p_ref = _psnr_unit(g["out_refbf16"].float(), g["out"])
+    print(f"pipeline at production width/depth (3B x 32 layers + full VAE, tiled) vs the reference chain: PSNR {p:.1f} dB at the "
+          f"nominal peak, rel-err {e:.3e}; the reference chain in bf16 on the same inputs: {p_ref:.1f} dB")
+    assert p >= 50.0 and p >= p_ref
     _ENGINES.clear()                                   # (7 GB of weights: not needed by the tests that follow)
+
+
+def test_dit_7b_full_depth_vs_reference_golden(hip):
+    """SeedVR2-7B at FULL depth and production width: 36 layers x 3072 (8.2e9 synthetic parameters; dit_7b/nadit.py,
+    configs_7b/main.yaml:11-33) at BASELINE config 1's shape (latent 1x32x32); golden from the imported reference's dit_7b code
+    in fp32 (33 GB of weights on the build box, oracle/make_golden.py --only r4-dit7b36)."""
+    from oracle import make_golden as mg
+    config, weights, dit = sub("config"), sub("weights"), sub("dit")
+    g, txt = _golden("dit7b_36l_cfg1.pt"), _golden("text_pos_emb.pt")
+    cfg = config.DIT_7B
+    eng = dit.NaDiTEngine(cfg, weights.synth_dit_state_dict(cfg, seed=g["seed_weights"]), hip)
+    vid = mg.dit_inputs(*g["latent"], seed=g["seed_input"]).cuda()
+    out = eng.forward(vid, txt.cuda(), 1000.0).float().cpu()
+    e, p = rel_err(out, g["out"]), psnr(out, g["out"])
+    print(f"DiT-7B, 36 layers at production width (cfg-1 shape): rel-err {e:.3e}, PSNR {p:.1f} dB")
+    assert e < 1.0e-2 and p > 55
+    del eng
+    torch.cuda.empty_cache()
 
 
 def test_dit_7b_production_width_vs_reference_golden(hip):
@@ -123,7 +173,7 @@ def test_dit_3b_width_multiwindow_vs_reference_golden(hip):
     """Production WIDTH (2560, 20 heads x 128) on a cropped BASELINE config-3 token grid 9x30x54: the config-3 window
     (3x15x27 = 1215 video rows + 58 text rows), 12 regular + 36 shifted windows with ragged edges (77 .. 1215 rows),
     2 MM + 2 shared blocks, last block video-only; golden from the imported reference (fp32).  Both window-attention
-    kernels.  Measured on MI355X: see the printed values; bound = measured x 1.5."""
+    kernels.  Measured on MI355X: 2.9e-3 / 70 dB; asserted: <= 9e-3, and never worse than the reference's own bf16 run."""
     from oracle import make_golden as mg
     config, weights, dit = sub("config"), sub("weights"), sub("dit")
     g, txt = _golden("dit3b_w4l_crop.pt"), _golden("text_pos_emb.pt")
@@ -139,7 +189,7 @@ def test_dit_3b_width_multiwindow_vs_reference_golden(hip):
             hip.set_option("attn_impl", 0)
         e, p = rel_err(out, g["out"]), psnr(out, g["out"])
         print(f"DiT 3B-width 4 layers, 48 windows, attn_impl={impl}: rel-err {e:.3e}, PSNR {p:.1f} dB")
-        assert e < 9e-3 and p > 60, (impl, e, p)      # measured 5.7e-3 / 64.3 dB (4 layers; 32-layer budget: 2e-2)
+        assert e < 9e-3 and p > 60, (impl, e, p)      # measured 2.9e-3 / 70.3 dB with the fp32 residual stream
         outs[impl] = out
     assert rel_err(outs[0], outs[1]) < 4e-3
     e_ref = rel_err(_golden("refbf16.pt")["dit3b_w4l_crop"].float(), g["out"])
@@ -327,12 +377,10 @@ def test_pipeline_vs_reference_golden(hip):
     """The whole chain (batching with uniform padding, 4n+1 padding, input transform in bf16, VAE encode, one-step DiT, VAE
     decode, trims, 2-frame overlap blend, LAB colour fix, [-1,1] -> [0,1]) on the GPU against the golden of the REFERENCE's
     components in fp32 (tests/golden/pipeline_small.pt, oracle/make_golden.py --only r2-pipe) -- not against this repo's
-    own host logic.  Reported: PSNR at the nominal peak (1.0 on [0,1] frames) with and without the colour fix stage.
-    Measured on MI355X (round 2): 48.2 dB at the nominal peak, rel-err 6.9e-3; asserted = measured - 1.5 dB.  Where the dB
-    go: the VAE decode in bf16 storage alone measures 49.4 / 50.3 dB at the same peak on exact inputs (the 17-frame and the
-    1024-px-tile tests above; rel-err 1.0e-2), encode + DiT errors arriving in its input cost the rest; the glue is exact
-    (tests/test_pipeline_oracle.py).  The reference's own bf16 path sits at 46.3 dB for the decode alone (BASELINE.md
-    section 2), so 50 dB end to end is below the bf16 storage floor of this architecture with random-initialised weights."""
+    own host logic.  Measured on MI355X (round 3, fp32 trunk / stream): 50.7 dB at the nominal peak (1.0 on [0, 1] frames),
+    rel-err 5.2e-3; the reference's own chain in bf16 on the same inputs: 47.3 dB.  Asserted at the bar: >= 50.0 dB and
+    >= the reference-bf16 run (tests/golden/refbf16.pt).  The same chain at production width and depth:
+    test_pipeline_production_width_and_depth_vs_reference_golden."""
     from oracle import make_golden as mg
     config, weights, dit, vae, runner, pipeline = (sub(n) for n in ("config", "weights", "dit", "vae", "runner", "pipeline"))
     g = _golden("pipeline_small.pt")
