@@ -23,6 +23,7 @@ all-reduced count of ranks that ran.
 import argparse
 import importlib
 import json
+import math
 import os
 import socket
 import statistics
@@ -65,6 +66,7 @@ def make_profiled_ops(device):
     class ProfiledOps(ops_mod.HipOps):
         def __init__(self, device):
             super().__init__(device)
+            self.record_kernel_class = True
             self.recording = False
             self.events = []        # (kind, flops, start, end)
 
@@ -73,24 +75,16 @@ def make_profiled_ops(device):
                 return super().gemm(A, W, out, **kw)
             conv = kw.get("conv")
             if conv is not None:
-                M = conv.To * conv.Ho * conv.Wo
-                # mirrors conv_halo_eligible() in csrc/svr_conv_halo.hip: stride-1 "same" 3x3 spatial kernels
-                halo = (conv.k[1] == 3 and conv.k[2] == 3 and tuple(conv.stride) == (1, 1, 1) and conv.pad[1] == 1
-                        and conv.pad[2] == 1 and conv.Ho == conv.H and conv.Wo == conv.W and conv.Cin % 64 == 0
-                        and (kw["N"] % 128 == 0 or kw["N"] <= 32))
-                # (kt, 2, 2)-tap phase convs of the sub-pixel upsamplers: svr_conv_sub.hip when the fragment-ordered weights are given
-                sub = conv.k[1] == 2 and conv.k[2] == 2 and kw.get("phase") is not None
-                kind = "conv_halo" if halo else ("conv_subpixel" if sub else "conv_generic")
-                flops = 2.0 * M * kw["N"] * conv.k[0] * conv.k[1] * conv.k[2] * conv.Cin
+                flops = 2.0 * conv.To * conv.Ho * conv.Wo * kw["N"] * conv.k[0] * conv.k[1] * conv.k[2] * conv.Cin
             else:
-                M = kw.get("M") or A.shape[0]
-                kind = "gemm"
-                flops = 2.0 * M * kw["N"] * kw["K"]
+                flops = 2.0 * (kw.get("M") or A.shape[0]) * kw["N"] * kw["K"]
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
+            s.record()                                   # (on the CURRENT stream = the stream the C ABI launches on)
             r = super().gemm(A, W, out, **kw)
             e.record()
-            self.events.append((kind, flops, s, e))
+            # which kernel served the launch is the LIBRARY's answer (svr_gemm_kernel_class, the routing function the launch
+            # itself uses: csrc/svr_gemm.hip gemm_route) -- "conv_halo" is conv_halo2_kernel alone
+            self.events.append((self.last_kernel_class, flops, s, e))
             return r
 
         def summary(self):
@@ -107,18 +101,21 @@ def make_profiled_ops(device):
 
 
 def cpu_baseline(flops_per_frame: float) -> dict:
-    """The CPU oracle (oracle/, a port of the reference's PyTorch path) timed on this host's cores on a bounded
-    sample of the same pipeline: 1 warm-up + median of 3 per leg, converted to the metric's
-    unit through the algorithmic FLOP ratio (labelled extrapolation).  Test infrastructure used only as a reported
-    baseline.  profiles/r2_cpu_reference_vs_port.json holds the calibration of this port against the reference
-    implementation itself on the same sample (build container, where /root/reference is mounted)."""
-    from oracle import dit_oracle, vae_oracle
+    """The reference's CPU path timed on this host's cores on a bounded sample of the same pipeline: 1 warm-up + median of 3
+    per leg, converted to the metric's unit through the algorithmic FLOP ratio (labelled extrapolation).
+    ``kind`` "reference": the reference's own NaDiT / VideoAutoencoderKLWrapper classes (PyTorch-SDPA path, fp32), imported by
+    oracle/reference_loader.py from the checkout or -- on the GPU box -- from oracle/_ref, the same modules byte-compiled by the
+    committed recipe oracle/build_ref.py.  ``kind`` "port" (only when neither is present): the in-repo restatement oracle/*.py,
+    calibrated against the reference at 1.06x its time (profiles/r2_cpu_reference_vs_port.json).  Test infrastructure used only
+    as a reported baseline."""
+    from oracle import dit_oracle, vae_oracle, reference_loader as rl
     config, weights, windows, flops = sub("config"), sub("weights"), sub("windows"), sub("flops")
     cores = torch.get_num_threads()
     vcfg = config.VAE_V3
     vsd = {k: v.float() for k, v in weights.synth_vae_state_dict(vcfg).items()}
     g = torch.Generator().manual_seed(0)
     x = torch.rand(3, 5, 96, 96, generator=g) * 2 - 1
+    use_ref = rl.available()
 
     def median3(fn):
         fn()                                            # warm-up
@@ -129,23 +126,42 @@ def cpu_baseline(flops_per_frame: float) -> dict:
             ts.append(time.perf_counter() - t0)
         return statistics.median(ts)
 
-    def vae_leg():
-        lat = vae_oracle.runner_vae_encode(x, vsd, vcfg)
-        vae_oracle.runner_vae_decode(lat, vsd, vcfg)
-
-    t_vae = median3(vae_leg)
-    f_vae = sum(flops.vae_flops_tiled(vcfg, 5, 96, 96, False).values())
     # 2-layer slice (one regular + one shifted window layer) of the 3B-width DiT on a 3x48x48 latent
     dcfg = config.DiTConfig(num_layers=2, mm_layers=1)
     dsd = weights.synth_dit_state_dict(dcfg)
     vid = torch.randn(3, 48, 48, 33, generator=g)
     txt = weights.synth_text_embedding().float()
-    t_dit = median3(lambda: dit_oracle.dit_forward(dsd, dcfg, vid, txt, 1000.0, windows_mod=windows))
+    if use_ref:
+        ref_vae = rl.build_reference_vae(vsd)                       # slicing split 4 + memory limits as configs_3b/main.yaml:53-58
+        ref_dit = rl.build_reference_dit(dcfg.as_dict(), {k: v.float() for k, v in dsd.items()})
+
+        def vae_leg():
+            with torch.no_grad():
+                lat = ref_vae.encode(x[None]).latent
+                ref_vae.decode(lat)
+
+        def dit_leg():
+            with torch.no_grad():
+                ref_dit(vid=vid.reshape(-1, 33), txt=txt, vid_shape=torch.tensor([[3, 48, 48]]),
+                        txt_shape=torch.tensor([[txt.shape[0]]]), timestep=torch.tensor([1000.0]))
+    else:
+        def vae_leg():
+            lat = vae_oracle.runner_vae_encode(x, vsd, vcfg)
+            vae_oracle.runner_vae_decode(lat, vsd, vcfg)
+
+        def dit_leg():
+            dit_oracle.dit_forward(dsd, dcfg, vid, txt, 1000.0, windows_mod=windows)
+
+    t_vae = median3(vae_leg)
+    f_vae = sum(flops.vae_flops_tiled(vcfg, 5, 96, 96, False).values())
+    t_dit = median3(dit_leg)
     f_dit = flops.dit_flops(dcfg, (3, 24, 24))["total"]
     tflops = (f_vae + f_dit) / (t_vae + t_dit) / 1e12
-    return {"value": tflops * 1e12 / flops_per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
+    what = (f"the reference's own model classes ({rl.kind()}: {'oracle/_ref, byte-compiled by oracle/build_ref.py' if rl.kind() == 'compiled' else rl.REFERENCE_ROOT}), fp32, PyTorch-SDPA path"
+            if use_ref else "oracle/*.py (in-repo port of the reference's PyTorch path), fp32")
+    return {"value": tflops * 1e12 / flops_per_frame, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
             "cpu_tflops": tflops, "timing": "1 warm-up + median of 3 per leg",
-            "sample": f"oracle fp32: full VAE enc+dec of a 5x96x96 clip ({t_vae:.2f}s) + 2-layer (regular + shifted windows) "
+            "sample": f"{what}: full VAE enc+dec of a 5x96x96 clip ({t_vae:.2f}s) + 2-layer (regular + shifted windows) "
                       f"3B-width DiT on a 3x48x48 latent ({t_dit:.2f}s); extrapolated to the workload by algorithmic FLOPs"}
 
 
@@ -183,6 +199,9 @@ def main():
     ap.add_argument("--bf16-trunk", action="store_true",
                     help="A/B: round 2's storage regime -- the VAE's residual trunk and the DiT's residual stream in bf16 instead of "
                          "fp32 (48.1 instead of 51.2 dB end to end against the fp32 reference)")
+    ap.add_argument("--tile-streams", type=int, default=None,
+                    help="A/B: HIP streams the VAE's spatial tiles are issued on (VideoVAEEngine(tile_streams=...); default: the "
+                         "engine's, 2; 1 = every launch on one stream)")
     ap.add_argument("--branch", choices=["fp32", "bf16"], default=None,
                     help="A/B: storage of conv1's output inside a VAE block (VideoVAEEngine(branch_fp32=...)); default: the engine's")
     args = ap.parse_args()
@@ -210,6 +229,7 @@ def main():
     vae = sub("vae").VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, device=device), ops,
                                     merge_upsamplers=not args.two_step_upsampler, merge_causal_head=not args.three_tap_head,
                                     trunk_fp32=not args.bf16_trunk,
+                                    **({} if args.tile_streams is None else {"tile_streams": args.tile_streams}),
                                     **({} if args.branch is None else {"branch_fp32": args.branch == "fp32"}))
     runner_mod = sub("runner")
     runner = runner_mod.VideoDiffusionInfer(
@@ -254,8 +274,17 @@ def main():
             if timed: ev[4].record()
             return gathered, ev
 
+    def fingerprint(t):
+        """fp64 sum and sum of squares of an output (on the device, OUTSIDE the timed region)."""
+        d = t.double()
+        return torch.stack([d.sum(), (d * d).sum()])
+
+    first_print = None
     for _ in range(args.warmup):
-        step(False)
+        out, _ = step(False)
+        if first_print is None:
+            first_print = fingerprint(out)
+        del out
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -263,13 +292,45 @@ def main():
     evs = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, ev = step(True)
+        last_out, ev = step(True)
         evs.append(ev)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     ops.recording = False
+    # ---- output guards (after the timed region): a kernel that exits early, or a launch that was dropped, must not post a record.
+    # (1) every value of the last step's output is finite; (2) its statistics sit in the band the REFERENCE's decoder produces
+    # with these synthetic weights (tests/golden/vae_tile1024.pt records mean / std / min / max of the reference's fp32 decode
+    # at the real tile size: std 0.58, range about [-3.5, 3]); for the [0, 1] frames of the cfg4 pipeline the band is that of
+    # clamped frames; (3) the hot path is deterministic, so the last timed step must reproduce the first warm-up step's
+    # output sums bit for bit (same inputs).  On failure: no JSON line, exit code 3.
+    guard = {"finite": bool(torch.isfinite(last_out).all())}
+    fp_last = fingerprint(last_out)
+    n_el = last_out.numel()
+    g_mean, g_std = float(fp_last[0]) / n_el, math.sqrt(max(float(fp_last[1]) / n_el - (float(fp_last[0]) / n_el) ** 2, 0.0))
+    try:
+        gold = torch.load(os.path.join(ROOT, "tests", "golden", "vae_tile1024.pt"), weights_only=True)
+        ref_mean, ref_std = float(gold["dec_mean"]), float(gold["dec_std"])
+    except (OSError, KeyError):
+        ref_mean, ref_std = 0.0, 0.58
+    if sharded:
+        band_ok = 0.05 <= g_std <= 0.6 and 0.2 <= g_mean <= 0.8          # [0, 1] frames after clamp and colour fix
+    else:
+        band_ok = 0.5 * ref_std <= g_std <= 2.0 * ref_std and abs(g_mean - ref_mean) <= ref_std
+    guard.update(mean=g_mean, std=g_std, band_ok=band_ok, reference_decode_mean=ref_mean, reference_decode_std=ref_std,
+                 deterministic=None if first_print is None else bool(torch.equal(first_print, fp_last)))
+    bad = (not guard["finite"]) or (not band_ok) or guard["deterministic"] is False
+    if world > 1:
+        flag = torch.tensor([int(bad)], device=device)
+        torch.distributed.all_reduce(flag)
+        bad = bool(flag.item())
+    if bad:
+        print(f"[bench] rank {rank}: output guard FAILED, refusing to report a number: {guard}", file=sys.stderr)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        sys.exit(3)
+    del last_out
     n_ranks = 1
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -303,17 +364,21 @@ def main():
             frames_per_step = world * useful
             padded_per_step = world * frames
         kern = ops.summary()
-        # dominant kernel: the LDS-halo implicit-GEMM conv (73 % of the step, profiles/r2_cfg3_kernel_stats.csv)
-        dom = kern.get("conv_halo") or kern.get("conv_generic") or kern["gemm"]
+        # dominant kernel: the LDS-halo implicit-GEMM conv (63 % of the step, profiles/r3_cfg3_kernel_stats.csv) -- its launches
+        # ALONE (the thin-output / thin-input / sub-pixel / generic conv kernels are separate classes of `per_kernel`)
+        dom = kern.get("conv_halo") or kern.get("conv_generic") or kern.get("gemm_persistent") or kern["gemm"]
         c_flops, c_sec, c_n = dom["flops"], dom["seconds"], dom["launches"]
         traffic, traffic_note = None, None
-        for name in ("r3_cfg3_pmc_traffic.json", "r2_cfg3_pmc_traffic.json", "r1_cfg3_pmc_traffic.json"):
+        shader_clock = None
+        for name in ("r4_cfg3_pmc_traffic.json", "r3_cfg3_pmc_traffic.json", "r2_cfg3_pmc_traffic.json", "r1_cfg3_pmc_traffic.json"):
             # HBM bytes per launch come from separate rocprofv3 --pmc passes of this workload (counters cannot be collected
             # inside the timed run); the file names the commit it was measured on
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pmc.get("workload") == "cfg3" and args.workload == "cfg3" and "conv_halo" in kern:
-                    traffic = pmc["kernels"][pmc.get("dominant", "svr::conv_halo2_kernel")]["hbm_bytes_per_launch"]
+                    krec = pmc["kernels"][pmc.get("dominant", "svr::conv_halo2_kernel")]
+                    traffic = krec["hbm_bytes_per_launch"]
+                    shader_clock = krec.get("shader_clock_ghz")
                     traffic_note = f"bytes/launch, FETCH_SIZE*2 + WRITE_SIZE from profiles/{name}" + \
                                    (f" (kernels as of {pmc['measured_at']})" if pmc.get("measured_at") else "")
                     break
@@ -323,6 +388,12 @@ def main():
                 "achieved": c_flops / max(c_sec, 1e-12) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": c_flops / max(c_sec, 1e-12) / 1e12 / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "traffic_note": traffic_note,
+                # effective shader clock of this kernel under load = GRBM_GUI_ACTIVE cycles / launch duration, from the same PMC
+                # passes (the chip is power-managed: nominal 2.4 GHz is what `peak` assumes)
+                "shader_clock_ghz": shader_clock,
+                "timing_note": ("HIP events on the launch stream; with tile_streams > 1 another tile's kernels share the chip while "
+                                "a launch runs, so durations include that overlap (--tile-streams 1 isolates the kernel)")
+                               if getattr(vae, "tile_streams", 1) > 1 else "HIP events on the launch stream",
                 "launches": c_n, "avg_launch_us": c_sec / max(c_n, 1) * 1e6,
                 "algorithmic_flops_per_launch": c_flops / max(c_n, 1),
                 "share_of_step_time": c_sec / max(dt, 1e-12),
@@ -350,7 +421,22 @@ def main():
             "executed_tflop_per_step": f_exec / 1e12,
             "achieved_tflops_per_gpu": f_exec * (1 if sharded else world) * args.steps / dt / 1e12 / world,
             "roofline": roof,
+            "vae_tile_streams": getattr(vae, "tile_streams", 1),
+            "output_guard": guard,
         }
+        # DESIGN.md section 6's falsifiable prediction for THIS launch (from the 1-GPU phase times of rounds 3-4): compute is
+        # perfectly parallel over ranks, communication = direct xGMI transfers at ~64 GB/s per direction and link
+        if world > 1 or sharded:
+            frame_bytes = H * W * 3 * 2
+            if sharded:
+                per_batch_s, n_b = 44.7 / 8, len(plans)
+                comm = (frames * frame_bytes / max(world, 1)) / 64e9 + 0.001 * (n_b - 1)
+                res["predicted_s"] = {"per_step": math.ceil(n_b / world) * per_batch_s + (comm if world > 1 else 0.0),
+                                      "model": f"ceil({n_b} batches / {world} ranks) x 5.6 s per 17-frame batch (44.7 s / 8 on one GPU, "
+                                               "profiles/r3_bench_cfg4_1gpu.json) + gather of the clip over xGMI"}
+            else:
+                res["predicted_s"] = {"per_step": 9.82 + (world - 1) * useful * frame_bytes / 64e9 / max(world - 1, 1) + 0.003,
+                                      "model": "the 1-GPU step (9.82 s, round 3) + all-gather: each link carries one rank's frames once"}
         if not sharded:
             dit_tf = f_dit["total"] / max(phase["dit"], 1e-9) / 1e9
             res.update({"dit_ms_per_step": phase["dit"], "vae_encode_ms": phase["encode"], "vae_decode_ms": phase["decode"],

@@ -68,11 +68,34 @@ int svr_device_info(char* buf, int32_t buflen) {
 }
 
 int svr_gemm_bf16(const svr_gemm_args* args, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (!args) return fail("svr_gemm_bf16: null args");
     const char* why = nullptr;
     const int rc = gemm_dispatch(*args, (hipStream_t)stream, &why);
     if (why) return fail(why);
     return check(rc, "svr_gemm_bf16");
+}
+
+int32_t svr_gemm_kernel_class(const svr_gemm_args* args) {
+    if (!args) { fail("svr_gemm_kernel_class: null args"); return -1; }
+    const char* why = nullptr;
+    const int cls = gemm_route(*args, &why);
+    if (why) fail(why);
+    return cls;
+}
+
+const char* svr_gemm_kernel_name(int32_t cls) {
+    switch (cls) {
+        case SVR_KERNEL_NONE: return "none";
+        case SVR_KERNEL_GEMM: return "svr::gemm_kernel";
+        case SVR_KERNEL_GEMM_PERSISTENT: return "svr::gemm_w4q_kernel";
+        case SVR_KERNEL_CONV_HALO: return "svr::conv_halo2_kernel";
+        case SVR_KERNEL_CONV_SUBPIXEL: return "svr::conv_sub_kernel";
+        case SVR_KERNEL_CONV_THIN_IN: return "svr::conv_halo2_kernel<8, 2> (thin input)";
+        case SVR_KERNEL_CONV_THIN_OUT: return "svr::conv_thinout_kernel";
+        case SVR_KERNEL_CONV_GENERIC: return "svr::gemm_kernel<..., CONV>";
+        default: return "invalid";
+    }
 }
 
 int32_t svr_gemm_gn_blocks(const svr_gemm_args* args) {
@@ -81,6 +104,7 @@ int32_t svr_gemm_gn_blocks(const svr_gemm_args* args) {
 }
 
 int svr_groupnorm_reduce(const void* partial, double* stats, int32_t T, int32_t nblk, int32_t groups, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (T <= 0 || nblk <= 0) return 0;
     if (groups <= 0 || groups > 65535) return fail("svr_groupnorm_reduce: 1..65535 groups");
     hipLaunchKernelGGL(groupnorm_reduce_kernel, dim3(T, groups), dim3(256), 0, (hipStream_t)stream,
@@ -90,6 +114,7 @@ int svr_groupnorm_reduce(const void* partial, double* stats, int32_t T, int32_t 
 
 int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps, const float* w, const float* scale,
                     const float* shift, int32_t x_f32, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (rows <= 0) return 0;
     if (dim % 8 || dim > 64 * 8 * 8) return fail("svr_rmsnorm_mod: dim must be a multiple of 8 and <= 4096");
     const unsigned grid = (unsigned)(rows < 4 * 2048 ? blocks_for(rows, 4) : 2048);      // 8 blocks per CU, rows strided
@@ -109,6 +134,7 @@ int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps
 
 int svr_ada_combine(const void* emb, const void* params, const int32_t* slot, float* out, int32_t n_vec, int32_t dim,
                     void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (n_vec <= 0) return 0;
     hipLaunchKernelGGL(ada_combine_kernel, dim3(blocks_for(dim, 256), n_vec), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)emb, (const bf16_t*)params, slot, out, n_vec, dim);
@@ -118,6 +144,7 @@ int svr_ada_combine(const void* emb, const void* params, const int32_t* slot, fl
 int svr_qknorm_rope(void* qkv, int64_t rows, int32_t heads, const int16_t* pos, int32_t t_offset, const float* cos_tab,
                     const float* sin_tab, int32_t n_pos, int32_t n_freq, const float* wq, const float* wk, float eps,
                     void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (rows <= 0) return 0;
     if (n_freq * 3 > 64) return fail("svr_qknorm_rope: at most 21 frequencies per axis (head_dim 128)");
     hipLaunchKernelGGL(qknorm_rope_kernel, dim3(blocks_for(rows * heads, 4)), dim3(256), 0, (hipStream_t)stream,
@@ -128,6 +155,7 @@ int svr_qknorm_rope(void* qkv, int64_t rows, int32_t heads, const int16_t* pos, 
 int svr_attn_varlen(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,
                     const int32_t* out_rows, const int32_t* cu, int32_t n_seq, int32_t max_len, int32_t heads,
                     int32_t head_dim, float scale, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     const char* why = nullptr;
     const int rc = attn_dispatch(qkv, ld_qkv, out, ld_out, seq_rows, out_rows, cu, n_seq, max_len, heads, head_dim,
                                  scale, (hipStream_t)stream, &why);
@@ -145,6 +173,7 @@ extern "C" int svr_debug_conv_epilogue(void* dst_host, int64_t bytes) {
 #endif
 
 int svr_conv_pack_frag_taps(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t kh, int32_t kw, int32_t Cin, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (N <= 0 || N % 32 || Cin <= 0 || Cin % 32 || kt < 1 || kt > 3 || kh < 1 || kh > 3 || kw < 1 || kw > 3 || K != kt * kh * kw * Cin)
         return fail("svr_conv_pack_frag_taps: need N % 32 == 0, Cin % 32 == 0, kt, kh, kw in 1..3, K == kt * kh * kw * Cin");
     const int64_t chunks = (int64_t)N * K / 8;
@@ -154,6 +183,7 @@ int svr_conv_pack_frag_taps(const void* W, void* out, int32_t N, int32_t K, int3
 }
 
 int svr_conv_pack_frag(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t Cin, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (N <= 0 || N % 32 || Cin <= 0 || Cin % 32 || kt < 1 || kt > 3 || K != kt * 9 * Cin)
         return fail("svr_conv_pack_frag: need N % 32 == 0, Cin % 32 == 0, kt in 1..3, K == kt * 9 * Cin");
     const int64_t chunks = (int64_t)N * K / 8;
@@ -164,6 +194,7 @@ int svr_conv_pack_frag(const void* W, void* out, int32_t N, int32_t K, int32_t k
 
 int svr_softmax_rows(const float* S, void* P, int64_t rows, int32_t cols, int64_t ld_s, int64_t ld_p, float scale,
                      void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (rows <= 0 || cols <= 0) return 0;
     if (cols % 4 || cols > 1024 * SM_MAXV * 4 || ld_s % 4 || ld_p % 4)
         return fail("svr_softmax_rows: cols must be a multiple of 4 and <= 65536, leading dimensions multiples of 4");
@@ -177,6 +208,7 @@ int svr_softmax_rows(const float* S, void* P, int64_t rows, int32_t cols, int64_
 }
 
 int svr_rows_mean(const void* src, void* dst, int32_t n_groups, int32_t rows_per_group, int32_t dim, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (n_groups <= 0 || rows_per_group <= 0) return 0;
     if (dim % 8) return fail("svr_rows_mean: dim must be a multiple of 8");
     hipLaunchKernelGGL(rows_mean_kernel, dim3(blocks_for(dim / 8, 64), rows_per_group), dim3(64), 0,
@@ -185,6 +217,7 @@ int svr_rows_mean(const void* src, void* dst, int32_t n_groups, int32_t rows_per
 }
 
 int svr_patchify(const void* in, void* out, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kpad, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if ((H & 1) || (W & 1) || kpad < 4 * C) return fail("svr_patchify: H, W must be even and kpad >= 4*C");
     const int64_t total = (int64_t)T * (H / 2) * (W / 2) * kpad;
     if (total <= 0) return 0;
@@ -195,6 +228,7 @@ int svr_patchify(const void* in, void* out, int32_t T, int32_t H, int32_t W, int
 
 int svr_unpatchify_euler(const void* pred, int64_t ldp, const void* x_t, void* out, int32_t T, int32_t H, int32_t W,
                          int32_t C, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if ((H & 1) || (W & 1)) return fail("svr_unpatchify_euler: H, W must be even");
     const int64_t total = (int64_t)T * H * W * C;
     if (total <= 0) return 0;
@@ -209,6 +243,7 @@ int64_t svr_groupnorm_workspace_bytes(int32_t T, int64_t HW, int32_t groups) {
 
 int svr_groupnorm_stats(const void* x, double* stats, void* workspace, int32_t T, int64_t HW, int32_t C, int32_t groups,
                         int32_t x_f32, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (T <= 0 || HW <= 0) return 0;
     if (C % 8 || C > 512 || groups > 32 || (C / groups) % 4 || (256 % (C / 8)))
         return fail("svr_groupnorm_stats: need C in {128,256,512}-like (C%8==0, C<=512, groups<=32, (C/groups)%4==0)");
@@ -223,6 +258,7 @@ int svr_groupnorm_stats(const void* x, double* stats, void* workspace, int32_t T
 
 int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float* gamma, const float* beta, int32_t T,
                         int64_t HW, int32_t C, int32_t groups, float eps, int32_t apply_silu, int32_t x_f32, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (T <= 0 || HW <= 0) return 0;
     if (C % 8 || C > 512) return fail("svr_groupnorm_apply: C must be a multiple of 8 and <= 512");
     const int64_t nchunks = HW * (C / 8);
@@ -236,6 +272,7 @@ int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float
 }
 
 int svr_im2col_causal(const void* in, void* out, const svr_conv_geom* g, int32_t kpad, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (!g) return fail("svr_im2col_causal: null geometry");
     if (g->Cin % 4 || kpad % g->Cin || kpad < g->kt * g->kh * g->kw * g->Cin)
         return fail("svr_im2col_causal: Cin % 4 == 0 and kpad a multiple of Cin covering all taps required");
@@ -248,6 +285,7 @@ int svr_im2col_causal(const void* in, void* out, const svr_conv_geom* g, int32_t
 
 int svr_blend_accumulate(const void* tile, float* acc, float* cnt, const float* wy, const float* wx, int32_t T,
                          int32_t h, int32_t w, int32_t C, int32_t H, int32_t W, int32_t y0, int32_t x0, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     const int64_t total = (int64_t)T * h * w * C;
     if (total <= 0) return 0;
     if (y0 < 0 || x0 < 0 || y0 + h > H || x0 + w > W) return fail("svr_blend_accumulate: tile outside the canvas");
@@ -258,6 +296,7 @@ int svr_blend_accumulate(const void* tile, float* acc, float* cnt, const float* 
 
 int svr_blend_finalize(const float* acc, const float* cnt, void* out, int32_t T, int64_t HW, int32_t C, int32_t c_take,
                        float scale, float shift, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     const int64_t total = (int64_t)T * HW * c_take;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(blend_finalize_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, acc, cnt,
@@ -267,6 +306,7 @@ int svr_blend_finalize(const float* acc, const float* cnt, void* out, int32_t T,
 
 int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int32_t c_out, float scale, float shift,
                      void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
     if (rows <= 0) return 0;
     if (c_out > c_in) return fail("svr_affine_slice: c_out > c_in");
     hipLaunchKernelGGL(affine_slice_kernel, dim3(blocks_for(rows * c_out, 256)), dim3(256), 0, (hipStream_t)stream,

@@ -92,6 +92,23 @@ static inline int set_max_dynamic_lds(const void* kern, int bytes, uint64_t& don
     return 0;
 }
 
+// Every entry point launches on the caller's stream; the per-device state above (function attributes, CU count) and the launch
+// itself belong to THAT stream's device, which need not be the thread's current one (a ComfyUI process with nodes pinned to
+// several cuda:N only switches devices when torch itself launches).  Entry points open one of these: a no-op read pair when
+// the devices agree, hipSetDevice there and back when they do not.
+struct StreamDeviceGuard {
+    int prev = -1;
+    explicit StreamDeviceGuard(void* stream) {
+        int cur = 0, dev = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return;
+        if (stream == nullptr || hipStreamGetDevice((hipStream_t)stream, &dev) != hipSuccess || dev == cur) return;
+        if (hipSetDevice(dev) == hipSuccess) prev = cur;
+    }
+    ~StreamDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    StreamDeviceGuard(const StreamDeviceGuard&) = delete;
+    StreamDeviceGuard& operator=(const StreamDeviceGuard&) = delete;
+};
+
 // Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier).  __syncthreads() also carries a memory fence, for
 // which hipcc waits vmcnt(0): between the passes of an LDS-staged epilogue that is a wait for the previous pass's global stores
 // (and for any residual loads already on their way) that nothing needs -- the stores only have to leave before the kernel ends.

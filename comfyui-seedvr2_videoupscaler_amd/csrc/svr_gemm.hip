@@ -645,7 +645,8 @@ SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, cha
             case SVR_EPI_RESID_GATE * 4 + 0: SVR_EPI_CASE(SVR_EPI_RESID_GATE, false, false); return;
             case SVR_EPI_RESID_GATE * 4 + 1: SVR_EPI_CASE(SVR_EPI_RESID_GATE, false, true); return;
             case SVR_EPI_RESID_GATE * 4 + 2: SVR_EPI_CASE(SVR_EPI_RESID_GATE, true, false); return;
-            default:                         SVR_EPI_CASE(SVR_EPI_RESID_GATE, true, true); return;
+            case SVR_EPI_RESID_GATE * 4 + 3: SVR_EPI_CASE(SVR_EPI_RESID_GATE, true, true); return;
+            default: return;                 // (unreachable: gemm_route() rejects unknown epilogue codes and a residual type without a residual)
         }
     }
     if constexpr (!PLAIN_ONLY) {
@@ -1655,16 +1656,23 @@ static bool gemm_w4_eligible(const svr_gemm_args& a) {
            (a.N % 256) == 0 && a.K >= 2 * BK &&
            (a.lda % 8) == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0 && gemm_epi_lds_aligned(a) &&
            (int64_t)a.lda * 2 * 255 < ((int64_t)1 << 31) && (int64_t)a.K * 2 * 255 < ((int64_t)1 << 31) &&
-           (int64_t)((a.M + 255) / 256) * (a.N / 256) >= 256;
+           (int64_t)((a.M + 255) / 256) * (a.N / 256) >= 256 &&
+           device_cu_count() >= 8;          // (the persistent grid is a multiple of the 8 XCDs: a smaller partition takes gemm_kernel)
 }
 
 // per-frame partial blocks of fused GroupNorm statistics for this problem (0: not produced)
 static int conv_gn_blocks(const svr_gemm_args& a);
 
-int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
+// Which kernel serves a problem: ONE decision, used by the launch below and reported through svr_gemm_kernel_class() (bench.py
+// attributes launch times to kernels with it; a second copy of these predicates in Python would drift).
+// -> SVR_KERNEL_* (include/seedvr2_hip.h), or -1 with *why set when the arguments are invalid.
+int gemm_route(const svr_gemm_args& a, const char** why) {
     *why = nullptr;
-    if (a.M <= 0 || a.N <= 0) return 0;
+    if (a.M <= 0 || a.N <= 0) return SVR_KERNEL_NONE;
     if (a.K <= 0 || (a.K % BK) != 0) { *why = "svr_gemm_bf16: K must be a positive multiple of 64"; return -1; }
+    if ((unsigned)a.epilogue > (unsigned)SVR_EPI_BIAS_GELU) { *why = "svr_gemm_bf16: unknown epilogue code"; return -1; }
+    if (a.resid && a.epilogue != SVR_EPI_RESID_GATE) { *why = "svr_gemm_bf16: resid needs SVR_EPI_RESID_GATE"; return -1; }
+    if (a.resid_f32 && !a.resid) { *why = "svr_gemm_bf16: resid_f32 without resid"; return -1; }
     if (a.conv.enabled) {
         const svr_conv_geom& g = a.conv;
         if (!conv_thin_eligible(a)) {       // (thin input: Cin = 4, K = taps * 4 zero-padded to 128)
@@ -1689,13 +1697,29 @@ int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
         }
     }
     if (a.gn_partial && conv_gn_blocks(a) == 0) { *why = "svr_gemm_bf16: gn_partial set but this launch cannot produce fused GroupNorm statistics"; return -1; }
-    if (conv_thin_eligible(a)) return launch_conv_thin(a, s);
-    if (conv_sub_eligible(a)) return launch_conv_sub(a, s);
-    if ((g_conv_impl == 0 || g_conv_impl == 3) && conv_halo2_eligible(a)) return launch_conv_halo2(a, s);
-    if (g_conv_impl != 1 && conv_halo_eligible(a) && a.N <= 32) return launch_conv_thinout(a, s);
-    // 256-wide tiles when N allows it (otherwise W is padded to a multiple of 128 rows) -- unless they would leave CUs idle:
-    // the VAE attention's P V product (16384 x 512 x 16384) has only 128 such tiles for 256 CUs
-    if (gemm_w4_eligible(a)) return launch_gemm_w4(a, s);
+    if (conv_thin_eligible(a)) return SVR_KERNEL_CONV_THIN_IN;
+    if (conv_sub_eligible(a)) return SVR_KERNEL_CONV_SUBPIXEL;
+    if ((g_conv_impl == 0 || g_conv_impl == 3) && conv_halo2_eligible(a)) return SVR_KERNEL_CONV_HALO;
+    if (g_conv_impl != 1 && conv_halo_eligible(a) && a.N <= 32) return SVR_KERNEL_CONV_THIN_OUT;
+    if (a.conv.enabled) return SVR_KERNEL_CONV_GENERIC;
+    if (gemm_w4_eligible(a)) return SVR_KERNEL_GEMM_PERSISTENT;
+    return SVR_KERNEL_GEMM;
+}
+
+int gemm_dispatch(const svr_gemm_args& a, hipStream_t s, const char** why) {
+    const int route = gemm_route(a, why);
+    if (route < 0) return -1;
+    switch (route) {
+        case SVR_KERNEL_NONE: return 0;
+        case SVR_KERNEL_CONV_THIN_IN: return launch_conv_thin(a, s);
+        case SVR_KERNEL_CONV_SUBPIXEL: return launch_conv_sub(a, s);
+        case SVR_KERNEL_CONV_HALO: return launch_conv_halo2(a, s);
+        case SVR_KERNEL_CONV_THIN_OUT: return launch_conv_thinout(a, s);
+        case SVR_KERNEL_GEMM_PERSISTENT: return launch_gemm_w4(a, s);
+        default: break;
+    }
+    // gemm_kernel: 256-wide tiles when N allows it (otherwise W is padded to a multiple of 128 rows) -- unless they would leave
+    // CUs idle: the VAE attention's P V product (16384 x 512 x 16384) has only 128 such tiles for 256 CUs
     const bool wide = (a.N % 256) == 0 &&
                       (int64_t)((a.M + 255) / 256) * (a.N / 256) >= (a.conv.enabled ? 0 : 256);
     if (gemm_epi_lds(a)) {

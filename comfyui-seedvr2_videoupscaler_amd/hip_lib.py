@@ -19,7 +19,10 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                "-mllvm", "-pragma-unroll-threshold=1000000"]
 
 EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU, EPI_BIAS_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 5
+ABI_VERSION = 6
+# svr_gemm_kernel_class() codes (include/seedvr2_hip.h)
+KERNEL_CLASSES = {0: "none", 1: "gemm", 2: "gemm_persistent", 3: "conv_halo", 4: "conv_subpixel", 5: "conv_thin_in",
+                  6: "conv_thinout", 7: "conv_generic"}
 
 
 class ConvGeom(C.Structure):
@@ -65,6 +68,8 @@ SYMBOLS = {
     "svr_conv_pack_frag": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "svr_conv_pack_frag_taps": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "svr_gemm_gn_blocks": (C.c_int32, [C.POINTER(GemmArgs)]),
+    "svr_gemm_kernel_class": (C.c_int32, [C.POINTER(GemmArgs)]),
+    "svr_gemm_kernel_name": (C.c_char_p, [_i32]),
     "svr_groupnorm_reduce": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "svr_rmsnorm_mod": (C.c_int, [_vp, _vp, _i64, _i32, _f, _vp, _vp, _vp, _i32, _vp]),
     "svr_ada_combine": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
@@ -99,9 +104,16 @@ def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] + [INCLUDE]
 
 
+def _extra_defines():
+    return ["-DSVR_ABLATIONS"] if os.environ.get("SVR_BUILD_ABLATIONS") else []   # measurement-only kernel variants
+
+
 def source_id() -> str:
-    """hex SHA-256 over the library's sources (names and contents, sorted by name): what svr_build_id() of a current build returns."""
+    """hex SHA-256 over the library's sources (names and contents, sorted by name) and its compile configuration (flags and
+    defines -- a -DSVR_ABLATIONS measurement build must not pass for the product build): what svr_build_id() of a current
+    build returns."""
     h = hashlib.sha256()
+    h.update("\0".join(HIPCC_FLAGS + _extra_defines()).encode() + b"\0")
     for path in sources():
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as f:
@@ -135,7 +147,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    extra = ["-DSVR_ABLATIONS"] if os.environ.get("SVR_BUILD_ABLATIONS") else []   # measurement-only kernel variants
+    extra = _extra_defines()
     cmd = [hipcc] + HIPCC_FLAGS + extra + [f'-DSVR_BUILD_ID="{source_id()}"', os.path.join(CSRC, "svr_api.hip"), "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -55,6 +55,80 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def fill_gemm_args(A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None, out_f32=False,
+                   conv: Optional[Conv3dGeom] = None, ps: Optional[PixelShuffleGeom] = None, lda=None, ldc=None, ldr=None,
+                   W_frag=None, phase: Optional[PhaseScatter] = None, zeros_ptr: int = 0, chk=None, ptr=None):
+    """svr_gemm_args for one ``gemm`` call (layout checks included).  ``chk(tensor, dtype, name)`` validates device / dtype /
+    contiguity (HipOps._chk), ``ptr(tensor)`` yields the device address -- both injectable so that tools and CPU tests can fill
+    the struct for shape-only (meta) tensors and ask the library which kernel would serve the call (svr_gemm_kernel_class)."""
+    chk = chk or (lambda t, dtype=None, name="tensor": t)
+    ptr = ptr or (lambda t: t.data_ptr())
+    chk(A, BF16, "A"); chk(W, BF16, "W")
+    chk(out, torch.float32 if out_f32 else BF16, "out")
+    if W.shape[1] != K or W.shape[0] < N or W.shape[0] % 128:
+        raise ValueError(f"packed weight shape {tuple(W.shape)} incompatible with N={N}, K={K}")
+    a = hip_lib.GemmArgs()
+    if conv is not None:
+        M = conv.To * conv.Ho * conv.Wo
+        g = a.conv
+        g.enabled = 1
+        g.T, g.H, g.W, g.Cin = conv.T, conv.H, conv.W, conv.Cin
+        g.To, g.Ho, g.Wo = conv.To, conv.Ho, conv.Wo
+        g.kt, g.kh, g.kw = conv.k
+        g.st, g.sh, g.sw = conv.stride
+        g.pt, g.ph, g.pw = conv.pad
+        if conv.halo is not None:
+            chk(conv.halo, BF16, "halo")
+            g.halo_frames = conv.halo.shape[0]
+            g.halo = ptr(conv.halo)
+        g.zeros = zeros_ptr
+        if A.numel() != conv.T * conv.H * conv.W * conv.Cin:
+            raise ValueError("conv input size mismatch")
+        lda = 0
+    else:
+        if M is None:
+            M = A.shape[0]
+        if lda is None:
+            lda = A.stride(0) if A.dim() == 2 else K
+    if phase is not None:
+        if conv is None or ps is not None or resid is not None:
+            raise ValueError("phase scatter: conv mode only, without pixel shuffle / residual; fused statistics through gn_shared")
+        if out.numel() < ((conv.To - 1) * phase.t_stride + 1) * 4 * conv.Ho * conv.Wo * N or not out.is_contiguous():
+            raise ValueError("phase scatter: out must be the dense [frames, 2*Ho, 2*Wo, N] tensor from the launch's first frame on")
+        a.phase.enabled, a.phase.py, a.phase.px, a.phase.t_stride = 1, int(phase.py), int(phase.px), int(phase.t_stride)
+        if phase.bias_border is not None:
+            if tuple(phase.bias_border.shape) != (3, N):
+                raise ValueError("phase scatter: bias_border must be [3, N]")
+            a.phase.bias_border = ptr(chk(phase.bias_border, torch.float32, "bias_border"))
+        ldc = 0
+    if ps is not None:
+        a.ps.enabled = 1
+        a.ps.F, a.ps.H, a.ps.W, a.ps.rz, a.ps.C = ps.F, ps.H, ps.W, ps.rz, ps.C
+        a.ps.drop_first = int(ps.drop_first)
+        ldc = 0
+    elif ldc is None:
+        ldc = out.stride(0) if out.dim() == 2 else (N // 2 if epilogue == EPI_SWIGLU else N)
+    a.A, a.lda, a.W, a.C, a.ldc = ptr(A), lda, ptr(W), ptr(out), ldc
+    a.M, a.N, a.K = M, N, K
+    if bias is not None:
+        a.bias = ptr(chk(bias, torch.float32, "bias"))
+    if gate is not None:
+        a.gate = ptr(chk(gate, torch.float32, "gate"))
+    if resid is not None:
+        if resid.dtype not in (BF16, torch.float32):
+            raise ValueError(f"resid must be bf16 or fp32, got {resid.dtype}")
+        chk(resid, None, "resid")
+        a.resid = ptr(resid)
+        a.resid_f32 = int(resid.dtype == torch.float32)
+        a.ldr = ldr if ldr is not None else (resid.stride(0) if resid.dim() == 2 else N)
+    a.epilogue, a.out_f32 = epilogue, int(out_f32)
+    if W_frag is not None:
+        if W_frag.numel() < N * K:
+            raise ValueError(f"W_frag holds {W_frag.numel()} elements, the problem needs N * K = {N * K}")
+        a.W_frag = ptr(chk(W_frag, BF16, "W_frag"))
+    return a, M
+
+
 class HipOps:
     """The product backend.  One instance per device."""
 
@@ -73,6 +147,7 @@ class HipOps:
             if rc != 0:
                 raise hip_lib.HipLibraryError(f"unsupported device: {self.device_info}")
         self.zeros = torch.zeros(64, dtype=torch.uint8, device=self.device)
+        self.record_kernel_class, self.last_kernel_class = False, None
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -120,69 +195,11 @@ class HipOps:
         ``gn_shared`` (with ``gn_groups``): several launches write ONE output tensor (the phases of a sub-pixel upsampler); the
         caller passes the same dict {"frames": output frames, "frame0": first output frame of this launch} to each of them and
         calls gn_shared_stats() after the last -- the launches then return ``out`` only."""
-        self._chk(A, BF16, "A"); self._chk(W, BF16, "W")
-        self._chk(out, torch.float32 if out_f32 else BF16, "out")
-        if W.shape[1] != K or W.shape[0] < N or W.shape[0] % 128:
-            raise ValueError(f"packed weight shape {tuple(W.shape)} incompatible with N={N}, K={K}")
-        a = hip_lib.GemmArgs()
-        if conv is not None:
-            M = conv.To * conv.Ho * conv.Wo
-            g = a.conv
-            g.enabled = 1
-            g.T, g.H, g.W, g.Cin = conv.T, conv.H, conv.W, conv.Cin
-            g.To, g.Ho, g.Wo = conv.To, conv.Ho, conv.Wo
-            g.kt, g.kh, g.kw = conv.k
-            g.st, g.sh, g.sw = conv.stride
-            g.pt, g.ph, g.pw = conv.pad
-            if conv.halo is not None:
-                self._chk(conv.halo, BF16, "halo")
-                g.halo_frames = conv.halo.shape[0]
-                g.halo = conv.halo.data_ptr()
-            g.zeros = self.zeros.data_ptr()
-            if A.numel() != conv.T * conv.H * conv.W * conv.Cin:
-                raise ValueError("conv input size mismatch")
-            lda = 0
-        else:
-            if M is None:
-                M = A.shape[0]
-            if lda is None:
-                lda = A.stride(0) if A.dim() == 2 else K
-        if phase is not None:
-            if conv is None or ps is not None or resid is not None or (gn_groups and gn_shared is None):
-                raise ValueError("phase scatter: conv mode only, without pixel shuffle / residual; fused statistics through gn_shared")
-            if out.numel() < ((conv.To - 1) * phase.t_stride + 1) * 4 * conv.Ho * conv.Wo * N or not out.is_contiguous():
-                raise ValueError("phase scatter: out must be the dense [frames, 2*Ho, 2*Wo, N] tensor from the launch's first frame on")
-            a.phase.enabled, a.phase.py, a.phase.px, a.phase.t_stride = 1, int(phase.py), int(phase.px), int(phase.t_stride)
-            if phase.bias_border is not None:
-                if tuple(phase.bias_border.shape) != (3, N):
-                    raise ValueError("phase scatter: bias_border must be [3, N]")
-                a.phase.bias_border = self._chk(phase.bias_border, torch.float32, "bias_border").data_ptr()
-            ldc = 0
-        if ps is not None:
-            a.ps.enabled = 1
-            a.ps.F, a.ps.H, a.ps.W, a.ps.rz, a.ps.C = ps.F, ps.H, ps.W, ps.rz, ps.C
-            a.ps.drop_first = int(ps.drop_first)
-            ldc = 0
-        elif ldc is None:
-            ldc = out.stride(0) if out.dim() == 2 else (N // 2 if epilogue == EPI_SWIGLU else N)
-        a.A, a.lda, a.W, a.C, a.ldc = A.data_ptr(), lda, W.data_ptr(), out.data_ptr(), ldc
-        a.M, a.N, a.K = M, N, K
-        if bias is not None:
-            a.bias = self._chk(bias, torch.float32, "bias").data_ptr()
-        if gate is not None:
-            a.gate = self._chk(gate, torch.float32, "gate").data_ptr()
-        if resid is not None:
-            if resid.dtype not in (BF16, torch.float32):
-                raise ValueError(f"resid must be bf16 or fp32, got {resid.dtype}")
-            self._chk(resid, None, "resid")
-            a.resid = resid.data_ptr()
-            a.resid_f32 = int(resid.dtype == torch.float32)
-            a.ldr = ldr if ldr is not None else (resid.stride(0) if resid.dim() == 2 else N)
-        a.epilogue, a.out_f32 = epilogue, int(out_f32)
-        if W_frag is not None:
-            if W_frag.numel() < N * K:
-                raise ValueError(f"W_frag holds {W_frag.numel()} elements, the problem needs N * K = {N * K}")
-            a.W_frag = self._chk(W_frag, BF16, "W_frag").data_ptr()
+        if phase is not None and gn_groups and gn_shared is None:
+            raise ValueError("phase scatter: fused statistics through gn_shared")
+        a, M = fill_gemm_args(A, W, out, N=N, K=K, M=M, bias=bias, epilogue=epilogue, gate=gate, resid=resid, out_f32=out_f32,
+                              conv=conv, ps=ps, lda=lda, ldc=ldc, ldr=ldr, W_frag=W_frag, phase=phase,
+                              zeros_ptr=self.zeros.data_ptr(), chk=self._chk)
         stats = None
         if gn_groups > 0 and conv is not None:
             a.gn_groups = gn_groups
@@ -204,6 +221,8 @@ class HipOps:
                 stats = torch.empty(conv.To, gn_groups, 2, dtype=torch.float64, device=self.device)
             else:
                 a.gn_groups = 0
+        if self.record_kernel_class:                      # (bench.py: which kernel does the library pick for this launch)
+            self.last_kernel_class = hip_lib.KERNEL_CLASSES.get(int(self.lib.svr_gemm_kernel_class(C.byref(a))), "invalid")
         hip_lib.check(self.lib.svr_gemm_bf16(C.byref(a), self._stream()), "svr_gemm_bf16")
         if gn_groups > 0 and gn_shared is None:
             if stats is not None:

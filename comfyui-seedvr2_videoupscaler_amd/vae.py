@@ -119,8 +119,13 @@ def _cos_ramp(n: int) -> Optional[torch.Tensor]:
 class VideoVAEEngine:
     def __init__(self, cfg: VAEConfig, state_dict: Dict[str, torch.Tensor], ops,
                  act_budget_bytes: int = 12 << 30, merge_upsamplers: bool = True, merge_causal_head: bool = True,
-                 trunk_fp32: bool = True, branch_fp32: bool = False):
-        """``merge_upsamplers``: run the spatial-only upsampler (upscale_conv + pixel shuffle + 3x3x3 conv) as four sub-pixel
+                 trunk_fp32: bool = True, branch_fp32: bool = False, tile_streams: int = 2):
+        """``tile_streams``: spatial tiles of a tiled encode / decode are independent until the blend (attn_video_vae.py:1302-1630),
+        so on the GPU they are issued round-robin onto this many HIP streams: the HBM-bound passes of one tile (GroupNorm apply,
+        statistics, layout copies) and its under-filled low-resolution launches run in the shadow of another tile's MFMA-bound
+        convolutions -- the conv kernel holds one wave per SIMD, so a second kernel's waves fit beside it.  The blends are issued
+        on the caller's stream in tile order, so the result is bit-identical to ``tile_streams=1`` (_run_tiles).
+        ``merge_upsamplers``: run the spatial-only upsampler (upscale_conv + pixel shuffle + 3x3x3 conv) as four sub-pixel
         convs over its low-resolution input (subpixel.py) -- same function, 12 instead of 28 MACs per output voxel and channel
         pair, no upsampled intermediate; False keeps the reference's two steps.
         ``merge_causal_head``: output frame 0 of a clip sees the replicated first frame under all three temporal taps
@@ -142,6 +147,9 @@ class VideoVAEEngine:
         self.branch_wide = bool(trunk_fp32 and branch_fp32)
         self.device = ops.device
         self.act_budget_bytes = act_budget_bytes
+        self.tile_streams = int(tile_streams)
+        self._streams = []
+        self._edges = {}
         sd, dev = state_dict, ops.device
         ch = cfg.block_out_channels
         n = len(ch)
@@ -610,6 +618,49 @@ class VideoVAEEngine:
             outs.append(self._decoder_slice(z_thwc[a:b], st, i == 0))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
+    # ------------------------------------------------------------------ tile-level concurrency
+    def _edge_dev(self, length: int, ov: int, fade_lo: bool, fade_hi: bool) -> torch.Tensor:
+        """Blend weights of a tile edge on the device, cached per (length, overlap, faded sides): a host -> device copy of pageable
+        memory inside the tile loop would block the host until the stream it is issued on has drained, which serialises the tiles
+        (callers warm the cache before _run_tiles)."""
+        key = (length, ov, fade_lo, fade_hi)
+        w = self._edges.get(key)
+        if w is None:
+            w = self._edges[key] = _edge_weights(length, ov, fade_lo, fade_hi, _cos_ramp(ov)).to(self.device)
+        return w
+
+    def _run_tiles(self, jobs, compute, blend):
+        """``compute(job)`` -> the tile's result (any number of launches on the CURRENT stream); ``blend(job, result)``
+        accumulates it into the shared output.  Sequential on one stream when ``tile_streams`` <= 1 (and always on the CPU
+        double of the C ABI).  Otherwise tile i is issued on side stream i mod n -- which first waits for everything the
+        caller's stream has produced so far -- and its blend on the caller's stream behind the tile's completion event, in tile
+        order: same launches with the same operands, same accumulation order, so the same bits.  The host never blocks; at most n
+        tiles' activations are in flight (each side stream owns its allocator pool: 288 GB of HBM)."""
+        n = min(self.tile_streams, len(jobs)) if self.device.type == "cuda" else 1
+        if n <= 1:
+            for job in jobs:
+                blend(job, compute(job))
+            return
+        main = torch.cuda.current_stream(self.device)
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for i, job in enumerate(jobs):
+            side = self._streams[i % n]
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                result = compute(job)
+                done = torch.cuda.Event()
+                done.record(side)
+            main.wait_event(done)
+            blend(job, result)
+            result.record_stream(main)              # (allocated on the side stream, last read by the blend on the caller's)
+        for side in self._streams[:n]:              # the caller may free / overwrite the inputs once ITS stream is done
+            done = torch.cuda.Event()
+            done.record(side)
+            main.wait_event(done)
+
     # ------------------------------------------------------------------ public API (runner level)
     def _to_thwc4(self, x_cthw: torch.Tensor) -> torch.Tensor:
         Cc, T, H, W = x_cthw.shape
@@ -635,22 +686,31 @@ class VideoVAEEngine:
         loh = max(0, min(tile_overlap[0] // s, lth - 1))
         low = max(0, min(tile_overlap[1] // s, ltw - 1))
         Hl, Wl = (H + s - 1) // s, (W + s - 1) // s
-        rh, rw = _cos_ramp(loh), _cos_ramp(low)
-        acc = cnt = None
-        for (y0, y1) in _tile_ranges(Hl, lth, loh):
-            for (x0, x1) in _tile_ranges(Wl, ltw, low):
-                tile = x[:, y0 * s:min(y1 * s, H), x0 * s:min(x1 * s, W)].contiguous()
-                enc = self.encode_clip(tile, frames_per_slice)
-                if acc is None:
-                    acc = torch.zeros(enc.shape[0], Hl, Wl, enc.shape[3], dtype=torch.float32, device=self.device)
-                    cnt = torch.zeros(Hl, Wl, dtype=torch.float32, device=self.device)
-                eh = min(y1 - y0, enc.shape[1], Hl - y0)
-                ew = min(x1 - x0, enc.shape[2], Wl - x0)
-                if (eh, ew) != (enc.shape[1], enc.shape[2]):
-                    enc = enc[:, :eh, :ew].contiguous()
-                wy = _edge_weights(eh, loh, y0 > 0, y1 < Hl, rh).to(self.device)
-                wx = _edge_weights(ew, low, x0 > 0, x1 < Wl, rw).to(self.device)
-                ops.blend_accumulate(enc, acc, cnt, wy, wx, y0, x0)
+        buf = {}
+        jobs = [(y0, y1, x0, x1) for (y0, y1) in _tile_ranges(Hl, lth, loh) for (x0, x1) in _tile_ranges(Wl, ltw, low)]
+
+        def compute(job):
+            y0, y1, x0, x1 = job
+            tile = x[:, y0 * s:min(y1 * s, H), x0 * s:min(x1 * s, W)].contiguous()
+            enc = self.encode_clip(tile, frames_per_slice)
+            eh = min(y1 - y0, enc.shape[1], Hl - y0)
+            ew = min(x1 - x0, enc.shape[2], Wl - x0)
+            return enc if (eh, ew) == (enc.shape[1], enc.shape[2]) else enc[:, :eh, :ew].contiguous()
+
+        def blend(job, enc):
+            y0, y1, x0, x1 = job
+            if not buf:
+                buf["acc"] = torch.zeros(enc.shape[0], Hl, Wl, enc.shape[3], dtype=torch.float32, device=self.device)
+                buf["cnt"] = torch.zeros(Hl, Wl, dtype=torch.float32, device=self.device)
+            wy = self._edge_dev(enc.shape[1], loh, y0 > 0, y1 < Hl)
+            wx = self._edge_dev(enc.shape[2], low, x0 > 0, x1 < Wl)
+            ops.blend_accumulate(enc, buf["acc"], buf["cnt"], wy, wx, y0, x0)
+
+        for (y0, y1, x0, x1) in jobs:                    # warm the weight cache (expected tile extents) before any tile is issued
+            self._edge_dev(min(y1 - y0, Hl - y0), loh, y0 > 0, y1 < Hl)
+            self._edge_dev(min(x1 - x0, Wl - x0), low, x0 > 0, x1 < Wl)
+        self._run_tiles(jobs, compute, blend)
+        acc, cnt = buf["acc"], buf["cnt"]
         out = ops.empty(acc.shape[0], Hl, Wl, lc)
         return ops.blend_finalize(acc, cnt, out, cfg.scaling_factor, cfg.shifting_factor)
 
@@ -680,18 +740,27 @@ class VideoVAEEngine:
             oh, ow = tile_overlap
             loh = max(0, min(oh // s, lth - 1))
             low = max(0, min(ow // s, ltw - 1))
-            rh, rw = _cos_ramp(oh), _cos_ramp(ow)          # decode ramps live in output pixels
-            acc = cnt = None
-            for (y0, y1) in _tile_ranges(H, lth, loh):
-                for (x0, x1) in _tile_ranges(W, ltw, low):
-                    dec = self.decode_clip(z[:, y0:y1, x0:x1].contiguous(), latents_per_slice, keep_frames)
-                    if acc is None:
-                        acc = torch.zeros(dec.shape[0], H * s, W * s, dec.shape[3], dtype=torch.float32, device=self.device)
-                        cnt = torch.zeros(H * s, W * s, dtype=torch.float32, device=self.device)
-                    ho, wo = (y1 - y0) * s, (x1 - x0) * s
-                    wy = _edge_weights(ho, oh, y0 > 0, y1 < H, rh).to(self.device)
-                    wx = _edge_weights(wo, ow, x0 > 0, x1 < W, rw).to(self.device)
-                    ops.blend_accumulate(dec, acc, cnt, wy, wx, y0 * s, x0 * s)
+            buf = {}
+            jobs = [(y0, y1, x0, x1) for (y0, y1) in _tile_ranges(H, lth, loh) for (x0, x1) in _tile_ranges(W, ltw, low)]
+
+            def compute(job):
+                y0, y1, x0, x1 = job
+                return self.decode_clip(z[:, y0:y1, x0:x1].contiguous(), latents_per_slice, keep_frames)
+
+            def blend(job, dec):
+                y0, y1, x0, x1 = job
+                if not buf:
+                    buf["acc"] = torch.zeros(dec.shape[0], H * s, W * s, dec.shape[3], dtype=torch.float32, device=self.device)
+                    buf["cnt"] = torch.zeros(H * s, W * s, dtype=torch.float32, device=self.device)
+                ho, wo = (y1 - y0) * s, (x1 - x0) * s
+                ops.blend_accumulate(dec, buf["acc"], buf["cnt"], self._edge_dev(ho, oh, y0 > 0, y1 < H),
+                                     self._edge_dev(wo, ow, x0 > 0, x1 < W), y0 * s, x0 * s)
+
+            for (y0, y1, x0, x1) in jobs:                # warm the weight cache before any tile is issued
+                self._edge_dev((y1 - y0) * s, oh, y0 > 0, y1 < H)
+                self._edge_dev((x1 - x0) * s, ow, x0 > 0, x1 < W)
+            self._run_tiles(jobs, compute, blend)
+            acc, cnt = buf["acc"], buf["cnt"]
             y = ops.empty(*acc.shape)
             ops.blend_finalize(acc, cnt, y, 1.0, 0.0)
         y = y.permute(3, 0, 1, 2)                           # layout only: [3, T, H, W]

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SVR_ABI_VERSION 5
+#define SVR_ABI_VERSION 6
 
 /* ---- GEMM / implicit-GEMM convolution epilogues ------------------------------------------ */
 #define SVR_EPI_BIAS        0   /* C = acc + bias                                              */
@@ -112,6 +112,20 @@ int svr_conv_pack_frag_taps(const void* W, void* out, int32_t N, int32_t K, int3
 /* Number of per-frame partial blocks the launch described by `args` will write to args->gn_partial
  * (0: the kernel that serves this problem does not produce fused statistics -- use svr_groupnorm_stats). */
 int32_t svr_gemm_gn_blocks(const svr_gemm_args* args);
+
+/* Which kernel svr_gemm_bf16 would launch for `args` (no launch, no GPU needed): one of SVR_KERNEL_*, or -1 with
+ * svr_last_error() set when svr_gemm_bf16 would refuse the arguments.  ABI v6.  bench.py attributes launch times to kernels
+ * with it (the `roofline` object is the SVR_KERNEL_CONV_HALO launches only), tests pin it on the shapes a VAE tile issues. */
+#define SVR_KERNEL_NONE            0   /* empty problem: nothing is launched                                           */
+#define SVR_KERNEL_GEMM            1   /* gemm_kernel (eight waves, 256x256 / 256x128 tiles)                           */
+#define SVR_KERNEL_GEMM_PERSISTENT 2   /* gemm_w4q_kernel (persistent four-wave workgroups, the NaDiT's big GEMMs)     */
+#define SVR_KERNEL_CONV_HALO       3   /* conv_halo2_kernel: stride-1 3x3 spatial taps, LDS halo (the dominant kernel) */
+#define SVR_KERNEL_CONV_SUBPIXEL   4   /* conv_sub_kernel: (kt, 2, 2)-tap phases of the sub-pixel upsamplers           */
+#define SVR_KERNEL_CONV_THIN_IN    5   /* conv_halo2_kernel<8, thin>: Cin = 4 (encoder.conv_in)                        */
+#define SVR_KERNEL_CONV_THIN_OUT   6   /* conv_thinout_kernel: Cout <= 32 (conv_out)                                   */
+#define SVR_KERNEL_CONV_GENERIC    7   /* gemm_kernel in conv mode: strided / 1x1x1 / everything else                  */
+int32_t svr_gemm_kernel_class(const svr_gemm_args* args);
+const char* svr_gemm_kernel_name(int32_t kernel_class);
 
 /* nn.Linear / F.conv3d replacement (MFMA bf16, fp32 accumulate).
  * Replaces: every nn.Linear in src/models/dit_3b (mmattn.py:173,269; mlp.py:60-61; patch_v1.py:96,113;
@@ -214,7 +228,8 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
 int svr_set_option(const char* key, int32_t value);
 const char* svr_last_error(void);
 int svr_abi_version(void);
-/* hex SHA-256 of the sources (every .hip and .h file under csrc/ and this header; sorted by name) this binary was compiled from, as passed by the
+/* hex SHA-256 of the sources (every .hip and .h file under csrc/ and this header; sorted by name) AND the compile configuration (hipcc flags
+ * and -D defines: a measurement build is not the product build) this binary was compiled from, as passed by the
  * build (-DSVR_BUILD_ID=...); "unknown" if the build did not pass one.  The Python loader refuses a library whose id differs
  * from the sources next to it (a stale binary shipped with newer sources). */
 const char* svr_build_id(void);

@@ -30,8 +30,8 @@ def test_library_builds_loads_and_exports_header_symbols():
         assert hasattr(lib, name), f"{name} declared in seedvr2_hip.h but not exported"
     assert sorted(hip_lib.SYMBOLS) == declared, "ctypes table and header disagree"
     lib.svr_abi_version.restype = ctypes.c_int
-    assert lib.svr_abi_version() == hip_lib.ABI_VERSION == 5
-    assert hip_lib.lib().svr_abi_version() == 5
+    assert lib.svr_abi_version() == hip_lib.ABI_VERSION == 6
+    assert hip_lib.lib().svr_abi_version() == 6
     # the binary carries the content hash of the sources it was compiled from; the loader refuses any other
     assert hip_lib.built_id() == hip_lib.source_id() and not hip_lib.needs_build()
 
@@ -94,3 +94,83 @@ def test_loader_refuses_a_binary_built_from_other_sources(tmp_path, monkeypatch)
     monkeypatch.setattr(hip_lib, "_lib", None)
     with pytest.raises(hip_lib.HipLibraryError, match="other sources"):
         hip_lib.lib()
+
+
+def test_build_id_covers_the_compile_configuration(monkeypatch):
+    """A measurement build (-DSVR_ABLATIONS: kernel variants that give garbage on purpose) compiled from the same sources must not
+    pass for the product build: the id hashes flags and defines too."""
+    hip_lib = sub("hip_lib")
+    monkeypatch.delenv("SVR_BUILD_ABLATIONS", raising=False)
+    product = hip_lib.source_id()
+    monkeypatch.setenv("SVR_BUILD_ABLATIONS", "1")
+    assert hip_lib.source_id() != product
+    monkeypatch.delenv("SVR_BUILD_ABLATIONS")
+    monkeypatch.setattr(hip_lib, "HIPCC_FLAGS", hip_lib.HIPCC_FLAGS + ["-O1"])
+    assert hip_lib.source_id() != product
+
+
+@pytest.mark.skipif(not HAVE_HIPCC, reason="hipcc not available")
+def test_kernel_classifier_on_the_launches_a_vae_tile_issues():
+    """bench.py attributes launch times to kernels with svr_gemm_kernel_class() -- the routing function the launch itself uses
+    (csrc/svr_gemm.hip gemm_route), so the two cannot disagree.  Here the engine's host code runs over shape-only tensors
+    (tools/shape_census.py) and every gemm call of one 1024-px tile, encode and decode, is classified by the library:
+    stride-1 3x3 convs -> the LDS-halo kernel (the `roofline` kernel) and NOTHING else lands in that class."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import shape_census
+    sub("hip_lib").build()
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    cfg = config.VAE_V3
+    eng_ops = shape_census.MetaOps(classify=True)
+    eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg, device="meta"), eng_ops)
+    eng.decode_clip(torch.empty(3, 128, 128, cfg.latent_channels, dtype=torch.bfloat16, device="meta"))
+    eng.encode_clip(torch.empty(9, 1024, 1024, 4, dtype=torch.bfloat16, device="meta"))
+    seen = {}
+    for cls, g, M, N, K in eng_ops.launches:
+        assert cls != "invalid"
+        seen[cls] = seen.get(cls, 0) + 1
+        if g is None:
+            assert cls in ("gemm", "gemm_persistent")
+            continue
+        same = tuple(g.stride) == (1, 1, 1) and g.Ho == g.H and g.Wo == g.W
+        if cls == "conv_halo":
+            assert g.k[1:] == (3, 3) and same and g.Cin % 64 == 0 and N % 128 == 0
+        elif cls == "conv_subpixel":
+            assert g.k[1:] == (2, 2) and same
+        elif cls == "conv_thin_in":
+            assert g.Cin == 4 and N == 128
+        elif cls == "conv_thinout":
+            assert g.k[1:] == (3, 3) and same and N <= 32
+        else:
+            assert cls == "conv_generic" and (not same or g.k[1:] == (1, 1) or g.Cin % 64 != 0), (g, N)
+        if g.k[1:] == (3, 3) and same and g.Cin % 64 == 0 and N % 128 == 0:
+            assert cls == "conv_halo"
+    assert {"conv_halo", "conv_subpixel", "conv_thin_in", "conv_thinout", "conv_generic", "gemm"} <= set(seen), seen
+    # the NaDiT's big plain GEMMs go to the persistent kernel; invalid arguments are refused with a message, not launched
+    import ctypes
+    ops_mod, hip_lib = sub("ops"), sub("hip_lib")
+    L = hip_lib.lib()
+    meta = lambda *s_, dt=torch.bfloat16: torch.empty(*s_, dtype=dt, device="meta")
+    fill = lambda **kw: ops_mod.fill_gemm_args(meta(291600, 2560), meta(7680, 2560), meta(291600, 7680), N=7680, K=2560,
+                                               ptr=lambda t: 0x100000, **kw)[0]
+    assert hip_lib.KERNEL_CLASSES[L.svr_gemm_kernel_class(ctypes.byref(fill()))] == "gemm_persistent"
+    a = fill()
+    a.epilogue = 9
+    assert L.svr_gemm_kernel_class(ctypes.byref(a)) == -1 and b"unknown epilogue" in L.svr_last_error()
+    a = fill(resid=meta(291600, 7680, dt=torch.float32))                  # a residual without the residual epilogue
+    assert L.svr_gemm_kernel_class(ctypes.byref(a)) == -1 and b"RESID_GATE" in L.svr_last_error()
+
+
+def test_product_package_never_touches_the_oracle():
+    """oracle/ (incl. the byte-compiled reference under oracle/_ref) is test infrastructure: nothing in the product package or
+    the CLI may import, open or execute it -- only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do."""
+    pkg = os.path.join(ROOT, "comfyui-seedvr2_videoupscaler_amd")
+    files = [os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith(".py")] + [os.path.join(ROOT, "inference_cli.py")]
+    files += [os.path.join(pkg, "csrc", f) for f in os.listdir(os.path.join(pkg, "csrc")) if f.endswith((".hip", ".h"))]
+    for path in files:
+        src = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
+        assert "oracle/_ref" not in src and "_ref" + os.sep not in src and "reference_loader" not in src, path
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle import", bench)]
+    assert len(uses) == 1 and bench.rfind("def cpu_baseline", 0, uses[0]) > bench.rfind("\ndef ", 0, bench.rfind("def cpu_baseline", 0, uses[0]))

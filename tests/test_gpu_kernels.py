@@ -964,3 +964,42 @@ def test_vae_attention_gemm_path_matches_fused_kernel(hip, T, H, W):
         err = (t - want).abs()
         assert err.max() < 0.08 and err.mean() < 6e-3, (name_, float(err.max()), float(err.mean()))
     assert (got - fused).abs().max() < 0.08
+
+
+def test_vae_attention_at_config2_shape_512_channels_65536_tokens(hip):
+    """BASELINE config 2's untiled 2048x2048 frames put 256 x 256 = 65536 tokens of 512 channels through the mid-block attention
+    (attn_video_vae.py:615-665: one head, d = 512, softmax rows of 65536 columns): the engine runs it as four blocks of 16384 query
+    rows of Q K^T GEMM (fp32 scores) -> svr_softmax_rows -> P V GEMM (vae.py::_attention).  Checked at exactly that shape against a
+    blocked fp32 torch restatement on the device, and against the fused d = 512 kernel."""
+    from conftest import sub
+    vae_mod, weights, config = sub("vae"), sub("weights"), sub("config")
+    cfg = config.VAE_V3
+    sd = weights.synth_vae_state_dict(cfg, seed=3)
+    eng = vae_mod.VideoVAEEngine(cfg, sd, hip)
+    ab = eng.dec_mid[1]
+    C, H, W = 512, 256, 256
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = (torch.randn(1, H, W, C, device="cuda", generator=g) * 0.7).bfloat16()
+    assert eng.attn_as_gemm
+    got = eng._attention(ab, x).float()
+    name = "decoder.mid_block.attentions.0"
+    w = {k: sd[f"{name}.{k}"].float().cuda() for k in
+         ("group_norm.weight", "group_norm.bias", "to_q.weight", "to_q.bias", "to_k.weight", "to_k.bias",
+          "to_v.weight", "to_v.bias", "to_out.0.weight", "to_out.0.bias")}
+    xf = x.float()
+    y = torch.nn.functional.group_norm(xf.permute(0, 3, 1, 2), 32, w["group_norm.weight"], w["group_norm.bias"], 1e-6)
+    y = y.permute(0, 2, 3, 1).reshape(-1, C)
+    q, k, v = (y @ w[f"to_{c}.weight"].T + w[f"to_{c}.bias"] for c in "qkv")
+    o = torch.empty_like(q)
+    for r0 in range(0, q.shape[0], 8192):                              # 8192 x 65536 fp32 scores = 2 GiB per block
+        o[r0:r0 + 8192] = torch.softmax(q[r0:r0 + 8192] @ k.T / C ** 0.5, -1) @ v
+    want = (o @ w["to_out.0.weight"].T + w["to_out.0.bias"]).reshape(xf.shape) + xf
+    err = (got - want).abs()
+    e = float((got - want).norm() / want.norm())
+    print(f"VAE mid-block attention, 512 channels x 65536 tokens (config 2): rel-err {e:.3e}, max abs {float(err.max()):.3e}")
+    assert e < 4e-3 and err.max() < 0.08
+    eng.attn_as_gemm = False
+    fused = eng._attention(ab, x).float()
+    ef = float((fused - want).norm() / want.norm())
+    print(f"  fused d = 512 kernel at the same shape: rel-err {ef:.3e}")
+    assert ef < 4e-3 and (got - fused).abs().max() < 0.08

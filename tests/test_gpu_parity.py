@@ -309,6 +309,28 @@ def test_vae_temporal_slicing_invariance(hip):
     assert a.shape == (3, 13, 64, 64) and torch.equal(a, b), rel_err(b.float(), a.float())
 
 
+def test_vae_tile_streams_are_bit_invisible(hip):
+    """Spatial tiles issued round-robin on 2 or 3 HIP streams (VideoVAEEngine(tile_streams=), vae.py::_run_tiles) against every
+    launch on one stream: same launches, same blend order -> the same bits, encode and decode, also when the run is repeated
+    (a race between a tile's launches and another tile's allocations would show up as a flipped value somewhere)."""
+    from oracle import make_golden as mg
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    cfg = config.VAE_V3
+    sd = weights.synth_vae_state_dict(cfg)
+    kw = dict(tiled=True, tile_size=(64, 64), tile_overlap=(16, 16))
+    x = mg.blocky_frames(9, 160, 224, seed=51, cell=8)[0].cuda()                     # 3 x 4 tiles of 64 px (stride 48)
+    z = (mg.latent_input(3, 20, 28, seed=52)[0].permute(1, 2, 3, 0).float() * cfg.scaling_factor).to(BF16).cuda()
+    ref_eng = vae.VideoVAEEngine(cfg, sd, hip, tile_streams=1)
+    lat1, dec1 = ref_eng.encode(x, **kw), ref_eng.decode(z, **kw)
+    for n in (2, 3):
+        eng = vae.VideoVAEEngine(cfg, sd, hip, tile_streams=n)
+        for rep in range(2):
+            assert torch.equal(eng.encode(x, **kw), lat1), (n, rep)
+            assert torch.equal(eng.decode(z, **kw), dec1), (n, rep)
+            assert torch.equal(eng.decode(z, keep_frames=6, **kw), dec1[:, :6]), (n, rep)
+    torch.cuda.synchronize()
+
+
 def test_vae_decode_keep_frames_bit_exact(hip):
     """VideoVAEEngine.decode(keep_frames=n) -- what pipeline.upscale asks for by default so that the 4n+1 / uniform-batch padding it
     trims is never decoded -- equals the first n frames of the full decode BIT FOR BIT on the HIP path: untiled, forced one-latent

@@ -21,6 +21,25 @@ for path in sorted(glob.glob(prefix + "*/**/*counter_collection.csv", recursive=
             a = agg[name][row["Counter_Name"]]
             a[0] += float(row["Counter_Value"])
             a[1] += 1
+# per-kernel mean duration in the pass that collected GRBM_GUI_ACTIVE (the kernel trace of the same run): effective shader clock
+dur = defaultdict(lambda: [0.0, 0])
+for path in sorted(glob.glob(prefix + "*/**/*counter_collection.csv", recursive=True)):
+    with open(path, newline="") as f:
+        if "GRBM_GUI_ACTIVE" not in f.read():
+            continue
+    for tr in glob.glob(path.rsplit("/", 1)[0] + "/*kernel_trace.csv"):
+        with open(tr, newline="") as f:
+            for row in csv.DictReader(f):
+                name = row.get("Kernel_Name") or "?"
+                if "svr::" not in name:
+                    continue
+                name = re.sub(r"\(.*", "", name).replace("void ", "")
+                try:
+                    d = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                except (KeyError, ValueError):
+                    continue
+                dur[name][0] += d
+                dur[name][1] += 1
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC / SQ passes (separate, --kernel-trace only) -- python bench.py "
                  f"--workload {workload} --steps 1 --warmup 0 --no-cpu-baseline; tools/gpu_pmc_bench.sh",
        "corrections": "bytes = FETCH_SIZE*1024*2 (gfx950 wide-read under-count) + WRITE_SIZE*1024",
@@ -42,6 +61,10 @@ for k in sorted(agg):
     ga = mean(k, "GRBM_GUI_ACTIVE")
     if ga is not None:
         e["gui_active_cycles_per_launch_all_xcd"] = ga
+        if dur[k][1]:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; ns of the same run's kernel trace -> GHz under this kernel's load
+            e["avg_duration_ns_in_pmc_pass"] = dur[k][0] / dur[k][1]
+            e["shader_clock_ghz"] = ga / 8.0 / (dur[k][0] / dur[k][1])
     out["kernels"][k] = e
     tot = e["hbm_bytes_per_launch"] * e["dispatches"]
     if "conv_halo2" in k and tot > best[0]:

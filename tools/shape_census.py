@@ -18,16 +18,32 @@ class MetaOps:
     act_dtype = torch.bfloat16
     device = torch.device("meta")
 
-    def __init__(self):
+    def __init__(self, classify=False):
+        """``classify``: ask the LIBRARY which kernel it would launch for every gemm call (svr_gemm_kernel_class on the
+        svr_gemm_args the product's own ops.fill_gemm_args builds, with stand-in addresses): no GPU needed."""
         self.calls = collections.defaultdict(lambda: [0, 0.0, 0.0])
+        self.classify = classify
+        self.classes = collections.defaultdict(set)          # kind string -> kernel classes seen
+        self.launches = []                                   # (kernel class, conv geometry | None, M, N, K)
 
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or torch.bfloat16, device="meta")
 
     def pack_conv_frag(self, W, kt, Cin, N, taps=(3, 3)):
-        return torch.empty(1, device="meta")
+        # (same acceptance rule as HipOps.pack_conv_frag)
+        if Cin % 64 or N % 128 or W.shape[1] != kt * taps[0] * taps[1] * Cin or tuple(taps) not in ((3, 3), (2, 2)):
+            return None
+        return torch.empty(N * W.shape[1], dtype=torch.bfloat16, device="meta")
 
     def gemm(self, A, W, out, *, N, K, M=None, conv=None, ps=None, resid=None, out_f32=False, gn_groups=0, **kw):
+        if self.classify:
+            import ctypes
+            ops_mod, hip_lib = sub("ops"), sub("hip_lib")
+            kw2 = {k: v for k, v in kw.items() if k != "gn_shared"}
+            a, _ = ops_mod.fill_gemm_args(A, W, out, N=N, K=K, M=M, conv=conv, ps=ps, resid=resid, out_f32=out_f32,
+                                          zeros_ptr=0x1000, ptr=lambda t: 0x100000, **kw2)
+            cls = hip_lib.KERNEL_CLASSES.get(int(hip_lib.lib().svr_gemm_kernel_class(ctypes.byref(a))), "invalid")
+            self.launches.append((cls, conv, a.M, N, K))
         if conv is not None:
             g = conv
             M = g.To * g.Ho * g.Wo
