@@ -228,9 +228,8 @@ def main():
     dit = sub("dit").NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, device=device), ops, hid_fp32=not args.bf16_trunk)
     vae = sub("vae").VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, device=device), ops,
                                     merge_upsamplers=not args.two_step_upsampler, merge_causal_head=not args.three_tap_head,
-                                    trunk_fp32=not args.bf16_trunk,
-                                    **({} if args.tile_streams is None else {"tile_streams": args.tile_streams}),
-                                    **({} if args.branch is None else {"branch_fp32": args.branch == "fp32"}))
+                                    trunk_store="bf16" if args.bf16_trunk else args.trunk, branch_store=args.branch,
+                                    **({} if args.tile_streams is None else {"tile_streams": args.tile_streams}))
     runner_mod = sub("runner")
     runner = runner_mod.VideoDiffusionInfer(
         runner_mod.default_config(), encode_tiled=tiled, encode_tile_size=(1024, 1024), encode_tile_overlap=(128, 128),
@@ -407,8 +406,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "storage": "bf16 activations (every MFMA operand), bf16 residual trunk / stream (round-2 regime)" if args.bf16_trunk else
-                       "bf16 activations (every MFMA operand), fp32 residual trunk (VAE) and residual stream (DiT)",
+            "storage": f"bf16 activations (every MFMA operand); VAE residual trunk {vae.trunk_store}, conv1 outputs {vae.branch_store} "
+                       f"(h16 = IEEE half of x * 2^-6); DiT residual stream {'bf16' if args.bf16_trunk else 'fp32'}",
             "config": {"workload": f"{args.workload}: {desc}",
                        "frames_per_step_per_gpu": useful if not sharded else f"{frames} per clip, 8 batches of 17 shared by the ranks",
                        "pixels": [H, W], "latent": [Tl, hl, wl] if not sharded else [(CFG4["batch_size"] - 1) // 4 + 1, hl, wl],

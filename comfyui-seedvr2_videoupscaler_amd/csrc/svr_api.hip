@@ -249,8 +249,10 @@ int svr_groupnorm_stats(const void* x, double* stats, void* workspace, int32_t T
         return fail("svr_groupnorm_stats: need C in {128,256,512}-like (C%8==0, C<=512, groups<=32, (C/groups)%4==0)");
     if (!workspace) return fail("svr_groupnorm_stats: workspace missing (svr_groupnorm_workspace_bytes)");
     const unsigned nblk = blocks_for(HW, GN_ROWS_PER_BLOCK);
-    if (x_f32) hipLaunchKernelGGL(groupnorm_stats_kernel<true>, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream, x, (double2*)workspace, HW, C, groups);
-    else hipLaunchKernelGGL(groupnorm_stats_kernel<false>, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream, x, (double2*)workspace, HW, C, groups);
+    if ((unsigned)x_f32 > (unsigned)SVR_STORE_H16) return fail("svr_groupnorm_stats: x_f32 must be SVR_STORE_BF16 / _FP32 / _H16");
+    if (x_f32 == SVR_STORE_FP32) hipLaunchKernelGGL(groupnorm_stats_kernel<1>, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream, x, (double2*)workspace, HW, C, groups);
+    else if (x_f32 == SVR_STORE_H16) hipLaunchKernelGGL(groupnorm_stats_kernel<2>, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream, x, (double2*)workspace, HW, C, groups);
+    else hipLaunchKernelGGL(groupnorm_stats_kernel<0>, dim3(nblk, T), dim3(256), 0, (hipStream_t)stream, x, (double2*)workspace, HW, C, groups);
     hipLaunchKernelGGL(groupnorm_reduce_kernel, dim3(T, groups), dim3(256), 0, (hipStream_t)stream,
                        (const double2*)workspace, stats, (int)nblk, groups);
     return check(hipGetLastError(), "svr_groupnorm_stats");
@@ -264,9 +266,12 @@ int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float
     const int64_t nchunks = HW * (C / 8);
     unsigned gx = blocks_for(nchunks, 256 * 4);
     if (gx > 8192) gx = 8192;
-    if (x_f32) hipLaunchKernelGGL(groupnorm_apply_kernel<true>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,
-                                  (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
-    else hipLaunchKernelGGL(groupnorm_apply_kernel<false>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,
+    if ((unsigned)x_f32 > (unsigned)SVR_STORE_H16) return fail("svr_groupnorm_apply: x_f32 must be SVR_STORE_BF16 / _FP32 / _H16");
+    if (x_f32 == SVR_STORE_FP32) hipLaunchKernelGGL(groupnorm_apply_kernel<1>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,
+                                                    (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
+    else if (x_f32 == SVR_STORE_H16) hipLaunchKernelGGL(groupnorm_apply_kernel<2>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,
+                                                        (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
+    else hipLaunchKernelGGL(groupnorm_apply_kernel<0>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,
                             (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
     return check(hipGetLastError(), "svr_groupnorm_apply");
 }

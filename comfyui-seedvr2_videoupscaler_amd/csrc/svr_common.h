@@ -43,11 +43,38 @@ SVR_DEVICE void unpack8(const uint4& v, float* o) {
     o[6] = __builtin_bit_cast(float, v.w << 16); o[7] = __builtin_bit_cast(float, v.w & 0xffff0000u);
 }
 
-// 8 consecutive activations starting at element index e8 (a multiple of 8) of a bf16 or -- XF32: the wide residual trunk -- fp32 tensor
-template <bool XF32> SVR_DEVICE void load8(const void* base, int64_t e8, float* o) {
-    if constexpr (XF32) {
+// ---- "h16": the 2-byte WIDE storage format of the residual trunk (SVR_STORE_H16, include/seedvr2_hip.h) ----------------------
+// An IEEE half holding x * 2^-6: 11 significant bits instead of bf16's 8 for the same bytes -- measured on the production-width
+// chain it is as good as fp32 storage (tools/error_budget.py: 49.99 vs 50.01 dB) -- and the exponent shift moves half's range to
+// +-4.2e6 with an absolute floor of 3.8e-6 (un-normalised VAE activations of real checkpoints can exceed half's 65504).
+// Only GroupNorm and residual adds read such a tensor; every MFMA operand stays bf16.
+constexpr float H16_SCALE = 0.015625f, H16_INV = 64.0f;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+SVR_DEVICE uint32_t pack2h_raw(float lo, float hi) {            // RNE (v_cvt_pk_f16_f32), values already scaled
+    const f16x2_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+SVR_DEVICE uint4 pack8h(const float* o) {                       // fp32 values -> 8 h16
+    uint4 v;
+    v.x = pack2h_raw(o[0] * H16_SCALE, o[1] * H16_SCALE); v.y = pack2h_raw(o[2] * H16_SCALE, o[3] * H16_SCALE);
+    v.z = pack2h_raw(o[4] * H16_SCALE, o[5] * H16_SCALE); v.w = pack2h_raw(o[6] * H16_SCALE, o[7] * H16_SCALE);
+    return v;
+}
+SVR_DEVICE void unpack8h(const uint4& v, float* o) {            // 8 h16 -> the fp32 values they stand for
+    const f16x2_t a = __builtin_bit_cast(f16x2_t, v.x), b = __builtin_bit_cast(f16x2_t, v.y),
+                  c = __builtin_bit_cast(f16x2_t, v.z), d = __builtin_bit_cast(f16x2_t, v.w);
+    o[0] = (float)a[0] * H16_INV; o[1] = (float)a[1] * H16_INV; o[2] = (float)b[0] * H16_INV; o[3] = (float)b[1] * H16_INV;
+    o[4] = (float)c[0] * H16_INV; o[5] = (float)c[1] * H16_INV; o[6] = (float)d[0] * H16_INV; o[7] = (float)d[1] * H16_INV;
+}
+
+// 8 consecutive activations starting at element index e8 (a multiple of 8) of a tensor stored as KIND: 0 bf16, 1 fp32, 2 h16
+// (the SVR_STORE_* codes; bool arguments keep their old meaning: false bf16, true fp32)
+template <int KIND> SVR_DEVICE void load8(const void* base, int64_t e8, float* o) {
+    if constexpr (KIND == 1) {
         const float4 a = *(const float4*)((const float*)base + e8), b = *(const float4*)((const float*)base + e8 + 4);
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    } else if constexpr (KIND == 2) {
+        unpack8h(*(const uint4*)((const bf16_t*)base + e8), o);
     } else {
         unpack8(*(const uint4*)((const bf16_t*)base + e8), o);
     }

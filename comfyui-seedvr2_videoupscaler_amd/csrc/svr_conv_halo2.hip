@@ -725,9 +725,12 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
         constexpr int F = decltype(fc)::value;
         constexpr bool RT = F < 0, F_RESID = !RT && (F & 1), F_GN = !RT && (F & 2);
         const bool with_resid = RT ? (resid_gate && a.resid != nullptr) : F_RESID;
-        // wide residual trunk (ABI v5): fp32 output (F & 4) / fp32 residual (F & 8); the fused statistics are then those of the fp32 values
-        const bool o32 = RT ? (a.out_f32 != 0) : ((F & 4) != 0);
-        const bool r32 = RT ? (a.resid_f32 != 0) : ((F & 8) != 0);
+        // wide residual trunk: the compiled option sets store / read it as h16 (F & 4 output, F & 8 residual; ABI v6 -- round 3's
+        // fp32 trunk cost 2.4 % of the step for the same parity); fp32 tensors take the run-time body.  The fused statistics are
+        // those of the values as stored.
+        const int ko = RT ? a.out_f32 : ((F & 4) != 0 ? SVR_STORE_H16 : SVR_STORE_BF16);
+        const int kr = RT ? a.resid_f32 : ((F & 8) != 0 ? SVR_STORE_H16 : SVR_STORE_BF16);
+        const bool o32 = ko == SVR_STORE_FP32, r32 = kr == SVR_STORE_FP32;
         const bool with_gn = RT ? a.gn_partial != nullptr : F_GN;
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
@@ -812,6 +815,8 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { r8[e] = rf0[RT ? 0 : it][e]; r8[4 + e] = rf1[RT ? 0 : it][e]; }
+                    } else if (kr == SVR_STORE_H16) {
+                        unpack8h(rr8[it], r8);
                     } else {
                         unpack8(rr8[it], r8);
                     }
@@ -831,11 +836,11 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
                         }
                     }
                 } else {
-                    const uint4 pk = pack8(f);
+                    const uint4 pk = ko == SVR_STORE_H16 ? pack8h(f) : pack8(f);
                     if (ok[it]) *(uint4*)((bf16_t*)a.C + mrow[it] * a.ldc + n) = pk;
                     if (with_gn && ok[it]) {
                         float r[8];
-                        unpack8(pk, r);
+                        if (ko == SVR_STORE_H16) unpack8h(pk, r); else unpack8(pk, r);
                         gs0 += r[0] + r[1] + r[2] + r[3];
                         gq0 += r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
                         gs1 += r[4] + r[5] + r[6] + r[7];
@@ -849,9 +854,11 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
         }
     };
     // (measurement builds' DBG variants: the round-2 option sets only -- they are never launched with a wide trunk)
-    if (a.epilogue != SVR_EPI_BIAS_SILU && a.gate == nullptr && (DBG == 0 || (!a.out_f32 && !a.resid_f32))) {
-        const bool wr = resid_gate && a.resid != nullptr;
-        const int F = (wr ? 1 : 0) | (a.gn_partial != nullptr ? 2 : 0) | (a.out_f32 ? 4 : 0) | (wr && a.resid_f32 ? 8 : 0);
+    const bool wr = resid_gate && a.resid != nullptr;
+    if (a.epilogue != SVR_EPI_BIAS_SILU && a.gate == nullptr && a.out_f32 != SVR_STORE_FP32 && !(wr && a.resid_f32 == SVR_STORE_FP32) &&
+        (DBG == 0 || (!a.out_f32 && !a.resid_f32))) {
+        const int F = (wr ? 1 : 0) | (a.gn_partial != nullptr ? 2 : 0) | (a.out_f32 == SVR_STORE_H16 ? 4 : 0) |
+                      (wr && a.resid_f32 == SVR_STORE_H16 ? 8 : 0);
         switch (F) {
 #define SVR_EP_CASE(v) case v: ep_body(std::integral_constant<int, v>{}); break;
             SVR_EP_CASE(0) SVR_EP_CASE(1) SVR_EP_CASE(2) SVR_EP_CASE(3)

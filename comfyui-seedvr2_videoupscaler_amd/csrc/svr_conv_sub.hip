@@ -298,9 +298,10 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
     const int yb = a.phase.py ? g.H - 1 : 0, xb = a.phase.px ? g.W - 1 : 0;
     const float* btab = a.phase.enabled ? a.phase.bias_border : nullptr;
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;      // fused GroupNorm statistics of the stored values (columns n .. n + 3, n + 4 .. n + 7)
-    // (the body is instantiated per output type -- bf16 | fp32 for the wide residual trunk -- so its loops carry no option branches)
+    // (the body is instantiated per output kind -- bf16 | fp32 | h16, the wide residual trunk -- so its loops carry no option branches)
     auto ep_body = [&](auto o32c) {
-    constexpr bool O32 = decltype(o32c)::value;
+    constexpr int OKIND = decltype(o32c)::value;
+    constexpr bool O32 = OKIND == SVR_STORE_FP32;
 #pragma unroll
     for (int pass = 0; pass < MTW / 2; ++pass) {
         __builtin_amdgcn_sched_barrier(0);
@@ -356,9 +357,9 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) r[e] = f[e];
                 } else {
-                    const uint4 pk = pack8(f);
+                    const uint4 pk = OKIND == SVR_STORE_H16 ? pack8h(f) : pack8(f);
                     if (ok[it]) *(uint4*)((bf16_t*)a.C + off[it]) = pk;
-                    unpack8(pk, r);
+                    if constexpr (OKIND == SVR_STORE_H16) unpack8h(pk, r); else unpack8(pk, r);
                 }
                 if (a.gn_partial != nullptr && ok[it]) {
                     gs0 += r[0] + r[1] + r[2] + r[3];
@@ -371,7 +372,9 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
         if (pass + 1 < MTW / 2) lds_barrier();
     }
     };
-    if (a.out_f32) ep_body(std::true_type{}); else ep_body(std::false_type{});
+    if (a.out_f32 == SVR_STORE_FP32) ep_body(std::integral_constant<int, SVR_STORE_FP32>{});
+    else if (a.out_f32 == SVR_STORE_H16) ep_body(std::integral_constant<int, SVR_STORE_H16>{});
+    else ep_body(std::integral_constant<int, SVR_STORE_BF16>{});
     if (a.gn_partial) {
         // fixed-order reduction thread -> quad -> group (svr_conv_halo2.hip's); the (sum, sum of squares) of this patch go to
         // gn_partial[output frame][phase (py, px)][block][group]: the four phase launches of an upsampled frame fill one row of

@@ -207,7 +207,7 @@ __global__ void unpatchify_euler_kernel(const bf16_t* __restrict__ pred, int64_t
 constexpr int GN_ROWS_PER_BLOCK = 2048;
 
 // partial[(t * nblk + blockIdx.x) * groups + g] = {sum, sum of squares} of this block's rows
-template <bool XF32>
+template <int XF32>   // storage kind of x (SVR_STORE_*: 0 bf16, 1 fp32, 2 h16)
 __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const void* __restrict__ x, double2* __restrict__ partial,
                                                               int64_t HW, int C, int groups) {
     __shared__ float red[256][4];
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void groupnorm_reduce_kernel(const double2* __
     }
 }
 
-template <bool XF32>
+template <int XF32>    // storage kind of x (SVR_STORE_*: 0 bf16, 1 fp32, 2 h16)
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __restrict__ x, bf16_t* __restrict__ y,
                                                               const double* __restrict__ stats,
                                                               const float* __restrict__ gamma,
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __rest
         var = var > 0.0 ? var : 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float ga = gamma[c] * rstd;
-        a_s[c] = ga;
+        a_s[c] = XF32 == 2 ? ga * H16_INV : ga;         // (h16 input: the stored value is x * 2^-6 -- the factor absorbs the 2^6)
         b_s[c] = beta[c] - (float)mean * ga;
     }
     __syncthreads();
@@ -307,6 +307,19 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __rest
     bf16_t* yb = y + (int64_t)t * HW * C;
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
     auto act = [&](float u) { return apply_silu ? silu(u) : u; };
+    auto raw8 = [&](const uint4& v, float* o) {         // 16 bytes of a 2-byte format -> 8 floats (h16: still scaled by 2^-6)
+        if constexpr (XF32 == 2) {
+            const f16x2_t a = __builtin_bit_cast(f16x2_t, v.x), b = __builtin_bit_cast(f16x2_t, v.y),
+                          c = __builtin_bit_cast(f16x2_t, v.z), d = __builtin_bit_cast(f16x2_t, v.w);
+            o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)b[0]; o[3] = (float)b[1];
+            o[4] = (float)c[0]; o[5] = (float)c[1]; o[6] = (float)d[0]; o[7] = (float)d[1];
+        } else {
+            unpack8(v, o);
+        }
+    };
+    auto ld8 = [&](int64_t e8, float* o) {              // (tails / odd channel counts)
+        if constexpr (XF32 == 1) load8<1>(x, e8, o); else raw8(*(const uint4*)((const bf16_t*)x + e8), o);
+    };
     if ((256 % cchunks) == 0) {
         // every chunk this thread touches starts at the same channel (the grid stride is a multiple of C / 8):
         // its 8 scale / offset pairs live in registers, no per-chunk index arithmetic or LDS reads
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __rest
         int64_t i = i0;
         for (; i + stride < nchunks; i += 2 * stride) {
             float f[8], h[8];
-            if constexpr (XF32) {
+            if constexpr (XF32 == 1) {
                 const f32x4 a0 = __builtin_nontemporal_load((const f32x4*)(xf + i * 8)), a1 = __builtin_nontemporal_load((const f32x4*)(xf + i * 8 + 4));
                 const f32x4 b0 = __builtin_nontemporal_load((const f32x4*)(xf + (i + stride) * 8)), b1 = __builtin_nontemporal_load((const f32x4*)(xf + (i + stride) * 8 + 4));
 #pragma unroll
@@ -327,8 +340,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __rest
             } else {
                 const u32x4 v0 = __builtin_nontemporal_load((const u32x4*)(xb + i * 8));
                 const u32x4 v1 = __builtin_nontemporal_load((const u32x4*)(xb + (i + stride) * 8));
-                unpack8(make_uint4(v0.x, v0.y, v0.z, v0.w), f);
-                unpack8(make_uint4(v1.x, v1.y, v1.z, v1.w), h);
+                raw8(make_uint4(v0.x, v0.y, v0.z, v0.w), f);
+                raw8(make_uint4(v1.x, v1.y, v1.z, v1.w), h);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { f[e] = act(f[e] * sa[e] + sb[e]); h[e] = act(h[e] * sa[e] + sb[e]); }
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __rest
         }
         for (; i < nchunks; i += stride) {
             float f[8];
-            load8<XF32>(x, xo + i * 8, f);
+            ld8(xo + i * 8, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = act(f[e] * sa[e] + sb[e]);
             *(uint4*)(yb + i * 8) = pack8(f);
@@ -347,7 +360,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __rest
         for (int64_t i = i0; i < nchunks; i += stride) {
             const int c0 = (int)(i % cchunks) * 8;
             float f[8];
-            load8<XF32>(x, xo + i * 8, f);
+            ld8(xo + i * 8, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = act(f[e] * a_s[c0 + e] + b_s[c0 + e]);
             *(uint4*)(yb + i * 8) = pack8(f);

@@ -53,7 +53,7 @@ SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f
     if (epi == SVR_EPI_SWIGLU) {
         // n = 32*hb + 4g (gate block of hidden block hb) -> hidden index 16*hb + 4g
         const int hid = ((n >> 5) << 4) + (n & 15);
-        if (a.out_f32) {        // fp32-store test epilogue (tests/test_gpu_kernels.py: the 1e-3 contract)
+        if (a.out_f32 == SVR_STORE_FP32) {        // fp32-store test epilogue (tests/test_gpu_kernels.py: the 1e-3 contract)
             *(float4*)((float*)a.C + (int64_t)m * a.ldc + hid) =
                 make_float4(silu(v[0]) * u[0], silu(v[1]) * u[1], silu(v[2]) * u[2], silu(v[3]) * u[3]);
             return;
@@ -85,10 +85,14 @@ SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] *= a.gate[n + r];
         }
-        if (a.resid && a.resid_f32) {
+        if (a.resid && a.resid_f32 == SVR_STORE_FP32) {
             const float* rp = (const float*)a.resid + (int64_t)m * a.ldr + n;
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += rp[r];
+        } else if (a.resid && a.resid_f32 == SVR_STORE_H16) {
+            const _Float16* rp = (const _Float16*)a.resid + (int64_t)m * a.ldr + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += (float)rp[r] * H16_INV;
         } else if (a.resid) {
             const bf16_t* rp = (const bf16_t*)a.resid + (int64_t)m * a.ldr + n;
             if (full) {
@@ -123,7 +127,7 @@ SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f
     } else {
         off = (int64_t)m * a.ldc + n;
     }
-    if (a.out_f32) {
+    if (a.out_f32 == SVR_STORE_FP32) {
         float* cp = (float*)a.C + off;
         if (full) *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
         else {
@@ -131,13 +135,17 @@ SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f
             for (int r = 0; r < 4; ++r) if (n + r < a.N) cp[r] = v[r];
         }
     } else {
+        const bool h16 = a.out_f32 == SVR_STORE_H16;
         bf16_t* cp = (bf16_t*)a.C + off;
         if (full) {
-            uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+            uint2 o;
+            if (h16) { o.x = pack2h_raw(v[0] * H16_SCALE, v[1] * H16_SCALE); o.y = pack2h_raw(v[2] * H16_SCALE, v[3] * H16_SCALE); }
+            else { o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); }
             *(uint2*)cp = o;
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (n + r < a.N) cp[r] = f2bf(v[r]);
+            for (int r = 0; r < 4; ++r)
+                if (n + r < a.N) cp[r] = h16 ? (bf16_t)(pack2h_raw(v[r] * H16_SCALE, 0.f) & 0xffffu) : f2bf(v[r]);
         }
     }
 }
@@ -154,7 +162,7 @@ SVR_DEVICE void epilogue_store8(const svr_gemm_args& a, const float (&acc8)[8], 
         const int hid = ((n >> 5) << 4) + (n & 15);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = silu(acc8[e]) * u[e];
-        if (a.out_f32) {
+        if (a.out_f32 == SVR_STORE_FP32) {
             float* cp = (float*)a.C + (int64_t)m * a.ldc + hid;
             *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
             *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -189,8 +197,9 @@ SVR_DEVICE void epilogue_store8(const svr_gemm_args& a, const float (&acc8)[8], 
         }
         if (a.resid) {
             float r8[8];
-            if (a.resid_f32) load8<true>(a.resid, (int64_t)m * a.ldr + n, r8);
-            else load8<false>(a.resid, (int64_t)m * a.ldr + n, r8);
+            if (a.resid_f32 == SVR_STORE_FP32) load8<1>(a.resid, (int64_t)m * a.ldr + n, r8);
+            else if (a.resid_f32 == SVR_STORE_H16) load8<2>(a.resid, (int64_t)m * a.ldr + n, r8);
+            else load8<0>(a.resid, (int64_t)m * a.ldr + n, r8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += r8[e];
         }
@@ -217,12 +226,12 @@ SVR_DEVICE void epilogue_store8(const svr_gemm_args& a, const float (&acc8)[8], 
     } else {
         off = (int64_t)m * a.ldc + n;
     }
-    if (a.out_f32) {
+    if (a.out_f32 == SVR_STORE_FP32) {
         float* cp = (float*)a.C + off;
         *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
         *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-        *(uint4*)((bf16_t*)a.C + off) = pack8(v);
+        *(uint4*)((bf16_t*)a.C + off) = a.out_f32 == SVR_STORE_H16 ? pack8h(v) : pack8(v);
     }
 }
 
@@ -337,9 +346,12 @@ SVR_DEVICE void epilogue_generic_lds(const svr_gemm_args& a, const ACC& acc, cha
             // residual rows of the sweep (out-of-range rows read row M - 1 and are masked at the store)
             float r8[SW][8];
             if (with_resid) {
-                if (a.resid_f32) {
+                if (a.resid_f32 == SVR_STORE_FP32) {
 #pragma unroll
-                    for (int it = 0; it < SW; ++it) load8<true>(a.resid, (int64_t)min(mrow[it], a.M - 1) * a.ldr + n, r8[it]);
+                    for (int it = 0; it < SW; ++it) load8<1>(a.resid, (int64_t)min(mrow[it], a.M - 1) * a.ldr + n, r8[it]);
+                } else if (a.resid_f32 == SVR_STORE_H16) {
+#pragma unroll
+                    for (int it = 0; it < SW; ++it) load8<2>(a.resid, (int64_t)min(mrow[it], a.M - 1) * a.ldr + n, r8[it]);
                 } else {
 #pragma unroll
                     for (int it = 0; it < SW; ++it) load8<false>(a.resid, (int64_t)min(mrow[it], a.M - 1) * a.ldr + n, r8[it]);
@@ -375,12 +387,12 @@ SVR_DEVICE void epilogue_generic_lds(const svr_gemm_args& a, const ACC& acc, cha
                     off = (int64_t)mrow[it] * a.ldc + n;
                 }
                 if (!ok[it]) continue;
-                if (a.out_f32) {
+                if (a.out_f32 == SVR_STORE_FP32) {
                     float* cp = (float*)a.C + off;
                     *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
                     *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 } else {
-                    *(uint4*)((bf16_t*)a.C + off) = pack8(v);
+                    *(uint4*)((bf16_t*)a.C + off) = a.out_f32 == SVR_STORE_H16 ? pack8h(v) : pack8(v);
                 }
             }
         }
@@ -399,7 +411,7 @@ template <int OFF> SVR_DEVICE void agpr_park(unsigned lds_addr, const f32x4& v) 
 // the pass), the variant is a template argument, and an instance is ~2-3 KB.  Same arithmetic in the same order as the generic
 // form -> bit-identical results.
 template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES, bool M32, int RI_FORCE, int SW_FORCE, int EDBG, int RES_REGS_,
-          int EPI, bool OUT_F32, bool RESID_F32, bool PS, bool AGPR, typename ACC>
+          int EPI, int OUT_F32, int RESID_F32, bool PS, bool AGPR, typename ACC>      // OUT_F32 / RESID_F32: SVR_STORE_* kinds
 SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
     constexpr int WAVES_N = BN / WN, FM = WM / 16, FN = WN / 16;
     constexpr int WAVES_M = BM / WM;
@@ -494,7 +506,7 @@ SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char*
     //     parking writes of their own pass, and a slot is reloaded with row + PF when consumed.
     constexpr bool RES = EPI == SVR_EPI_RESID_GATE;
     constexpr int RES_REGS = RES_REGS_ < 0 ? -RES_REGS_ : RES_REGS_;
-    constexpr int RPR = RESID_F32 ? 2 : 1;                                  // 16-byte registers per row
+    constexpr int RPR = RESID_F32 == SVR_STORE_FP32 ? 2 : 1;                // 16-byte registers per row
     constexpr int PF = RES ? (ITERS * RPR <= RES_REGS ? ITERS : (RES_REGS / RPR / SW) * SW) : 0;      // rows in flight (whole sweeps)
     constexpr bool EARLY = RES && RES_REGS_ >= 0;
     static_assert(!RES || (PF >= SW && ITERS % PF == 0), "residual prefetch depth");
@@ -503,7 +515,7 @@ SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char*
         const int lr = it * ROWS_IT + r_it;
         const int mr = m0 + (lr / (RI * 16)) * WM + 16 * (pp * RI + ((lr >> 4) % RI)) + (lr & 15);
         const int64_t e8 = (int64_t)min(mr, a.M - 1) * a.ldr + n;             // (out-of-range rows read row M - 1, masked at the store)
-        if constexpr (RESID_F32) {
+        if constexpr (RESID_F32 == SVR_STORE_FP32) {
             raw[2 * slot] = *(const uint4*)((const float*)a.resid + e8);
             raw[2 * slot + 1] = *(const uint4*)((const float*)a.resid + e8 + 4);
         } else {
@@ -548,10 +560,12 @@ SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char*
 #pragma unroll
                     for (int it = 0; it < SW; ++it) {
                         const int slot = (s0 + it) % PF;
-                        if constexpr (RESID_F32) {
+                        if constexpr (RESID_F32 == SVR_STORE_FP32) {
                             const uint4 x = raw[2 * slot], y = raw[2 * slot + 1];
                             r8[it][0] = __uint_as_float(x.x); r8[it][1] = __uint_as_float(x.y); r8[it][2] = __uint_as_float(x.z); r8[it][3] = __uint_as_float(x.w);
                             r8[it][4] = __uint_as_float(y.x); r8[it][5] = __uint_as_float(y.y); r8[it][6] = __uint_as_float(y.z); r8[it][7] = __uint_as_float(y.w);
+                        } else if constexpr (RESID_F32 == SVR_STORE_H16) {
+                            unpack8h(raw[slot], r8[it]);
                         } else {
                             unpack8(raw[slot], r8[it]);
                         }
@@ -608,10 +622,12 @@ SVR_DEVICE void epilogue_plain_lds(const svr_gemm_args& a, const ACC& acc, char*
                     }
                 }
                 if (mrow[it] >= a.M || (EDBG & 1)) continue;
-                if constexpr (OUT_F32) {
+                if constexpr (OUT_F32 == SVR_STORE_FP32) {
                     float* cp = (float*)a.C + off;
                     *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
                     *(float4*)(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else if constexpr (OUT_F32 == SVR_STORE_H16) {
+                    *(uint4*)((bf16_t*)a.C + off) = pack8h(v);
                 } else {
                     *(uint4*)((bf16_t*)a.C + off) = pack8(v);
                 }
@@ -631,8 +647,27 @@ template <int BM, int BN, int WM, int WN, int NTHREADS, int LDS_BYTES, bool M32 
 SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
 #define SVR_EPI_CASE(E, OF, RF) \
     epilogue_plain_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG, RES_REGS, E, OF, RF, false, AGPR>(a, acc, smem, m0, n0, tid, lane, wave)
+    if constexpr (!PLAIN_ONLY) {
+        // the h16 trunk of the VAE (ABI v6; never on the persistent kernel: gemm_w4_eligible): its own compact instances
+        const bool rg = a.epilogue == SVR_EPI_RESID_GATE && a.resid != nullptr;
+        const int ok_ = a.out_f32, rk_ = rg ? a.resid_f32 : 0;
+        // (compact instances on the 256 x 128 tile only: the 256 x 256 tile's 128 accumulators leave the eight-wave kernel no
+        // registers for four more epilogue bodies -- hipcc spilled 200 of them -- and its h16 callers, the wide 1x1 / strided
+        // convs of the VAE, are short-K launches that the run-time form serves)
+        if (BN != 256 && (ok_ == SVR_STORE_H16 || rk_ == SVR_STORE_H16) && !a.ps.enabled && !a.phase.enabled && ok_ != SVR_STORE_FP32 && rk_ != SVR_STORE_FP32 &&
+            (a.epilogue == SVR_EPI_BIAS || a.epilogue == SVR_EPI_RESID_GATE)) {
+            if (a.epilogue == SVR_EPI_BIAS) { SVR_EPI_CASE(SVR_EPI_BIAS, SVR_STORE_H16, 0); return; }
+            if (ok_ == SVR_STORE_H16 && rk_ == SVR_STORE_H16) { SVR_EPI_CASE(SVR_EPI_RESID_GATE, SVR_STORE_H16, SVR_STORE_H16); return; }
+            if (ok_ == SVR_STORE_H16) { SVR_EPI_CASE(SVR_EPI_RESID_GATE, SVR_STORE_H16, SVR_STORE_BF16); return; }
+            SVR_EPI_CASE(SVR_EPI_RESID_GATE, SVR_STORE_BF16, SVR_STORE_H16); return;
+        }
+        if (ok_ == SVR_STORE_H16 || rk_ == SVR_STORE_H16) {              // anything else with an h16 tensor: the run-time form
+            epilogue_generic_lds<BM, BN, WM, WN, NTHREADS, LDS_BYTES, M32, RI_FORCE, SW_FORCE, EDBG>(a, acc, smem, m0, n0, tid, lane, wave);
+            return;
+        }
+    }
     if (PLAIN_ONLY || (!a.ps.enabled && !a.phase.enabled)) {
-        const int of = a.out_f32 ? 1 : 0, rf = (a.epilogue == SVR_EPI_RESID_GATE && a.resid && a.resid_f32) ? 1 : 0;
+        const int of = a.out_f32 == SVR_STORE_FP32 ? 1 : 0, rf = (a.epilogue == SVR_EPI_RESID_GATE && a.resid && a.resid_f32 == SVR_STORE_FP32) ? 1 : 0;
         switch (a.epilogue * 4 + of * 2 + rf) {
             case SVR_EPI_BIAS * 4 + 0:       SVR_EPI_CASE(SVR_EPI_BIAS, false, false); return;
             case SVR_EPI_BIAS * 4 + 2:       SVR_EPI_CASE(SVR_EPI_BIAS, true, false); return;
@@ -645,8 +680,9 @@ SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, cha
             case SVR_EPI_RESID_GATE * 4 + 0: SVR_EPI_CASE(SVR_EPI_RESID_GATE, false, false); return;
             case SVR_EPI_RESID_GATE * 4 + 1: SVR_EPI_CASE(SVR_EPI_RESID_GATE, false, true); return;
             case SVR_EPI_RESID_GATE * 4 + 2: SVR_EPI_CASE(SVR_EPI_RESID_GATE, true, false); return;
-            case SVR_EPI_RESID_GATE * 4 + 3: SVR_EPI_CASE(SVR_EPI_RESID_GATE, true, true); return;
-            default: return;                 // (unreachable: gemm_route() rejects unknown epilogue codes and a residual type without a residual)
+            // (RESID_GATE * 4 + 3; nothing else reaches this arm: gemm_route() rejects unknown epilogue codes and a residual type
+            // without a residual.  Written as the default on purpose -- with one more arm the persistent kernel spilled a register)
+            default:                         SVR_EPI_CASE(SVR_EPI_RESID_GATE, true, true); return;
         }
     }
     if constexpr (!PLAIN_ONLY) {
@@ -1652,7 +1688,7 @@ static bool gemm_epi_lds(const svr_gemm_args& a) {
 // what gemm_w4q_kernel serves: plain GEMMs with whole 256-column tiles, at least two K tiles, 16-byte aligned rows, the
 // row-contiguous epilogue's alignment, and enough tiles to fill the chip (one workgroup per CU)
 static bool gemm_w4_eligible(const svr_gemm_args& a) {
-    return g_gemm_w4 && !a.conv.enabled && !a.ps.enabled && !a.phase.enabled &&
+    return g_gemm_w4 && !a.conv.enabled && !a.ps.enabled && !a.phase.enabled && a.out_f32 != SVR_STORE_H16 && a.resid_f32 != SVR_STORE_H16 &&
            (a.N % 256) == 0 && a.K >= 2 * BK &&
            (a.lda % 8) == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0 && gemm_epi_lds_aligned(a) &&
            (int64_t)a.lda * 2 * 255 < ((int64_t)1 << 31) && (int64_t)a.K * 2 * 255 < ((int64_t)1 << 31) &&
@@ -1673,6 +1709,10 @@ int gemm_route(const svr_gemm_args& a, const char** why) {
     if ((unsigned)a.epilogue > (unsigned)SVR_EPI_BIAS_GELU) { *why = "svr_gemm_bf16: unknown epilogue code"; return -1; }
     if (a.resid && a.epilogue != SVR_EPI_RESID_GATE) { *why = "svr_gemm_bf16: resid needs SVR_EPI_RESID_GATE"; return -1; }
     if (a.resid_f32 && !a.resid) { *why = "svr_gemm_bf16: resid_f32 without resid"; return -1; }
+    if ((unsigned)a.out_f32 > (unsigned)SVR_STORE_H16 || (unsigned)a.resid_f32 > (unsigned)SVR_STORE_H16) {
+        *why = "svr_gemm_bf16: out_f32 / resid_f32 must be SVR_STORE_BF16 / _FP32 / _H16"; return -1;
+    }
+    if (a.out_f32 == SVR_STORE_H16 && (a.epilogue == SVR_EPI_SWIGLU || a.ps.enabled)) { *why = "svr_gemm_bf16: h16 output with SwiGLU / pixel shuffle"; return -1; }
     if (a.conv.enabled) {
         const svr_conv_geom& g = a.conv;
         if (!conv_thin_eligible(a)) {       // (thin input: Cin = 4, K = taps * 4 zero-padded to 128)

@@ -12,6 +12,24 @@ from . import hip_lib
 from .hip_lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU  # noqa: F401 (re-export)
 
 BF16 = torch.bfloat16
+# "h16": the 2-byte WIDE storage format of tensors that are not MFMA operands (SVR_STORE_H16 in include/seedvr2_hip.h): a
+# torch.float16 tensor whose elements hold x * 2^-6.  Only the library's kernels interpret it (GroupNorm, residual adds);
+# h16_to_float() is for tests and debugging.
+H16 = torch.float16
+H16_SCALE = 2.0 ** -6
+STORE_BF16, STORE_FP32, STORE_H16 = 0, 1, 2
+_KIND = {BF16: STORE_BF16, torch.float32: STORE_FP32, H16: STORE_H16}
+
+
+def store_kind(t: torch.Tensor) -> int:
+    try:
+        return _KIND[t.dtype]
+    except KeyError:
+        raise ValueError(f"activation storage must be bf16, fp32 or h16 (torch.float16), got {t.dtype}") from None
+
+
+def h16_to_float(t: torch.Tensor) -> torch.Tensor:
+    return t.float() * (1.0 / H16_SCALE) if t.dtype == H16 else t.float()
 
 
 @dataclass
@@ -64,7 +82,12 @@ def fill_gemm_args(A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gat
     chk = chk or (lambda t, dtype=None, name="tensor": t)
     ptr = ptr or (lambda t: t.data_ptr())
     chk(A, BF16, "A"); chk(W, BF16, "W")
-    chk(out, torch.float32 if out_f32 else BF16, "out")
+    # ``out_f32``: the caller expects a wide store (fp32, or h16 when ``out`` is a torch.float16 tensor); the kind itself comes
+    # from out.dtype
+    okind = store_kind(out)
+    if bool(out_f32) != (okind != STORE_BF16):
+        raise ValueError(f"out must be {'fp32 / h16' if out_f32 else 'bf16'}, got {out.dtype}")
+    chk(out, None, "out")
     if W.shape[1] != K or W.shape[0] < N or W.shape[0] % 128:
         raise ValueError(f"packed weight shape {tuple(W.shape)} incompatible with N={N}, K={K}")
     a = hip_lib.GemmArgs()
@@ -115,13 +138,11 @@ def fill_gemm_args(A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gat
     if gate is not None:
         a.gate = ptr(chk(gate, torch.float32, "gate"))
     if resid is not None:
-        if resid.dtype not in (BF16, torch.float32):
-            raise ValueError(f"resid must be bf16 or fp32, got {resid.dtype}")
         chk(resid, None, "resid")
         a.resid = ptr(resid)
-        a.resid_f32 = int(resid.dtype == torch.float32)
+        a.resid_f32 = store_kind(resid)
         a.ldr = ldr if ldr is not None else (resid.stride(0) if resid.dim() == 2 else N)
-    a.epilogue, a.out_f32 = epilogue, int(out_f32)
+    a.epilogue, a.out_f32 = epilogue, okind
     if W_frag is not None:
         if W_frag.numel() < N * K:
             raise ValueError(f"W_frag holds {W_frag.numel()} elements, the problem needs N * K = {N * K}")
@@ -243,11 +264,9 @@ class HipOps:
 
     # ------------------------------------------------------------------ DiT side kernels
     def _xf32(self, x, name="x"):
-        """activation inputs that may come from the wide (fp32) residual trunk: -> 1 if fp32, 0 if bf16"""
-        if x.dtype not in (BF16, torch.float32):
-            raise ValueError(f"{name} must be bf16 or fp32, got {x.dtype}")
+        """activation inputs that may come from the wide residual trunk: -> the SVR_STORE_* kind (0 bf16, 1 fp32, 2 h16)"""
         self._chk(x, None, name)
-        return int(x.dtype == torch.float32)
+        return store_kind(x)
 
     def rmsnorm_mod(self, x, out, eps, w=None, scale=None, shift=None):
         xf = self._xf32(x); self._chk(out, BF16, "out")

@@ -96,7 +96,7 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
             progress: Optional[Callable[[str, int, int], None]] = None,
             noise_provider: Optional[Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None,
             exchange_heads: Optional[Callable[[dict, list, tuple, torch.dtype], dict]] = None,
-            return_spans: bool = False, skip_trimmed_frames: bool = True):
+            return_spans: bool = False, skip_trimmed_frames: bool = True, output_dtype: Optional[torch.dtype] = torch.float32):
     """images [T, H, W, 3] in [0, 1] (any float dtype, on the runner's device) -> upscaled [T, H', W', 3] in [0, 1].
 
     ``batch_filter(i)`` restricts phases 1-3 to the temporal batches a rank owns (data parallelism over
@@ -107,6 +107,11 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
     # compute / storage dtype of the phases = the engines' activation dtype (bf16 on the HIP path, as the reference's
     # compute_dtype; fp32 when the CPU tests drive the engines with the fp32 torch double of the C ABI)
     dev, dt = runner.dit.device, getattr(getattr(runner.dit, "ops", None), "act_dtype", torch.bfloat16)
+    # what the decoded frames are held in from the decoder's output on (trims, overlap blend, colour fix, [-1, 1] -> [0, 1]) and
+    # returned in.  Default fp32 = ComfyUI's IMAGE dtype (video_upscaler.py:241): a bf16 [0, 1] frame has a step of 2^-8 above 0.5,
+    # i.e. 1.1e-3 rms of rounding per stage -- 1.3e-6 of the 1e-5 MSE that 50 dB allows (tools/error_budget.py);
+    # None: the engines' activation dtype (rounds 2-3; the reference keeps final_video in its compute dtype)
+    odt = output_dtype if output_dtype is not None else dt
     images = images_thwc.to(device=dev)
     if prepend_frames > 0:
         images = transforms.pad_video_temporal(images, count=prepend_frames, temporal_dim=0, prepend=True)
@@ -167,7 +172,7 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
             progress("upscale", n + 1, len(mine))
 
     # ---- phase 3: decode, trim, blend into the output clip ([-1, 1] until phase 4)
-    final = torch.zeros(total, true_h, true_w, 3, dtype=dt, device=dev)
+    final = torch.zeros(total, true_h, true_w, 3, dtype=odt, device=dev)
     spans, heads, starts = {}, {}, {}
     write = 0
     for i, plan in enumerate(plans):
@@ -181,7 +186,7 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
                       if skip_trimmed_frames and _takes_keep_frames(runner) else runner.vae_decode([upscaled.pop(i)])[0])
             if sample.dim() == 3:
                 sample = sample.unsqueeze(1)
-            sample = sample.permute(1, 2, 3, 0)[:ori, :true_h, :true_w]                   # T H W C, padding trimmed
+            sample = sample.permute(1, 2, 3, 0)[:ori, :true_h, :true_w].to(odt)           # T H W C, padding trimmed
             if i > 0 and 0 < overlap < sample.shape[0] and write >= overlap:
                 if (i - 1) in spans:                                                      # both sides are on this rank
                     final[write - overlap:write] = transforms.blend_overlapping_frames(
@@ -199,7 +204,7 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
         # batch boundaries that carry an overlap blend -- a function of the plans alone, so every rank derives the same list
         # and the point-to-point exchange posts matching sends and receives
         boundaries = [i for i, plan in enumerate(plans) if i > 0 and 0 < overlap < plan.end - plan.start and starts[i] >= overlap]
-        for i, head in exchange_heads(heads, boundaries, (overlap, true_h, true_w, 3), dt).items():    # (heads travel in the storage dtype)
+        for i, head in exchange_heads(heads, boundaries, (overlap, true_h, true_w, 3), odt).items():    # (heads travel in the frames' dtype)
             if (i - 1) in spans and i not in spans:
                 w = starts[i]
                 final[w - overlap:w] = transforms.blend_overlapping_frames(final[w - overlap:w], head.to(final), overlap)
@@ -210,14 +215,14 @@ def upscale(images_thwc: torch.Tensor, runner, text_pos: torch.Tensor, *, resolu
             continue
         sample = final[w0:w1].permute(0, 3, 1, 2)
         if color_correction != "none":
-            ref = prepare_batch(images, plans[i], resolution, max_resolution).to(dt).permute(1, 0, 2, 3)   # T C H W
+            ref = prepare_batch(images, plans[i], resolution, max_resolution).to(odt).permute(1, 0, 2, 3)   # T C H W
             if i > 0 and overlap > 0:
                 ref = ref[overlap:]
             ref = ref[:sample.shape[0], :, :true_h, :true_w]
             if color_correction not in colorfix.METHODS:
                 raise ValueError(f"Unknown color correction method: {color_correction}")
             sample = colorfix.METHODS[color_correction](sample, ref)
-        final[w0:w1] = sample.permute(0, 2, 3, 1).clamp(-1, 1).mul(0.5).add(0.5).to(dt)
+        final[w0:w1] = sample.permute(0, 2, 3, 1).clamp(-1, 1).mul(0.5).add(0.5).to(odt)
     if prepend_frames > 0:
         final = final[prepend_frames:]
         spans = {i: (max(a - prepend_frames, 0), max(b - prepend_frames, 0)) for i, (a, b) in spans.items()}

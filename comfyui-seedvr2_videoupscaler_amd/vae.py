@@ -119,12 +119,15 @@ def _cos_ramp(n: int) -> Optional[torch.Tensor]:
 class VideoVAEEngine:
     def __init__(self, cfg: VAEConfig, state_dict: Dict[str, torch.Tensor], ops,
                  act_budget_bytes: int = 12 << 30, merge_upsamplers: bool = True, merge_causal_head: bool = True,
-                 trunk_fp32: bool = True, branch_fp32: bool = False, tile_streams: int = 2):
-        """``tile_streams``: spatial tiles of a tiled encode / decode are independent until the blend (attn_video_vae.py:1302-1630),
-        so on the GPU they are issued round-robin onto this many HIP streams: the HBM-bound passes of one tile (GroupNorm apply,
-        statistics, layout copies) and its under-filled low-resolution launches run in the shadow of another tile's MFMA-bound
-        convolutions -- the conv kernel holds one wave per SIMD, so a second kernel's waves fit beside it.  The blends are issued
-        on the caller's stream in tile order, so the result is bit-identical to ``tile_streams=1`` (_run_tiles).
+                 trunk_fp32: Optional[bool] = None, branch_fp32: Optional[bool] = None, tile_streams: int = 1,
+                 trunk_store: Optional[str] = None, branch_store: Optional[str] = None):
+        """``tile_streams`` (default 1): spatial tiles of a tiled encode / decode are independent until the blend
+        (attn_video_vae.py:1302-1630), so they CAN be issued round-robin onto several HIP streams, the HBM-bound passes of one tile
+        (GroupNorm apply, statistics, layout copies) in the shadow of another tile's MFMA-bound convolutions; the blends are issued
+        on the caller's stream in tile order, so the result is bit-identical to one stream (_run_tiles; tested).  MEASURED on
+        MI355X at BASELINE config 3, round 4, same box: 9.89 s per step on one stream, 9.85 s on two, 9.87 s on three -- the launches
+        time-slice (every kernel's duration doubles) instead of overlapping: the chip is power-limited, idle issue slots of the conv
+        kernel are not free capacity (profiles/r4_tile_streams_ab.txt).  Kept as an option, off by default.
         ``merge_upsamplers``: run the spatial-only upsampler (upscale_conv + pixel shuffle + 3x3x3 conv) as four sub-pixel
         convs over its low-resolution input (subpixel.py) -- same function, 12 instead of 28 MACs per output voxel and channel
         pair, no upsampled intermediate; False keeps the reference's two steps.
@@ -133,21 +136,32 @@ class VideoVAEEngine:
         terms (hi + lo, exact to 2^-17): 18 instead of 27 MACs per voxel and channel pair, same result.  (Rounding the sum
         to ONE bf16 term -- and merging frame 1's two replicated taps the same way -- would save three times as much but costs
         0.4-0.8 dB against the fp32 reference: measured, not shipped.)  False keeps three taps on every frame.
-        ``trunk_fp32``: the residual trunk (ResnetBlock3D / attention outputs, attn_video_vae.py:311-362, 615-665) is stored in
-        fp32 wherever its only readers are GroupNorm and the next residual add; it is stored bf16 only where a conv reads it
-        directly as an MFMA operand (in front of a down/upsampler or a shortcut conv): 5 instead of 17 bf16 roundings on the
-        decoder's skip path, +2.6 dB against the fp32 reference (tools/error_budget.py) for ~1.5 x the bytes of the
-        GroupNorm-apply reads and the conv2 epilogue stores.  False keeps every activation in the ops' storage dtype.
-        ``branch_fp32`` (with ``trunk_fp32``; off by default): conv1's output inside a block -- read only by norm2 -- is stored
-        fp32 as well, so a block rounds to bf16 exactly where an MFMA consumes the value (the two GroupNorm-apply outputs).
-        Measured on one MI355X (tools/branch_ab.py, bench.py --branch): +0.4 dB end to end (51.15 vs 50.74 dB on
-        pipeline_small), +0.6 dB on the decoder alone (52.5 vs 51.9 dB), for +2.1 % step time at BASELINE config 3."""
+        ``trunk_store`` / ``branch_store`` ("bf16" | "h16" | "fp32"; default "h16" for both on a bf16 backend): how the tensors
+        that are NOT MFMA operands are held.  The residual TRUNK (ResnetBlock3D / attention / shortcut-conv outputs,
+        attn_video_vae.py:311-362, 615-665) is read only by GroupNorm and the next residual add; it is stored narrow (bf16) exactly
+        where a conv reads it directly as an MFMA operand (in front of a down/upsampler or a shortcut conv): 5 instead of 17 bf16
+        roundings on the decoder's skip path.  The BRANCH tensor is conv1's output inside a block, read only by norm2.
+        "h16" (round 4, ABI v6; ops.H16): an IEEE half holding x * 2^-6 -- 11 significant bits in bf16's two bytes, range +-4.2e6.
+        On the production-width chain (tests/golden/pipeline_prod.pt, CPU double of the C ABI, tools/error_budget.py): trunk / branch
+        fp32 / fp32 50.01 dB, h16 / h16 49.99 dB, fp32 / bf16 (round 3's default) 49.76 dB, bf16 / bf16 (round 2) 48.20 dB -- h16 is
+        as good as fp32 at half the bytes: GroupNorm-apply reads 2 instead of 4 B per element, conv2 epilogues store half as much
+        (round 3's fp32 trunk cost +2.4 % of the BASELINE config 3 step, its fp32 branch another +2.1 %).
+        ``trunk_fp32`` / ``branch_fp32`` (rounds 2-3, kept for A/B): True -> "fp32", False -> "bf16" for the respective tensor."""
         self.cfg, self.ops = cfg, ops
-        self.trunk_dtype = torch.float32 if trunk_fp32 else None      # None: the ops' activation dtype
-        self.branch_wide = bool(trunk_fp32 and branch_fp32)
+        kinds = {"bf16": None, "h16": torch.float16, "fp32": torch.float32}      # None: the ops' activation dtype
+        # (the exact-arithmetic CPU double of the C ABI -- act_dtype fp32, host-logic tests -- keeps everything in its one dtype)
+        default = "h16" if getattr(ops, "act_dtype", BF16) == BF16 else "bf16"
+        if trunk_store is None:
+            trunk_store = default if trunk_fp32 is None else ("fp32" if trunk_fp32 else "bf16")
+        if branch_store is None:
+            branch_store = (default if trunk_store != "bf16" else "bf16") if branch_fp32 is None else \
+                ("fp32" if (branch_fp32 and trunk_store != "bf16") else "bf16")
+        self.trunk_store, self.branch_store = trunk_store, branch_store
+        self.trunk_dtype, self.branch_dtype = kinds[trunk_store], kinds[branch_store]
         self.device = ops.device
         self.act_budget_bytes = act_budget_bytes
         self.tile_streams = int(tile_streams)
+        self.sample_dtype = None            # EXPERIMENT: dtype of the decoder's output frames (None: activation dtype)
         self._streams = []
         self._edges = {}
         sd, dev = state_dict, ops.device
@@ -298,7 +312,7 @@ class VideoVAEEngine:
         output when the conv kernel can fuse them into its epilogue (else None) -> ``(out, stats)``.
         ``wide``: store the output in the trunk dtype (fp32 under ``trunk_fp32``) instead of the activation dtype."""
         ops = self.ops
-        odt = self.trunk_dtype if wide else None
+        odt = wide if isinstance(wide, torch.dtype) else (self.trunk_dtype if wide else None)
         T, H, W, Cin = x.shape
         assert Cin == cw.cin, (cw.name, Cin, cw.cin)
         if first and cw.head is not None:
@@ -318,7 +332,7 @@ class VideoVAEEngine:
         if resid is not None and tuple(resid.shape) != (To, Ho, Wo, cw.cout):
             raise ValueError(f"{cw.name}: residual {tuple(resid.shape)} does not match the output {(To, Ho, Wo, cw.cout)}")
         out = ops.empty(To, Ho, Wo, cw.cout, dtype=odt)
-        f32 = out.dtype == torch.float32
+        f32 = out.dtype in (torch.float32, torch.float16)      # (a wide store: fp32, or the h16 format -- ops derives the kind from out.dtype)
         K = cw.w.shape[1]
         epi = EPI_RESID_GATE if resid is not None else EPI_BIAS
         stats = None
@@ -362,7 +376,7 @@ class VideoVAEEngine:
             res = self.ops.gemm(x[:n_in], sub.w, out[o:o + To], N=cw.cout, K=sub.w.shape[1], bias=cw.b,
                                 epilogue=EPI_RESID_GATE if r is not None else EPI_BIAS, resid=r, conv=geom,
                                 ldc=cw.cout, ldr=cw.cout, gn_groups=self.cfg.norm_num_groups if gn else 0, W_frag=sub.w_frag,
-                                out_f32=out.dtype == torch.float32)
+                                out_f32=out.dtype in (torch.float32, torch.float16))
             if gn:
                 stats.append(res[1])
         if not st.get("__last_slice__", False):
@@ -387,12 +401,13 @@ class VideoVAEEngine:
         ``wide``: the output stays on the residual trunk (only GroupNorm and the next residual add read it) -> trunk dtype;
         False: a conv reads it as an MFMA operand -> activation dtype."""
         h = self._gn(rb.norm1, x, True, x_stats)
-        h, hs = self._conv(rb.conv1, h, st, first, gn=True, wide=self.branch_wide)
+        h, hs = self._conv(rb.conv1, h, st, first, gn=True, wide=self.branch_dtype if self.branch_dtype is not None else False)
         h = self._gn(rb.norm2, h, True, hs)
         if rb.shortcut is not None and x.dtype != self.ops.act_dtype:
             raise RuntimeError(f"{rb.shortcut.name}: a shortcut conv reads its block input as an MFMA operand; the producer must store it "
                                f"in the activation dtype, got {x.dtype}")
-        sc = self._conv(rb.shortcut, x, st, first) if rb.shortcut is not None else x
+        # (the shortcut's output is only ever the residual of conv2: a trunk tensor)
+        sc = self._conv(rb.shortcut, x, st, first, wide=True) if rb.shortcut is not None else x
         return self._conv(rb.conv2, h, st, first, resid=sc, gn=True, wide=wide)
 
     def _attention(self, ab: _Attn, x):
@@ -437,7 +452,7 @@ class VideoVAEEngine:
             att = ops.empty(T * n, Cc)
             ops.attn_varlen(qkv, att, rows, rows, cu, n, 1, Cc, 1.0 / math.sqrt(Cc))
         ops.gemm(att, ab.out_w, out, N=Cc, K=Cc, M=T * n, bias=ab.out_b, epilogue=EPI_RESID_GATE,
-                 resid=x, ldc=Cc, ldr=Cc, out_f32=out.dtype == torch.float32)
+                 resid=x, ldc=Cc, ldr=Cc, out_f32=out.dtype in (torch.float32, torch.float16))
         return out
 
     def _mid(self, m, x, st, first, x_stats=None, wide=True):
@@ -476,7 +491,7 @@ class VideoVAEEngine:
         carry = kt - 1 if rz == 1 else 1                   # low-resolution frames the next slice needs
         outs = [subpixel.output_frames(t0 + tl, rz) for tl in range(T)]
         y = ops.empty(sum(len(o) for o in outs), 2 * H, 2 * W, cw.cout, dtype=self.trunk_dtype if wide else None)
-        f32 = y.dtype == torch.float32
+        f32 = y.dtype in (torch.float32, torch.float16)
         # GroupNorm statistics of y fused into the launches' epilogues where the ops offer it (one partial buffer for all of them)
         shared = {"frames": y.shape[0]} if hasattr(ops, "gn_shared_stats") else None
 
@@ -566,7 +581,7 @@ class VideoVAEEngine:
                             raise RuntimeError("keep_frames cuts a temporal slice that is not the clip's last one")
                         h, hs = h[:n], (hs[:n] if hs is not None else None)
         h = self._gn(self.dec_norm_out, h, True, hs)
-        return self._conv(self.dec_conv_out, h, st, first)
+        return self._conv(self.dec_conv_out, h, st, first, wide=self.sample_dtype if self.sample_dtype is not None else False)
 
     # ------------------------------------------------------------------ temporal slicing (slicing_encode / _decode)
     def _slices(self, T: int, unit: int, frames_per_slice: int) -> List[Tuple[int, int]]:
@@ -761,7 +776,7 @@ class VideoVAEEngine:
                 self._edge_dev((x1 - x0) * s, ow, x0 > 0, x1 < W)
             self._run_tiles(jobs, compute, blend)
             acc, cnt = buf["acc"], buf["cnt"]
-            y = ops.empty(*acc.shape)
+            y = ops.empty(*acc.shape, dtype=self.sample_dtype)
             ops.blend_finalize(acc, cnt, y, 1.0, 0.0)
         y = y.permute(3, 0, 1, 2)                           # layout only: [3, T, H, W]
         return y[:, 0] if y.shape[1] == 1 else y

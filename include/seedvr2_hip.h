@@ -22,6 +22,14 @@ extern "C" {
 #define SVR_ABI_VERSION 6
 
 /* ---- GEMM / implicit-GEMM convolution epilogues ------------------------------------------ */
+/* Storage kinds of activation tensors that are NOT MFMA operands (svr_gemm_args.out_f32 / .resid_f32, the x_f32 arguments).
+ * SVR_STORE_H16 (ABI v6): an IEEE half holding x * 2^-6 -- 11 significant bits for bf16's bytes, range +-4.2e6, absolute floor
+ * 3.8e-6: the residual trunk of the VAE (ResnetBlock3D / attention outputs, attn_video_vae.py:311-362, 615-665) and a block's
+ * conv1 output, read only by GroupNorm and residual adds.  Every MFMA operand is bf16. */
+#define SVR_STORE_BF16 0
+#define SVR_STORE_FP32 1
+#define SVR_STORE_H16  2
+
 #define SVR_EPI_BIAS        0   /* C = acc + bias                                              */
 #define SVR_EPI_BIAS_SILU   1   /* C = silu(acc + bias)                 embedding.py:56-61     */
 #define SVR_EPI_RESID_GATE  2   /* C = resid + gate * (acc + bias)      mmsr_block.py:108-109,

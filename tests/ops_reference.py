@@ -14,6 +14,19 @@ import torch
 import torch.nn.functional as F
 
 BF16 = torch.bfloat16
+H16, H16_SCALE = torch.float16, 2.0 ** -6      # the "h16" storage format of <package>.ops: IEEE half holding x * 2^-6
+
+
+def _ld(t):
+    """stored tensor -> fp32 values"""
+    return t.float() * (1.0 / H16_SCALE) if t.dtype == H16 else t.float()
+
+
+def _st(values, like):
+    """fp32 values -> the storage format of tensor ``like``"""
+    return (values * H16_SCALE).to(H16) if like.dtype == H16 else values.to(like.dtype)
+
+
 EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU, EPI_BIAS_GELU = 0, 1, 2, 3, 4
 
 
@@ -84,21 +97,21 @@ class TorchOps:
                 if gate is not None:
                     res = res * gate[:N].float()
                 if resid is not None:
-                    res = res + resid.reshape(M, -1)[:, :N].float()
+                    res = res + _ld(resid.reshape(M, -1)[:, :N])
         if phase is not None:
             g = conv
             ts = getattr(phase, "t_stride", 1)
             o4 = out.reshape(-1, 2 * g.Ho, 2 * g.Wo, N)
-            o4[0:(g.To - 1) * ts + 1:ts, phase.py::2, phase.px::2, :] = res.reshape(g.To, g.Ho, g.Wo, N).to(out.dtype)
+            o4[0:(g.To - 1) * ts + 1:ts, phase.py::2, phase.px::2, :] = _st(res.reshape(g.To, g.Ho, g.Wo, N), out)
             return out
         if ps is not None:
             r = res.reshape(ps.F, ps.H, ps.W, 2, 2, ps.rz, ps.C).permute(0, 5, 1, 3, 2, 4, 6)
             r = r.reshape(ps.F * ps.rz, 2 * ps.H, 2 * ps.W, ps.C)
             if ps.drop_first:
                 r = torch.cat([r[:1], r[2:]], dim=0)
-            out.copy_(r.reshape(out.shape).to(out.dtype))
+            out.copy_(_st(r.reshape(out.shape), out))
             return out
-        out.reshape(M, -1)[:, :res.shape[1]].copy_(res.to(out.dtype))
+        out.reshape(M, -1)[:, :res.shape[1]].copy_(_st(res, out))
         return out
 
     # ------------------------------------------------------------------ DiT side kernels
@@ -174,7 +187,7 @@ class TorchOps:
     # ------------------------------------------------------------------ VAE side kernels
     def groupnorm_stats(self, x, stats, groups):
         T, H, W, C = x.shape
-        xg = x.double().reshape(T, H * W, groups, C // groups)
+        xg = _ld(x).double().reshape(T, H * W, groups, C // groups) if x.dtype == H16 else x.double().reshape(T, H * W, groups, C // groups)
         stats[..., 0] = xg.sum(dim=(1, 3))
         stats[..., 1] = xg.pow(2).sum(dim=(1, 3))
         return stats
@@ -187,7 +200,7 @@ class TorchOps:
         rstd = 1.0 / torch.sqrt(var + eps)
         mean_c = mean.repeat_interleave(C // groups, dim=1).float()[:, None, None, :]
         rstd_c = rstd.repeat_interleave(C // groups, dim=1).float()[:, None, None, :]
-        y = (x.float() - mean_c) * rstd_c * gamma + beta
+        y = (_ld(x) - mean_c) * rstd_c * gamma + beta
         if silu:
             y = F.silu(y)
         out.copy_(y.to(out.dtype))

@@ -219,8 +219,11 @@ def test_pipeline_identity_runner_reproduces_transformed_input(total, bs, ov, un
                      temporal_overlap=ov, prepend_frames=prepend, color_correction="none")
     th, tw = tr.true_target_dims(20, 28, 40)
     want = tr.side_resize(images.permute(0, 3, 1, 2), 40).clamp(0, 1)[:, :, :th, :tw].permute(0, 2, 3, 1)
-    assert out.shape == (total, th, tw, 3) and out.dtype == torch.bfloat16
-    assert float((out.float() - want).abs().max()) < 1.2e-2              # bf16 storage of [0, 1] values
+    assert out.shape == (total, th, tw, 3) and out.dtype == torch.float32   # (the decoded frames are held in fp32: ComfyUI's IMAGE dtype)
+    assert float((out.float() - want).abs().max()) < 1.2e-2              # bf16 storage of the [-1, 1] input / decoder output
+    out_bf = pl.upscale(images, _IdentityRunner(), torch.zeros(58, 8), resolution=40, batch_size=bs, uniform_batch_size=uniform,
+                        temporal_overlap=ov, prepend_frames=prepend, color_correction="none", output_dtype=None)
+    assert out_bf.dtype == torch.bfloat16 and float((out_bf.float() - want).abs().max()) < 1.2e-2      # rounds 2-3: storage dtype throughout
     # colour correction against the input itself must keep the identity result (within bf16)
     out2 = pl.upscale(images, _IdentityRunner(), torch.zeros(58, 8), resolution=40, batch_size=bs, uniform_batch_size=uniform,
                       temporal_overlap=ov, prepend_frames=prepend, color_correction="wavelet")

@@ -137,7 +137,7 @@ def test_reference_phase_functions_drive_the_hip_runner(hip):
     got = _run_reference_phases(rl.reference_phases(), runner, images, text, g).float().cpu()
     want = pipeline.upscale(images.cuda(), runner, text.cuda(), resolution=g["resolution"], batch_size=g["batch_size"],
                             uniform_batch_size=g["uniform_batch_size"], temporal_overlap=g["temporal_overlap"],
-                            color_correction="lab", seed=42, skip_trimmed_frames=False).float().cpu()
+                            color_correction="lab", seed=42, skip_trimmed_frames=False, output_dtype=None).float().cpu()
     assert got.shape == want.shape == tuple(g["out"].shape)
     d = (got - want).abs()
     e, q999 = rel_err(got, want), float(d.flatten().kthvalue(int(d.numel() * 0.999)).values)

@@ -59,7 +59,7 @@ def test_reference_phase_functions_over_the_product_runner_equal_the_product_pip
     got = _run_reference_phases(rl.reference_phases(), runner, images, text, dt, g)
     want = pipeline.upscale(images, runner, text.to(dt), resolution=g["resolution"], batch_size=g["batch_size"],
                             uniform_batch_size=g["uniform_batch_size"], temporal_overlap=g["temporal_overlap"],
-                            color_correction="lab", seed=42)
+                            color_correction="lab", seed=42, output_dtype=None)      # (frames in the storage dtype, as the phase code keeps them)
     assert got.shape == want.shape == tuple(g["out"].shape) and got.dtype == dt
     # same runner, same seeds; the glue between the runner calls is this repo's restatement on one side (transforms.py,
     # colorfix.py: <= 2e-6 from the reference text in fp32, tests/test_glue.py) and the reference's own text on the other

@@ -113,16 +113,21 @@ def run_vae17(rounded, g, sd, mg, **eng_kw):
 
 def run_pipeline(rounded, g, mg, **eng_kw):
     config, weights, dit, vae, runner, pipeline = (sub(n) for n in ("config", "weights", "dit", "vae", "runner", "pipeline"))
-    dcfg, vcfg = config.DIT_TINY, config.VAEConfig(block_out_channels=tuple(g["vae_channels"]))
+    dcfg, vcfg = getattr(config, g.get("dit", "DIT_TINY")), config.VAEConfig(block_out_channels=tuple(g["vae_channels"]))
+    tile = (dict(encode_tiled=True, decode_tiled=True, encode_tile_size=tuple(g["vae_tile"]), decode_tile_size=tuple(g["vae_tile"]),
+                 encode_tile_overlap=tuple(g["vae_tile_overlap"]), decode_tile_overlap=tuple(g["vae_tile_overlap"]))
+            if g.get("vae_tile") else {})
     if rounded is None:
         ops_v = ops_d = TorchOps("cpu", act_dtype=BF16)
     else:
         ops_v, ops_d = BudgetOps(rounded), BudgetOps(rounded)
         ops_d._dit = True
-    r = runner.VideoDiffusionInfer(runner.default_config(dcfg, vcfg))
+    r = runner.VideoDiffusionInfer(runner.default_config(dcfg, vcfg), **tile)
     dit_kw = {k: eng_kw.pop(k) for k in ("hid_fp32",) if k in eng_kw}
     r.dit = dit.NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, seed=g["seed_dit"]), ops_d, **dit_kw)
+    sample_dtype = eng_kw.pop("sample_dtype", None)
     r.vae = vae.VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, seed=g["seed_vae"]), ops_v, **eng_kw)
+    r.vae.sample_dtype = sample_dtype
     images = torch.rand(g["frames"], g["hw"][0], g["hw"][1], 3, generator=torch.Generator().manual_seed(g["seed_images"]))
     out = pipeline.upscale(images, r, weights.synth_text_embedding().float(), resolution=g["resolution"],
                            batch_size=g["batch_size"], uniform_batch_size=g["uniform_batch_size"],
@@ -135,11 +140,12 @@ def main():
     ap.add_argument("--fixture", default="vae_tiled17")
     ap.add_argument("--quick", action="store_true", help="only: everything rounded / candidates")
     ap.add_argument("--engine-only", action="store_true", help="only the rows that run the engines in their real storage regimes")
+    ap.add_argument("--rows", default="", help="comma-separated substrings: only the rows whose name contains one of them")
     args = ap.parse_args()
     from oracle import make_golden as mg
     weights, config = sub("weights"), sub("config")
     g = torch.load(os.path.join(GOLDEN, args.fixture + ".pt"), weights_only=True)
-    if args.fixture == "pipeline_small":
+    if args.fixture.startswith("pipeline"):
         sites = VAE_SITES + DIT_SITES
         run = lambda rounded, **kw: run_pipeline(rounded, g, mg, **kw)
     else:
@@ -147,7 +153,12 @@ def main():
         sd = weights.synth_vae_state_dict(config.VAE_V3, seed=g["seed_weights"])
         run = lambda rounded, **kw: run_vae17(rounded, g, sd, mg, **kw)
     allr = set(sites)
-    rows = [("ENGINE, bf16 storage, trunk_fp32=False (round 2)", None, dict(trunk_fp32=False)),
+    rows = [(f"ENGINE store trunk={t} branch={b}", None, dict(trunk_store=t, branch_store=b))
+            for t, b in (("fp32", "h16"), ("h16", "h16"), ("h16", "bf16"), ("fp32", "fp32"))]
+    rows += [("ENGINE sample fp32, store trunk=h16 branch=h16", None, dict(trunk_store="h16", branch_store="h16", sample_dtype=torch.float32)),
+             ("ENGINE sample fp32, store trunk=fp32 branch=bf16", None, dict(trunk_store="fp32", branch_store="bf16", sample_dtype=torch.float32)),
+             ("ENGINE glue fp32 only, store trunk=fp32 branch=bf16", None, dict(trunk_store="fp32", branch_store="bf16"))]
+    rows += [("ENGINE, bf16 storage, trunk_fp32=False (round 2)", None, dict(trunk_fp32=False)),
             ("ENGINE, bf16 storage, trunk_fp32=True, branch_fp32=False", None, dict(trunk_fp32=True, branch_fp32=False)),
             ("ENGINE, bf16 storage, trunk_fp32=True, branch_fp32=True (product)", None, dict(trunk_fp32=True, branch_fp32=True)),
             ("every store bf16 (product)", allr, {}), ("no store rounded (weights bf16 only, sub-pixel merge)", set(), {}),
@@ -160,6 +171,8 @@ def main():
              ("every store bf16, two-step upsamplers", allr, dict(merge_upsamplers=False))]
     for name, rounded, kw in rows:
         if args.engine_only and rounded is not None:
+            continue
+        if args.rows and not any(t in name for t in args.rows.split(",")):
             continue
         e, p = run(rounded, **dict(kw))
         print(f"{args.fixture:16s} {name:70s} rel-err {e:.3e}   PSNR(nominal) {p:6.2f} dB", flush=True)

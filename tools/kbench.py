@@ -270,6 +270,11 @@ def main():
         report("groupnorm_stats 5x1024^2x128", sec, bytes_=x.numel() * 2)
         sec = timeit(lambda: ops.groupnorm_apply(x, y, stats, gam, gam, 32, 1e-6, True), args.reps)
         report("groupnorm_apply+silu 5x1024^2x128", sec, bytes_=x.numel() * 4)
+        for name, xw, nbytes in (("h16", (x.float() * 2.0 ** -6).to(torch.float16), 4), ("fp32", x.float(), 6)):     # wide trunk inputs
+            sec = timeit(lambda: ops.groupnorm_apply(xw, y, stats, gam, gam, 32, 1e-6, True), args.reps)
+            report(f"groupnorm_apply+silu 5x1024^2x128, {name} input", sec, bytes_=x.numel() * nbytes)
+            sec = timeit(lambda: ops.groupnorm_stats(xw, stats, 32), args.reps)
+            report(f"groupnorm_stats 5x1024^2x128, {name} input", sec, bytes_=x.numel() * (nbytes - 2))
         del x, y
         M, d = 291600, 2560
         x = rnd(M, d)
