@@ -198,12 +198,14 @@ def main():
                          "that fall on the replicated frame (VideoVAEEngine(merge_causal_head=False))")
     ap.add_argument("--bf16-trunk", action="store_true",
                     help="A/B: round 2's storage regime -- the VAE's residual trunk and the DiT's residual stream in bf16 instead of "
-                         "fp32 (48.1 instead of 51.2 dB end to end against the fp32 reference)")
+                         "h16 / fp32 (48.2 instead of 50 dB end to end against the fp32 reference at production width)")
+    ap.add_argument("--trunk", choices=["h16", "fp32", "bf16"], default=None,
+                    help="A/B: storage of the VAE's residual trunk (VideoVAEEngine(trunk_store=...)); default: the engine's (h16; round 3: fp32)")
     ap.add_argument("--tile-streams", type=int, default=None,
                     help="A/B: HIP streams the VAE's spatial tiles are issued on (VideoVAEEngine(tile_streams=...); default: the "
                          "engine's, 2; 1 = every launch on one stream)")
-    ap.add_argument("--branch", choices=["fp32", "bf16"], default=None,
-                    help="A/B: storage of conv1's output inside a VAE block (VideoVAEEngine(branch_fp32=...)); default: the engine's")
+    ap.add_argument("--branch", choices=["h16", "fp32", "bf16"], default=None,
+                    help="A/B: storage of conv1's output inside a VAE block (VideoVAEEngine(branch_store=...)); default: the engine's (h16; round 3: bf16)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -60,11 +60,25 @@ SVR_DEVICE uint4 pack8h(const float* o) {                       // fp32 values -
     v.z = pack2h_raw(o[4] * H16_SCALE, o[5] * H16_SCALE); v.w = pack2h_raw(o[6] * H16_SCALE, o[7] * H16_SCALE);
     return v;
 }
-SVR_DEVICE void unpack8h(const uint4& v, float* o) {            // 8 h16 -> the fp32 values they stand for
+// half -> float as a plain fp32 register value.  The empty asm keeps hipcc from folding the conversion into v_fma_mix_f32 / packed
+// mixed-precision forms of the consumer: with those, the fused GroupNorm statistics of conv_halo2_kernel<8, thin>'s h16 instance
+// came out DIFFERENT FROM RUN TO RUN on MI355X (outputs identical; found by bench.py's determinism guard, isolated with
+// tools/debug_thin_stats.py, gpurun r4e -> r4f) -- the conversions are a handful of VALU instructions in HBM-bound epilogues.
+SVR_DEVICE float h2f(_Float16 h) {
+    float t = (float)h;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+SVR_DEVICE void unpack8h_raw(const uint4& v, float* o) {        // 8 h16 -> 8 floats STILL scaled by 2^-6
     const f16x2_t a = __builtin_bit_cast(f16x2_t, v.x), b = __builtin_bit_cast(f16x2_t, v.y),
                   c = __builtin_bit_cast(f16x2_t, v.z), d = __builtin_bit_cast(f16x2_t, v.w);
-    o[0] = (float)a[0] * H16_INV; o[1] = (float)a[1] * H16_INV; o[2] = (float)b[0] * H16_INV; o[3] = (float)b[1] * H16_INV;
-    o[4] = (float)c[0] * H16_INV; o[5] = (float)c[1] * H16_INV; o[6] = (float)d[0] * H16_INV; o[7] = (float)d[1] * H16_INV;
+    o[0] = h2f(a[0]); o[1] = h2f(a[1]); o[2] = h2f(b[0]); o[3] = h2f(b[1]);
+    o[4] = h2f(c[0]); o[5] = h2f(c[1]); o[6] = h2f(d[0]); o[7] = h2f(d[1]);
+}
+SVR_DEVICE void unpack8h(const uint4& v, float* o) {            // 8 h16 -> the fp32 values they stand for
+    unpack8h_raw(v, o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= H16_INV;
 }
 
 // 8 consecutive activations starting at element index e8 (a multiple of 8) of a tensor stored as KIND: 0 bf16, 1 fp32, 2 h16

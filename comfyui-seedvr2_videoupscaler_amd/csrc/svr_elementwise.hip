@@ -309,10 +309,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __rest
     auto act = [&](float u) { return apply_silu ? silu(u) : u; };
     auto raw8 = [&](const uint4& v, float* o) {         // 16 bytes of a 2-byte format -> 8 floats (h16: still scaled by 2^-6)
         if constexpr (XF32 == 2) {
-            const f16x2_t a = __builtin_bit_cast(f16x2_t, v.x), b = __builtin_bit_cast(f16x2_t, v.y),
-                          c = __builtin_bit_cast(f16x2_t, v.z), d = __builtin_bit_cast(f16x2_t, v.w);
-            o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)b[0]; o[3] = (float)b[1];
-            o[4] = (float)c[0]; o[5] = (float)c[1]; o[6] = (float)d[0]; o[7] = (float)d[1];
+            unpack8h_raw(v, o);
         } else {
             unpack8(v, o);
         }

@@ -92,7 +92,7 @@ SVR_DEVICE void epilogue_store(const svr_gemm_args& a, const f32x4 accv, const f
         } else if (a.resid && a.resid_f32 == SVR_STORE_H16) {
             const _Float16* rp = (const _Float16*)a.resid + (int64_t)m * a.ldr + n;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += (float)rp[r] * H16_INV;
+            for (int r = 0; r < 4; ++r) if (n + r < a.N) v[r] += h2f(rp[r]) * H16_INV;
         } else if (a.resid) {
             const bf16_t* rp = (const bf16_t*)a.resid + (int64_t)m * a.ldr + n;
             if (full) {

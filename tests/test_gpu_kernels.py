@@ -946,9 +946,10 @@ def test_vae_attention_gemm_path_matches_fused_kernel(hip, T, H, W):
     eng = vae_mod.VideoVAEEngine(cfg, sd, hip)
     ab = eng.enc_mid[1]
     x = (torch.randn(T, H, W, 128, device="cuda") * 0.7).bfloat16()
-    got = eng._attention(ab, x).float()
+    h2f = sub("ops").h16_to_float                          # (the block's output is a trunk tensor: h16 by default)
+    got = h2f(eng._attention(ab, x))
     eng.attn_as_gemm = False
-    fused = eng._attention(ab, x).float()
+    fused = h2f(eng._attention(ab, x))
     # fp32 torch restatement of the block (GroupNorm -> q,k,v -> softmax(q k^T / sqrt(C)) v -> out proj + residual)
     name = "encoder.mid_block.attentions.0"
     w = {k: sd[f"{name}.{k}"].float().cuda() for k in
@@ -981,7 +982,8 @@ def test_vae_attention_at_config2_shape_512_channels_65536_tokens(hip):
     g = torch.Generator(device="cuda").manual_seed(11)
     x = (torch.randn(1, H, W, C, device="cuda", generator=g) * 0.7).bfloat16()
     assert eng.attn_as_gemm
-    got = eng._attention(ab, x).float()
+    h2f = sub("ops").h16_to_float                          # (the block's output is a trunk tensor: h16 by default)
+    got = h2f(eng._attention(ab, x))
     name = "decoder.mid_block.attentions.0"
     w = {k: sd[f"{name}.{k}"].float().cuda() for k in
          ("group_norm.weight", "group_norm.bias", "to_q.weight", "to_q.bias", "to_k.weight", "to_k.bias",
@@ -999,7 +1001,7 @@ def test_vae_attention_at_config2_shape_512_channels_65536_tokens(hip):
     print(f"VAE mid-block attention, 512 channels x 65536 tokens (config 2): rel-err {e:.3e}, max abs {float(err.max()):.3e}")
     assert e < 4e-3 and err.max() < 0.08
     eng.attn_as_gemm = False
-    fused = eng._attention(ab, x).float()
+    fused = h2f(eng._attention(ab, x))
     ef = float((fused - want).norm() / want.norm())
     print(f"  fused d = 512 kernel at the same shape: rel-err {ef:.3e}")
     assert ef < 4e-3 and (got - fused).abs().max() < 0.08

@@ -21,20 +21,28 @@ def main():
     cfg = config.VAE_V3
     eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg), hip)
     g = torch.Generator().manual_seed(3)
-    x = (torch.rand(3, 13, 64, 64, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 17
+    size = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    x = (torch.rand(3, frames, size, size, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    if len(sys.argv) > 3:
+        eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg), hip, trunk_store=sys.argv[3], branch_store=sys.argv[4])
+    print(f"{frames} frames {size}x{size}, trunk {eng.trunk_store} branch {eng.branch_store}")
 
     rec = {}
     orig_conv, orig_gn = eng._conv, eng._gn
 
-    def conv_hook(cw, xin, st, first, resid=None):
-        out = orig_conv(cw, xin, st, first, resid)
-        rec.setdefault(cw.name, []).append(out.float().clone())
+    def conv_hook(cw, xin, st, first, *a, **kw):
+        out = orig_conv(cw, xin, st, first, *a, **kw)
+        o, stats = out if isinstance(out, tuple) else (out, None)
+        rec.setdefault(cw.name, []).append(ops.h16_to_float(o).clone())
+        if stats is not None:
+            rec.setdefault(cw.name + "  [fused stats]", []).append(stats.float().clone())
         return out
 
     gn_count = [0]
 
-    def gn_hook(nm, xin, silu):
-        out = orig_gn(nm, xin, silu)
+    def gn_hook(nm, xin, silu, stats=None):
+        out = orig_gn(nm, xin, silu, stats)
         rec.setdefault(f"gn{gn_count[0]}", []).append(out.float().clone())
         gn_count[0] += 1
         return out
@@ -44,7 +52,6 @@ def main():
     def run(fps):
         rec.clear()
         outs = []
-        nslices = len(eng._slices(13, 4, fps if fps else 1 << 20))
         # GN hook names must line up across slices: reset the counter per slice via wrapper
         orig_slice = eng._encoder_slice
 
@@ -57,8 +64,8 @@ def main():
         eng._encoder_slice = orig_slice
         return out, {k: torch.cat(v, dim=0) for k, v in rec.items()}
 
-    a, ra = run(None)
-    a2, ra2 = run(None)
+    a, ra = run(1 << 20)
+    a2, ra2 = run(1 << 20)
     b, rb = run(4)
     print(f"run-to-run (unsliced twice): {rel(a2, a):.3e}")
     print(f"sliced vs unsliced:          {rel(b, a):.3e}")
