@@ -100,43 +100,77 @@ __global__ void ada_combine_kernel(const bf16_t* __restrict__ emb, const bf16_t*
 }
 
 // ------------------------------------------------------------------------------------------------
-// q/k RMSNorm(128, affine) + interleaved-pair RoPE on 126 of 128 dims, in place.  One wave per
-// (row, head); lane l owns the pair (2l, 2l+1).  mmattn.py:207-208, rope.py:118-126.
+// q/k RMSNorm(128, affine) + interleaved-pair RoPE on 3 * n_freq pairs of the 64, in place.  mmattn.py:207-208, rope.py:118-126.
+// Round 4: one THREAD per 16-byte chunk (8 dims = 4 pairs) of a q or k head vector, 16 lanes per vector, the sum of squares
+// reduced with four DPP adds inside the 16-lane row; a block walks the vectors in a grid-stride loop, so a thread keeps its
+// chunk of the norm weight and the (axis, frequency) of its four pairs in registers and only the position-dependent cos / sin
+// are looked up per row.  (The first version spent one wave on 256 B -- 373 M threads at BASELINE config 3 -- and moved
+// 2.8 TB/s; this is a plain streaming pass.)
 // ------------------------------------------------------------------------------------------------
+SVR_DEVICE float row16_sum(float v) {                   // sum over the 16 lanes of a DPP row, result in every lane
+    auto dpp_add = [](float x, auto ctrl) {
+        constexpr int CTRL = decltype(ctrl)::value;
+        const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true);
+        return x + __builtin_bit_cast(float, t);
+    };
+    v = dpp_add(v, std::integral_constant<int, 0xB1>{});     // quad_perm [1, 0, 3, 2]
+    v = dpp_add(v, std::integral_constant<int, 0x4E>{});     // quad_perm [2, 3, 0, 1]
+    v = dpp_add(v, std::integral_constant<int, 0x141>{});    // row_half_mirror: the other quad of the half row
+    v = dpp_add(v, std::integral_constant<int, 0x140>{});    // row_mirror: the other half row
+    return v;
+}
+
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16_t* __restrict__ qkv, int64_t rows, int heads,
                                                           const int16_t* __restrict__ pos, int t_offset,
                                                           const float* __restrict__ cos_tab,
                                                           const float* __restrict__ sin_tab, int n_pos, int n_freq,
                                                           const float* __restrict__ wq, const float* __restrict__ wk,
                                                           float eps) {
-    const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= rows * heads) return;
-    const int64_t row = item / heads;
-    const int head = (int)(item - row * heads);
-    const int64_t ld = (int64_t)3 * heads * 128;
-    uint32_t* qp = (uint32_t*)(qkv + row * ld + (int64_t)head * 128) + lane;
-    uint32_t* kp = (uint32_t*)(qkv + row * ld + (int64_t)(heads + head) * 128) + lane;
-    const uint32_t qraw = *qp, kraw = *kp;
-    float q0 = bf2f((bf16_t)(qraw & 0xffff)), q1 = bf2f((bf16_t)(qraw >> 16));
-    float k0 = bf2f((bf16_t)(kraw & 0xffff)), k1 = bf2f((bf16_t)(kraw >> 16));
-    const float qs = wave_sum(q0 * q0 + q1 * q1);
-    const float ks = wave_sum(k0 * k0 + k1 * k1);
-    const float qi = rsqrtf(qs * (1.0f / 128.0f) + eps), ki = rsqrtf(ks * (1.0f / 128.0f) + eps);
-    q0 = q0 * qi * wq[2 * lane]; q1 = q1 * qi * wq[2 * lane + 1];
-    k0 = k0 * ki * wk[2 * lane]; k1 = k1 * ki * wk[2 * lane + 1];
-    const int axis = lane / n_freq;
-    if (axis < 3) {
-        const int fi = lane - axis * n_freq;
-        int p = pos[row * 3 + axis] + (axis == 0 ? t_offset : 0);
-        p = min(max(p, 0), n_pos - 1);
-        const float c = cos_tab[p * n_freq + fi], s = sin_tab[p * n_freq + fi];
-        const float nq0 = q0 * c - q1 * s, nq1 = q1 * c + q0 * s;
-        const float nk0 = k0 * c - k1 * s, nk1 = k1 * c + k0 * s;
-        q0 = nq0; q1 = nq1; k0 = nk0; k1 = nk1;
+    // vector v = (row * heads + head) * 2 + (0: q | 1: k); a block takes 16 consecutive vectors per step (even base: a thread's
+    // q/k role is fixed)
+    const int sub16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int is_k = grp & 1;
+    const int d0 = sub16 * 8;
+    const float* wsrc = (is_k ? wk : wq) + d0;
+    const float4 w0 = *(const float4*)wsrc, w1 = *(const float4*)(wsrc + 4);
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    int axis[4], fi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pl = sub16 * 4 + i;                    // pair index 0..63
+        axis[i] = pl / n_freq;
+        fi[i] = pl - axis[i] * n_freq;
     }
-    *qp = pack2bf(q0, q1);
-    *kp = pack2bf(k0, k1);
+    const int64_t nvec = rows * heads * 2;
+    const int64_t ld = (int64_t)3 * heads * 128;
+    for (int64_t v = ((int64_t)blockIdx.x * 16 + grp); v < nvec; v += (int64_t)gridDim.x * 16) {
+        const int64_t rh = v >> 1;
+        const int64_t row = rh / heads;
+        const int head = (int)(rh - row * heads);
+        uint4* p = (uint4*)(qkv + row * ld + (int64_t)(is_k * heads + head) * 128 + d0);
+        const uint4 raw = *p;
+        float x[8];
+        unpack8(raw, x);
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+        ss = row16_sum(ss);
+        const float inv = rsqrtf(ss * (1.0f / 128.0f) + eps);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = x[e] * inv * wv[e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (axis[i] < 3) {
+                int pp = pos[row * 3 + axis[i]] + (axis[i] == 0 ? t_offset : 0);
+                pp = min(max(pp, 0), n_pos - 1);
+                const float c = cos_tab[pp * n_freq + fi[i]], sn = sin_tab[pp * n_freq + fi[i]];
+                const float a0 = x[2 * i], a1 = x[2 * i + 1];
+                x[2 * i] = a0 * c - a1 * sn;
+                x[2 * i + 1] = a1 * c + a0 * sn;
+            }
+        }
+        *p = pack8(x);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
