@@ -147,8 +147,8 @@ int svr_qknorm_rope(void* qkv, int64_t rows, int32_t heads, const int16_t* pos, 
     StreamDeviceGuard on_stream_device(stream);
     if (rows <= 0) return 0;
     if (n_freq * 3 > 64) return fail("svr_qknorm_rope: at most 21 frequencies per axis (head_dim 128)");
-    // 16 head vectors (q or k of a (row, head) pair) per block and step; 16 blocks per CU, the rest in the grid-stride loop
-    const int64_t nblk = (rows * heads * 2 + 15) / 16;
+    // 8 rows (q and k of each: 16 groups of 16 lanes) per block and step; 16 blocks per CU, the rest in the grid-stride loop
+    const int64_t nblk = (rows + 7) / 8;
     const unsigned grid = (unsigned)std::min<int64_t>(nblk, (int64_t)device_cu_count() * 16);
     hipLaunchKernelGGL(qknorm_rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (bf16_t*)qkv, rows, heads, pos, t_offset, cos_tab, sin_tab, n_pos, n_freq, wq, wk, eps);

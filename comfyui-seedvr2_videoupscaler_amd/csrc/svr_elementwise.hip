@@ -126,8 +126,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16_t* __restrict__ q
                                                           const float* __restrict__ sin_tab, int n_pos, int n_freq,
                                                           const float* __restrict__ wq, const float* __restrict__ wk,
                                                           float eps) {
-    // vector v = (row * heads + head) * 2 + (0: q | 1: k); a block takes 16 consecutive vectors per step (even base: a thread's
-    // q/k role is fixed)
+    // item = (row, q | k): a 16-lane group walks the `heads` head vectors of its item, four at a time (their loads in flight
+    // together), so the position-dependent cos / sin of its four pairs are gathered ONCE per row and reused for every head
+    // (the first streaming version gathered them per head vector and stayed latency-bound at 2.6 TB/s: gpurun r4h)
     const int sub16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int is_k = grp & 1;
     const int d0 = sub16 * 8;
@@ -141,35 +142,44 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(bf16_t* __restrict__ q
         axis[i] = pl / n_freq;
         fi[i] = pl - axis[i] * n_freq;
     }
-    const int64_t nvec = rows * heads * 2;
     const int64_t ld = (int64_t)3 * heads * 128;
-    for (int64_t v = ((int64_t)blockIdx.x * 16 + grp); v < nvec; v += (int64_t)gridDim.x * 16) {
-        const int64_t rh = v >> 1;
-        const int64_t row = rh / heads;
-        const int head = (int)(rh - row * heads);
-        uint4* p = (uint4*)(qkv + row * ld + (int64_t)(is_k * heads + head) * 128 + d0);
-        const uint4 raw = *p;
-        float x[8];
-        unpack8(raw, x);
-        float ss = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-        ss = row16_sum(ss);
-        const float inv = rsqrtf(ss * (1.0f / 128.0f) + eps);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = x[e] * inv * wv[e];
+    for (int64_t row = (int64_t)blockIdx.x * 8 + (grp >> 1); row < rows; row += (int64_t)gridDim.x * 8) {
+        float c[4], sn[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            c[i] = 1.f; sn[i] = 0.f;                      // (pairs beyond 3 * n_freq pass through)
             if (axis[i] < 3) {
                 int pp = pos[row * 3 + axis[i]] + (axis[i] == 0 ? t_offset : 0);
                 pp = min(max(pp, 0), n_pos - 1);
-                const float c = cos_tab[pp * n_freq + fi[i]], sn = sin_tab[pp * n_freq + fi[i]];
-                const float a0 = x[2 * i], a1 = x[2 * i + 1];
-                x[2 * i] = a0 * c - a1 * sn;
-                x[2 * i + 1] = a1 * c + a0 * sn;
+                c[i] = cos_tab[pp * n_freq + fi[i]];
+                sn[i] = sin_tab[pp * n_freq + fi[i]];
             }
         }
-        *p = pack8(x);
+        bf16_t* base = qkv + row * ld + (int64_t)is_k * heads * 128 + d0;
+        for (int h0 = 0; h0 < heads; h0 += 4) {
+            uint4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) raw[u] = h0 + u < heads ? *(const uint4*)(base + (int64_t)(h0 + u) * 128) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float x[8];
+                unpack8(raw[u], x);
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+                ss = row16_sum(ss);
+                const float inv = rsqrtf(ss * (1.0f / 128.0f) + eps);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = x[e] * inv * wv[e];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float a0 = x[2 * i], a1 = x[2 * i + 1];
+                    x[2 * i] = axis[i] < 3 ? a0 * c[i] - a1 * sn[i] : a0;
+                    x[2 * i + 1] = axis[i] < 3 ? a1 * c[i] + a0 * sn[i] : a1;
+                }
+                if (h0 + u < heads) *(uint4*)(base + (int64_t)(h0 + u) * 128) = pack8(x);
+            }
+        }
     }
 }
 

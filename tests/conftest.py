@@ -19,7 +19,12 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     """`-m gpu` (the driver's round-end run) spends its seconds on the shipped path: tests marked `variants` (non-default kernel
-    generations / A-B knobs) run only when the -m expression names them (`-m variants`)."""
+    generations / pure A-B knobs) run only when the -m expression names them (`-m variants`).  Every kernel production can still
+    REACH stays in the default set: the first-generation attention kernel through test_attn_varlen's 2049-row window and its
+    head_dim-512 case (and the config-2 VAE attention test with attn_as_gemm off), the generic implicit-GEMM conv through the
+    strided / 1x1x1 / ragged-Cout rows of CONV_CASES under conv_impl 0, the run-time conv epilogue body through the fp32-trunk
+    option sets of tests/test_gpu_wide_trunk.py.  What `variants` holds is only what no default route selects: conv_impl 1 on
+    3x3 stride-1 shapes, conv_rows 4, the LDS-weight halo kernel, attn_impl 1 on windows the second kernel serves."""
     if "variants" in (config.getoption("-m") or ""):
         return
     keep, drop = [], []

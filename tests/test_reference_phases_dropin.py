@@ -8,7 +8,8 @@ torch double of the C ABI, CPU) exactly as they drive the reference's runner:
   * with the noise the golden was made with injected, result == tests/golden/pipeline_small.pt (the reference's models + glue
     driven by oracle/pipeline_oracle.py) -- which pins that oracle's straight-line loop against the real phase code as well.
 
-Needs /root/reference (build container); skipped on the GPU box."""
+Needs the reference: the checkout at /root/reference (build container) or oracle/_ref, the same modules byte-compiled by
+oracle/build_ref.py (travels to the GPU box, where tests/test_gpu_ingest_dropin.py runs these phases over the HIP engines)."""
 import os
 
 import pytest
@@ -18,7 +19,7 @@ from conftest import sub, rel_err, GOLDEN
 from ops_reference import TorchOps
 from oracle import reference_loader as rl
 
-pytestmark = pytest.mark.skipif(not rl.available(), reason="needs the reference checkout at /root/reference")
+pytestmark = pytest.mark.skipif(not rl.available(), reason="needs the reference (checkout or oracle/_ref)")
 
 
 def _runner(act_dtype, g, exact_upsamplers):

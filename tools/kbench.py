@@ -282,6 +282,17 @@ def main():
         sc = torch.ones(d, dtype=torch.float32, device=dev)
         sec = timeit(lambda: ops.rmsnorm_mod(x, y, 1e-5, scale=sc, shift=sc), args.reps)
         report("rmsnorm_mod 291600x2560", sec, bytes_=x.numel() * 4)
+        xf = x.float()
+        sec = timeit(lambda: ops.rmsnorm_mod(xf, y, 1e-5, scale=sc, shift=sc), args.reps)
+        report("rmsnorm_mod 291600x2560, fp32 input (the NaDiT residual stream)", sec, bytes_=x.numel() * 6)
+        del x, y, xf
+        heads = 20
+        qkv = rnd(M, 3 * heads * 128)
+        pos = torch.randint(0, 60, (M, 3), device=dev, dtype=torch.int16)
+        cos_t, sin_t = torch.rand(128, 21, device=dev), torch.rand(128, 21, device=dev)
+        w = torch.ones(128, dtype=torch.float32, device=dev)
+        sec = timeit(lambda: ops.qknorm_rope(qkv, heads, pos, 58, cos_t, sin_t, w, w, 1e-5), args.reps)
+        report("qknorm_rope 291600 x 20 heads (q and k in place)", sec, bytes_=M * 2 * heads * 128 * 4)
     return out
 
 
