@@ -76,6 +76,8 @@ def make_profiled_ops(device):
             conv = kw.get("conv")
             if conv is not None:
                 flops = 2.0 * conv.To * conv.Ho * conv.Wo * kw["N"] * conv.k[0] * conv.k[1] * conv.k[2] * conv.Cin
+                if getattr(kw.get("phase"), "quad", None) is not None:
+                    flops *= 4.0                         # one launch = the four spatial phases of a sub-pixel upsampler
             else:
                 flops = 2.0 * (kw.get("M") or A.shape[0]) * kw["N"] * kw["K"]
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -82,6 +82,16 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
         const int xcd = bid & 7, j = bid >> 3, q = nwg >> 3, r = nwg & 7;
         tl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
+    // quad launch (svr_phase_scatter.quad): the spatial phase is the fastest tile index; everything that depends on the phase --
+    // pads, weights, biases, output position -- is taken from the per-phase arrays (wave-uniform: scalar loads)
+    const bool quad = a.phase.enabled && a.phase.quad != 0;
+    int qp = 0;
+    if (quad) { qp = tl & 3; tl >>= 2; }
+    const int ph_py = quad ? (qp >> 1) : a.phase.py, ph_px = quad ? (qp & 1) : a.phase.px;
+    const int pad_h = quad ? 1 - ph_py : g.ph, pad_w = quad ? 1 - ph_px : g.pw;
+    const void* const w_frag = quad ? a.phase.W_frag4[qp] : a.W_frag;
+    const float* const bias_p = quad ? a.phase.bias4[qp] : a.bias;
+    const float* const bias_border_p = quad ? a.phase.bias_border4[qp] : a.phase.bias_border;
     const int tn = tl % tiles_n;
     int rr = tl / tiles_n;
     const int tx = rr % tiles_x; rr /= tiles_x;
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
     for (int q = 0; q < CS_PIECES; ++q) {
         const int row = q * (NT / 4) + srow;
         const int hy = row / CS_HX, hx = row - hy * CS_HX;
-        const int y = y0 - g.ph + hy, x = x0 - g.pw + hx;
+        const int y = y0 - pad_h + hy, x = x0 - pad_w + hx;
         const bool ok = (row < CS_ROWS) & ((unsigned)y < (unsigned)g.H) & ((unsigned)x < (unsigned)g.W);
         poff[q] = ok ? (uint32_t)(y * g.W + x) : 0xffffffffu;
         akeys |= (uint32_t)(spos ^ ((hx >> 2) & 3)) << (2 * q);
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
 
     // ---- weights straight from global memory in fragment order ([32-cout block][interval][k-step][lane][8 bf16])
     const int64_t nstride = (int64_t)P * 2048;
-    const char* wp0 = (const char*)a.W_frag + (int64_t)(n0 / 32 + wn * 2) * nstride;       // wave-uniform
+    const char* wp0 = (const char*)w_frag + (int64_t)(n0 / 32 + wn * 2) * nstride;         // wave-uniform
     const char* wp1 = wp0 + nstride;
     const int voff = lane * 16;
     auto wload = [&](bf16x8 (&w)[NTW][2], int k) {
@@ -289,14 +299,14 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
     const int hi4 = hi * 4;
     const int n = n0 + (tid & 15) * 8;
     f32x4 bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) {
-        bias_lo = *(const f32x4*)(a.bias + n);
-        bias_hi = *(const f32x4*)(a.bias + n + 4);
+    if (bias_p) {
+        bias_lo = *(const f32x4*)(bias_p + n);
+        bias_hi = *(const f32x4*)(bias_p + n + 4);
     }
-    const int py = a.phase.enabled ? a.phase.py : 0, px = a.phase.enabled ? a.phase.px : 0;
+    const int py = a.phase.enabled ? ph_py : 0, px = a.phase.enabled ? ph_px : 0;
     const int up = a.phase.enabled ? 2 : 1, ts = a.phase.enabled ? a.phase.t_stride : 1;
-    const int yb = a.phase.py ? g.H - 1 : 0, xb = a.phase.px ? g.W - 1 : 0;
-    const float* btab = a.phase.enabled ? a.phase.bias_border : nullptr;
+    const int yb = py ? g.H - 1 : 0, xb = px ? g.W - 1 : 0;
+    const float* btab = a.phase.enabled ? bias_border_p : nullptr;
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;      // fused GroupNorm statistics of the stored values (columns n .. n + 3, n + 4 .. n + 7)
     // (the body is instantiated per output kind -- bf16 | fp32 | h16, the wide residual trunk -- so its loops carry no option branches)
     auto ep_body = [&](auto o32c) {
@@ -417,12 +427,21 @@ static bool conv_sub_gn_ok(const svr_gemm_args& a) {         // fused statistics
 
 static bool conv_sub_eligible(const svr_gemm_args& a) {
     const svr_conv_geom& g = a.conv;
-    return g_conv_sub && g.enabled && a.W_frag != nullptr && g.kh == 2 && g.kw == 2 && g.sh == 1 && g.sw == 1 && g.st == 1 &&
-           (unsigned)g.ph <= 1u && (unsigned)g.pw <= 1u && g.Ho == g.H && g.Wo == g.W && g.Cin % 32 == 0 && g.kt >= 1 && g.kt <= 3 &&
+    const bool quad = a.phase.enabled && a.phase.quad != 0;
+    bool ptrs = true;
+    if (quad) {
+        for (int p = 0; p < 4; ++p)
+            ptrs = ptrs && a.phase.W_frag4[p] != nullptr && (!a.phase.bias4[p] || ((uintptr_t)a.phase.bias4[p] % 16) == 0) &&
+                   (!a.phase.bias_border4[p] || ((uintptr_t)a.phase.bias_border4[p] % 16) == 0);
+    } else {
+        ptrs = a.W_frag != nullptr && (unsigned)g.ph <= 1u && (unsigned)g.pw <= 1u && (!a.bias || ((uintptr_t)a.bias % 16) == 0) &&
+               (!a.phase.bias_border || ((uintptr_t)a.phase.bias_border % 16) == 0);
+    }
+    return g_conv_sub && g.enabled && ptrs && g.kh == 2 && g.kw == 2 && g.sh == 1 && g.sw == 1 && g.st == 1 &&
+           g.Ho == g.H && g.Wo == g.W && g.Cin % 32 == 0 && g.kt >= 1 && g.kt <= 3 &&
            g.To == g.T + g.pt - g.kt + 1 && !a.ps.enabled && a.epilogue == SVR_EPI_BIAS && !a.resid && !a.gate &&
            (!a.gn_partial || conv_sub_gn_ok(a)) && (a.N % 128) == 0 && (a.phase.enabled || (a.ldc == a.N)) &&
-           (int64_t)g.H * g.W * g.Cin * 2 < (int64_t)1 << 32 && ((uintptr_t)a.C % 16) == 0 &&
-           (!a.bias || ((uintptr_t)a.bias % 16) == 0) && (!a.phase.bias_border || ((uintptr_t)a.phase.bias_border % 16) == 0);
+           (int64_t)g.H * g.W * g.Cin * 2 < (int64_t)1 << 32 && ((uintptr_t)a.C % 16) == 0;
 }
 
 // partial blocks per OUTPUT frame of the fused statistics (0: not produced); a phase launch fills a quarter of them
@@ -434,7 +453,8 @@ static int conv_sub_gn_blocks(const svr_gemm_args& a) {
 
 static int launch_conv_sub(const svr_gemm_args& a, hipStream_t s) {
     const svr_conv_geom& g = a.conv;
-    const int tiles = g.To * ((g.H + CS_TY - 1) / CS_TY) * ((g.W + CS_TX - 1) / CS_TX) * (a.N / 128);
+    const int tiles = g.To * ((g.H + CS_TY - 1) / CS_TY) * ((g.W + CS_TX - 1) / CS_TX) * (a.N / 128) *
+                      (a.phase.enabled && a.phase.quad ? 4 : 1);
     static uint64_t lds_attr_done = 0;               // per device (svr_common.h)
     {
         const int e = set_max_dynamic_lds((const void*)conv_sub_kernel, 160 * 1024, lds_attr_done);

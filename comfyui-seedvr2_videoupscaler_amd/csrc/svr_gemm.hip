@@ -1735,6 +1735,9 @@ int gemm_route(const svr_gemm_args& a, const char** why) {
             (a.phase.t_stride != 1 && a.phase.t_stride != 2)) {
             *why = "svr_gemm_bf16: phase scatter needs a stride-1 same-size conv without ps / residual / SwiGLU (fused statistics: sub-pixel conv kernel only)"; return -1;
         }
+        if (a.phase.quad && !conv_sub_eligible(a)) {
+            *why = "svr_gemm_bf16: a quad phase launch is served by the sub-pixel conv kernel only ((kt, 2, 2) taps, four fragment-ordered weight copies, bias epilogue)"; return -1;
+        }
     }
     if (a.gn_partial && conv_gn_blocks(a) == 0) { *why = "svr_gemm_bf16: gn_partial set but this launch cannot produce fused GroupNorm statistics"; return -1; }
     if (conv_thin_eligible(a)) return SVR_KERNEL_CONV_THIN_IN;

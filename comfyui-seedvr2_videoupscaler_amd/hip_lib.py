@@ -43,7 +43,8 @@ class PixelShuffle(C.Structure):
 
 class PhaseScatter(C.Structure):
     _fields_ = [("enabled", C.c_int32), ("py", C.c_int32), ("px", C.c_int32), ("t_stride", C.c_int32),
-                ("bias_border", C.c_void_p)]
+                ("bias_border", C.c_void_p), ("quad", C.c_int32), ("reserved_", C.c_int32),
+                ("W_frag4", C.c_void_p * 4), ("bias4", C.c_void_p * 4), ("bias_border4", C.c_void_p * 4)]
 
 
 class GemmArgs(C.Structure):

@@ -67,6 +67,10 @@ class PhaseScatter:
     px: int
     bias_border: Optional[torch.Tensor] = None
     t_stride: int = 1
+    # quad launch (ABI v6): ALL four spatial phases in one launch -- a list of four (py, px, W, bias, bias_border, W_frag) in
+    # any order; py / px / bias_border above and the call's own W / bias / W_frag / conv pads then describe phase (0, 0) only
+    # as a fallback (HipOps.gemm issues the four launches itself when the library does not take the quad form)
+    quad: Optional[list] = None
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -119,6 +123,17 @@ def fill_gemm_args(A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gat
         if out.numel() < ((conv.To - 1) * phase.t_stride + 1) * 4 * conv.Ho * conv.Wo * N or not out.is_contiguous():
             raise ValueError("phase scatter: out must be the dense [frames, 2*Ho, 2*Wo, N] tensor from the launch's first frame on")
         a.phase.enabled, a.phase.py, a.phase.px, a.phase.t_stride = 1, int(phase.py), int(phase.px), int(phase.t_stride)
+        if phase.quad is not None:
+            if len(phase.quad) != 4 or sorted((q[0], q[1]) for q in phase.quad) != [(0, 0), (0, 1), (1, 0), (1, 1)]:
+                raise ValueError("phase scatter: quad needs the four phases (0,0) (0,1) (1,0) (1,1)")
+            a.phase.quad = 1
+            for qpy, qpx, qw, qb, qbb, qfrag in phase.quad:
+                i = 2 * int(qpy) + int(qpx)
+                if qfrag is None or qfrag.numel() < N * K or (qbb is not None and tuple(qbb.shape) != (3, N)):
+                    raise ValueError("phase scatter: every quad phase needs its fragment-ordered weights (and a [3, N] border bias)")
+                a.phase.W_frag4[i] = ptr(chk(qfrag, BF16, "W_frag"))
+                a.phase.bias4[i] = None if qb is None else ptr(chk(qb, torch.float32, "bias"))
+                a.phase.bias_border4[i] = None if qbb is None else ptr(chk(qbb, torch.float32, "bias_border"))
         if phase.bias_border is not None:
             if tuple(phase.bias_border.shape) != (3, N):
                 raise ValueError("phase scatter: bias_border must be [3, N]")
@@ -155,6 +170,7 @@ class HipOps:
 
     name = "hip"
     act_dtype = BF16          # storage dtype of activations
+    phase_quad = True         # gemm(phase=PhaseScatter(quad=[...])): the four phases of a sub-pixel upsampler in one launch
 
     def __init__(self, device="cuda:0"):
         self.device = torch.device(device)
@@ -218,6 +234,14 @@ class HipOps:
         calls gn_shared_stats() after the last -- the launches then return ``out`` only."""
         if phase is not None and gn_groups and gn_shared is None:
             raise ValueError("phase scatter: fused statistics through gn_shared")
+        if phase is not None and phase.quad is not None and not self._quad_ok(A, W, out, N, K, conv, phase, out_f32):
+            # the library does not take this geometry as one launch: four phase launches (same results, same order)
+            import dataclasses
+            for qpy, qpx, qw, qb, qbb, qfrag in sorted(phase.quad, key=lambda q: (q[0], q[1])):
+                g1 = dataclasses.replace(conv, pad=(conv.pad[0], 1 - qpy, 1 - qpx))
+                self.gemm(A, qw, out, N=N, K=K, bias=qb, conv=g1, phase=PhaseScatter(qpy, qpx, qbb, phase.t_stride), W_frag=qfrag,
+                          out_f32=out_f32, gn_groups=gn_groups, gn_shared=gn_shared)
+            return out
         a, M = fill_gemm_args(A, W, out, N=N, K=K, M=M, bias=bias, epilogue=epilogue, gate=gate, resid=resid, out_f32=out_f32,
                               conv=conv, ps=ps, lda=lda, ldc=ldc, ldr=ldr, W_frag=W_frag, phase=phase,
                               zeros_ptr=self.zeros.data_ptr(), chk=self._chk)
@@ -251,6 +275,14 @@ class HipOps:
                                                             self._stream()), "svr_groupnorm_reduce")
             return out, stats
         return out
+
+    def _quad_ok(self, A, W, out, N, K, conv, phase, out_f32) -> bool:
+        """Does the library serve this quad phase launch with the sub-pixel conv kernel (svr_gemm_kernel_class)?"""
+        if any(q[5] is None for q in phase.quad):
+            return False
+        a, _ = fill_gemm_args(A, W, out, N=N, K=K, conv=conv, phase=phase, out_f32=out_f32, zeros_ptr=self.zeros.data_ptr(),
+                              chk=self._chk)
+        return hip_lib.KERNEL_CLASSES.get(int(self.lib.svr_gemm_kernel_class(C.byref(a)))) == "conv_subpixel"
 
     def gn_shared_stats(self, gn_shared: dict):
         """Statistics [frames, groups, 2] of a tensor whose launches shared ``gn_shared`` (gemm), or None when one of them could

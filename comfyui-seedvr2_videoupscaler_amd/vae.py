@@ -508,6 +508,18 @@ class VideoVAEEngine:
             else:
                 halo = mem[mem.shape[0] - pt:] if a == 0 else torch.cat([mem[mem.shape[0] - (pt - a):], x[:a]], 0).contiguous()
             geom_in = x[a:b]
+            if len(parts) == 4 and all(pp[5] is not None for pp in parts) and getattr(ops, "phase_quad", False):
+                # all four spatial phases in ONE launch (svr_phase_scatter.quad): the phase is the fastest tile index, so the
+                # four workgroups that stage the same low-resolution halo run side by side and three of them hit L2
+                py, px, w, bias, bb, frag = parts[0]
+                geom = Conv3dGeom(b - a, H, W, Cc, b - a, H, W, (n_src, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
+                kw = {}
+                if shared is not None:
+                    shared["frame0"] = base
+                    kw = dict(gn_groups=self.cfg.norm_num_groups, gn_shared=shared)
+                ops.gemm(geom_in, w, y[base:], N=cw.cout, K=w.shape[1], bias=bias, conv=geom,
+                         phase=PhaseScatter(py, px, bb, t_stride, quad=list(parts)), W_frag=frag, out_f32=f32, **kw)
+                return
             for py, px, w, bias, bb, frag in parts:
                 geom = Conv3dGeom(b - a, H, W, Cc, b - a, H, W, (n_src, 2, 2), (1, 1, 1), (pt, 1 - py, 1 - px), halo)
                 kw = {}

@@ -75,6 +75,17 @@ typedef struct svr_phase_scatter {
     const float* bias_border;   /* fp32 [3][N] or NULL: bias used INSTEAD of `bias` on the voxels whose window loses its
                                    border tap to the zero padding of the upsampled grid -- row yo == (py ? Ho-1 : 0):
                                    [0]; column xo == (px ? Wo-1 : 0): [1]; both: [2]                                  */
+    int32_t quad;               /* 1 (ABI v6): ONE launch computes all four spatial phases -- phase p = py * 2 + px takes its
+                                   fragment-ordered weights, bias and border bias from the arrays below and its spatial pads
+                                   (1 - py, 1 - px); py / px / bias_border above, conv.ph / conv.pw, W_frag and bias of the
+                                   launch are ignored.  The phase is the FASTEST index of the tile order, so the four
+                                   workgroups that stage the same low-resolution halo run next to each other on one XCD
+                                   (three of the four stagings come from L2 instead of HBM).  Served by the sub-pixel conv
+                                   kernel only (svr_gemm_kernel_class() == SVR_KERNEL_CONV_SUBPIXEL), refused otherwise.   */
+    int32_t reserved_;
+    const void* W_frag4[4];
+    const float* bias4[4];
+    const float* bias_border4[4];
 } svr_phase_scatter;
 
 typedef struct svr_gemm_args {

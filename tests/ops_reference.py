@@ -32,6 +32,7 @@ EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU, EPI_BIAS_GELU = 0, 1, 2, 3,
 
 class TorchOps:
     name = "torch-reference"
+    phase_quad = True
 
     def __init__(self, device="cpu", act_dtype=BF16):
         self.device = torch.device(device)
@@ -44,6 +45,13 @@ class TorchOps:
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
              out_f32=False, conv=None, ps=None, lda=None, ldc=None, ldr=None, gn_groups=0, W_frag=None, phase=None):
         """``gn_groups`` > 0: return ``(out, None)`` like a HIP launch whose kernel cannot fuse the statistics."""
+        if phase is not None and getattr(phase, "quad", None) is not None:       # the four phases of a quad launch, one by one
+            import dataclasses
+            for qpy, qpx, qw, qb, qbb, _ in phase.quad:
+                one = type(phase)(qpy, qpx, qbb, phase.t_stride)
+                self.gemm(A, qw, out, N=N, K=K, bias=qb, conv=dataclasses.replace(conv, pad=(conv.pad[0], 1 - qpy, 1 - qpx)),
+                          phase=one, out_f32=out_f32)
+            return (out, None) if gn_groups > 0 else out
         if gn_groups > 0:
             return self.gemm(A, W, out, N=N, K=K, M=M, bias=bias, epilogue=epilogue, gate=gate, resid=resid,
                              out_f32=out_f32, conv=conv, ps=ps, lda=lda, ldc=ldc, ldr=ldr, phase=phase), None

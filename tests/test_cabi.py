@@ -41,7 +41,8 @@ def test_struct_layout_matches_header():
     # svr_conv_geom: 18 int32 + 2 pointers; svr_pixel_shuffle: 7 int32
     assert ctypes.sizeof(hip_lib.ConvGeom) == 18 * 4 + 2 * 8
     assert ctypes.sizeof(hip_lib.PixelShuffle) == 7 * 4
-    assert ctypes.sizeof(hip_lib.PhaseScatter) == 4 * 4 + 8 and hip_lib.GemmArgs.phase.offset % 8 == 0
+    # svr_phase_scatter: 4 int32 + pointer + 2 int32 + 3 x 4 pointers (ABI v6: the quad launch)
+    assert ctypes.sizeof(hip_lib.PhaseScatter) == 4 * 4 + 8 + 2 * 4 + 12 * 8 and hip_lib.GemmArgs.phase.offset % 8 == 0
     assert hip_lib.GemmArgs.conv.offset % 8 == 0
 
 

@@ -456,7 +456,9 @@ def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, frag, T, H, W, Cin, Cou
     To = T + pt - kt + 1
     out = torch.full((To * ts, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=BF16)
     want = torch.full((To * ts, 2 * H, 2 * W, Cout), float("nan"), device="cuda", dtype=torch.float32)
+    out_quad = torch.full_like(out, float("nan"))
     for tz in range(ts):                                                           # temporal phase = first frame of the launch
+        quad = []
         for ph, (py, px) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
             w5 = rnd(Cout, Cin, kt, 2, 2, scale=1.0 / math.sqrt(Cin * 4 * kt), seed=20 + ph + 7 * tz)
             Wp = packing.pack_conv3d(w5, "cuda")
@@ -467,6 +469,14 @@ def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, frag, T, H, W, Cin, Cou
             # frag: the fragment-ordered weight copy selects the sub-pixel conv kernel (svr_conv_sub.hip; Cin % 64 == 0)
             Wf = hip.pack_conv_frag(Wp, kt, Cin, Cout, taps=(2, 2)) if frag else None
             assert Wf is not None or not frag
+            quad.append((py, px, Wp, bias, bb, Wf))
+            if ph == 3 and frag:
+                # the same four phases as ONE launch (svr_phase_scatter.quad: phase fastest in the tile order): same bits
+                q0 = quad[0]
+                g0 = opsmod.Conv3dGeom(T, H, W, Cin, To, H, W, (kt, 2, 2), (1, 1, 1), (pt, 1, 1), halo)
+                assert hip._quad_ok(x, q0[2], out_quad[tz:], Cout, q0[2].shape[1], g0, opsmod.PhaseScatter(0, 0, q0[4], ts, quad=quad), False)
+                hip.gemm(x, q0[2], out_quad[tz:], N=Cout, K=q0[2].shape[1], bias=q0[3], conv=g0, W_frag=q0[5],
+                         phase=opsmod.PhaseScatter(0, 0, q0[4], ts, quad=quad))
             hip.gemm(x, Wp, out[tz:], W_frag=Wf, **kw)
             ref.gemm(x, Wp, want[tz:], **kw)
             # independent check of the restatement on this phase: F.conv3d of the padded input + per-voxel bias
@@ -481,6 +491,8 @@ def test_conv_phase_scatter_subpixel(hip, ref, gemm_epi, frag, T, H, W, Cin, Cou
             assert rel_err(want[tz::ts, py::2, px::2], y + b) < 1e-5
     assert not torch.isnan(out.float()).any() and not torch.isnan(want).any()
     assert rel_err(out.float(), want) < TOL_BF16
+    if frag:
+        assert torch.equal(out_quad, out)
 
 
 @pytest.mark.parametrize("T,H,W,Cin,Cout,hf,kt,ts", [(3, 9, 11, 128, 128, 0, 3, 1), (2, 40, 70, 256, 256, 2, 3, 1), (3, 17, 33, 128, 256, 1, 2, 2),
@@ -515,6 +527,20 @@ def test_conv_subpixel_fused_groupnorm_statistics(hip, T, H, W, Cin, Cout, hf, k
                          W_frag=hip.pack_conv_frag(Wp, kt, Cin, Cout, taps=(2, 2)), gn_groups=G, gn_shared=shared)
         stats = hip.gn_shared_stats(shared)
         assert stats is not None and tuple(stats.shape) == (out.shape[0], G, 2)
+        # the same launches in their quad form (one launch per group): same output, same statistics, bit for bit
+        out_q = torch.zeros_like(out)
+        shared_q = {"frames": out.shape[0]}
+        for base, xin, hl, p_t, to_n, stride in groups:
+            quad = []
+            for ph, (py, px) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+                Wp = packing.pack_conv3d(rnd(Cout, Cin, kt, 2, 2, scale=1.0 / math.sqrt(Cin * 4 * kt), seed=20 + ph + base), "cuda")
+                quad.append((py, px, Wp, rnd(Cout, dtype=torch.float32, seed=30 + ph), rnd(3, Cout, dtype=torch.float32, seed=40 + ph),
+                             hip.pack_conv_frag(Wp, kt, Cin, Cout, taps=(2, 2))))
+            geom = opsmod.Conv3dGeom(xin.shape[0], H, W, Cin, to_n, H, W, (kt, 2, 2), (1, 1, 1), (p_t, 1, 1), hl)
+            shared_q["frame0"] = base
+            hip.gemm(xin, quad[0][2], out_q[base:], N=Cout, K=quad[0][2].shape[1], bias=quad[0][3], conv=geom, W_frag=quad[0][5],
+                     phase=opsmod.PhaseScatter(0, 0, quad[0][4], stride, quad=quad), gn_groups=G, gn_shared=shared_q)
+        assert torch.equal(out_q, out) and torch.equal(hip.gn_shared_stats(shared_q), stats)
         want = torch.empty(out.shape[0], G, 2, dtype=torch.float64, device="cuda")
         hip.groupnorm_stats(out, want, G)
         assert rel_err(stats[..., 0], want[..., 0]) < 1e-5 and rel_err(stats[..., 1], want[..., 1]) < 1e-6

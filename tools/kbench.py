@@ -205,6 +205,19 @@ def main():
             sec = timeit(lambda: ops.gemm(x, w, y, N=C, K=4 * kt * C, bias=b, conv=geom, W_frag=wf,
                                           phase=ops_mod.PhaseScatter(0, 0, bb, ts)), args.reps)
             report(name, sec, flops=2.0 * T * H * W * C * C * 4 * kt)
+            if wf is not None:
+                # the four spatial phases: as four launches (how rounds 2-3 ran them) and as ONE quad launch (phase fastest in the tile order)
+                quad = [(py, px, w, b, bb, wf) for py in (0, 1) for px in (0, 1)]
+
+                def four():
+                    for py, px, *_ in quad:
+                        gq = ops_mod.Conv3dGeom(T, H, W, C, T, H, W, (kt, 2, 2), (1, 1, 1), (kt - 1, 1 - py, 1 - px), halo)
+                        ops.gemm(x, w, y, N=C, K=4 * kt * C, bias=b, conv=gq, W_frag=wf, phase=ops_mod.PhaseScatter(py, px, bb, ts))
+                sec = timeit(four, args.reps)
+                report(name + " -- all four phases, four launches", sec, flops=4 * 2.0 * T * H * W * C * C * 4 * kt)
+                sec = timeit(lambda: ops.gemm(x, w, y, N=C, K=4 * kt * C, bias=b, conv=geom, W_frag=wf,
+                                              phase=ops_mod.PhaseScatter(0, 0, bb, ts, quad=quad)), args.reps)
+                report(name + " -- all four phases, ONE quad launch", sec, flops=4 * 2.0 * T * H * W * C * C * 4 * kt)
             del x, w, y
     if "attn" in only:
         windows, config = sub("windows"), sub("config")
