@@ -430,16 +430,16 @@ def main():
         # DESIGN.md section 6's falsifiable prediction for THIS launch (from the 1-GPU phase times of rounds 3-4): compute is
         # perfectly parallel over ranks, communication = direct xGMI transfers at ~64 GB/s per direction and link
         if world > 1 or sharded:
-            frame_bytes = H * W * 3 * 2
+            frame_bytes = H * W * 3 * (4 if sharded else 2)      # (the pipeline's frames are fp32, the runner's decode output bf16)
             if sharded:
-                per_batch_s, n_b = 44.7 / 8, len(plans)
+                per_batch_s, n_b = 41.2 / 8, len(plans)
                 comm = (frames * frame_bytes / max(world, 1)) / 64e9 + 0.001 * (n_b - 1)
                 res["predicted_s"] = {"per_step": math.ceil(n_b / world) * per_batch_s + (comm if world > 1 else 0.0),
-                                      "model": f"ceil({n_b} batches / {world} ranks) x 5.6 s per 17-frame batch (44.7 s / 8 on one GPU, "
-                                               "profiles/r3_bench_cfg4_1gpu.json) + gather of the clip over xGMI"}
+                                      "model": f"ceil({n_b} batches / {world} ranks) x 5.15 s per 17-frame batch (41.2 s / 8 on one GPU, "
+                                               "profiles/r4_bench_cfg4_1gpu.json) + gather of the clip over xGMI"}
             else:
-                res["predicted_s"] = {"per_step": 9.82 + (world - 1) * useful * frame_bytes / 64e9 / max(world - 1, 1) + 0.003,
-                                      "model": "the 1-GPU step (9.82 s, round 3) + all-gather: each link carries one rank's frames once"}
+                res["predicted_s"] = {"per_step": 9.45 + (world - 1) * useful * frame_bytes / 64e9 / max(world - 1, 1) + 0.003,
+                                      "model": "the 1-GPU step (9.36-9.60 s on four boxes, round 4) + all-gather: each link carries one rank's frames once"}
         if not sharded:
             dit_tf = f_dit["total"] / max(phase["dit"], 1e-9) / 1e9
             res.update({"dit_ms_per_step": phase["dit"], "vae_encode_ms": phase["encode"], "vae_decode_ms": phase["decode"],
