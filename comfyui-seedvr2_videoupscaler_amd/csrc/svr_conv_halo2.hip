@@ -277,7 +277,10 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             const int y = y0 + (tid >> 5), x = x0 + (tid & 31);
             char* rowp = smem + tid * TP;
             const int64_t fpix = (int64_t)g.H * g.W;
-#pragma unroll 4
+            // (all 27 gathers of a voxel in flight at once: with four at a time the gather phase was a chain of seven exposed L2
+            // latencies per workgroup -- kbench "thin": see profiles/r4_kbench_thin.txt)
+            uint2 vv[32];
+#pragma unroll
             for (int tap = 0; tap < 32; ++tap) {
                 uint2 v = make_uint2(0u, 0u);
                 if (tap < taps) {
@@ -293,8 +296,11 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
                         v = *(const uint2*)(basep + ((int64_t)f * fpix + (int64_t)ys * g.W + xs) * 8);
                     }
                 }
-                *(uint2*)(rowp + tap * 8) = v;
+                vv[tap] = v;
             }
+#pragma unroll
+            for (int tap = 0; tap < 32; tap += 2)
+                *(uint4*)(rowp + tap * 8) = make_uint4(vv[tap].x, vv[tap].y, vv[tap + 1].x, vv[tap + 1].y);
         }
         __syncthreads();
         const int nks = (taps * 4 + 15) >> 4;             // 16-wide k steps that hold real taps (7 for 3x3x3)

@@ -82,6 +82,20 @@ def main():
             sec = timeit(lambda: ops.gemm(x, w, y, N=Co, K=27 * Ci, bias=b, conv=geom, ldc=Co, W_frag=wf), args.reps)
             report(name, sec, flops=2.0 * T * H * W * Co * 27 * Ci)
             del x, w, y
+    if "thin" in only:
+        # encoder.conv_in: RGB padded to 4 channels -> 128, the im2col image of a patch built in LDS; output on the h16 trunk with
+        # fused GroupNorm statistics (how the engine launches it)
+        T, H, W, Co = 9, 1024, 1024, 128
+        x = rnd(T, H, W, 4)
+        w = packing.pack_conv3d(torch.randn(Co, 3, 3, 3, 3, generator=g, device=dev) / 9.0, dev, 4)
+        b = torch.zeros(Co, dtype=torch.float32, device=dev)
+        geom = ops_mod.Conv3dGeom(T, H, W, 4, T, H, W, (3, 3, 3), (1, 1, 1), (2, 1, 1), None)
+        for name, dt in (("h16", torch.float16), ("bf16", torch.bfloat16)):
+            y = torch.empty(T, H, W, Co, device=dev, dtype=dt)
+            sec = timeit(lambda: ops.gemm(x, w, y, N=Co, K=w.shape[1], bias=b, conv=geom, ldc=Co, gn_groups=32,
+                                          out_f32=dt != torch.bfloat16), args.reps)
+            report(f"thin conv_in 4->128 @9x1024^2, {name} output + fused statistics", sec, bytes_=T * H * W * (Co * 2 + 8))
+            del y
     if "gemm" in only:
         M = 291600
         for name, N, K, epi in (("gemm qkv 2560->7680", 7680, 2560, ops_mod.EPI_BIAS),
