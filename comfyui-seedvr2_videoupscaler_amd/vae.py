@@ -161,7 +161,8 @@ class VideoVAEEngine:
         self.device = ops.device
         self.act_budget_bytes = act_budget_bytes
         self.tile_streams = int(tile_streams)
-        self.sample_dtype = None            # EXPERIMENT: dtype of the decoder's output frames (None: activation dtype)
+        self.sample_dtype = None            # tools/error_budget.py only (CPU double): dtype of the decoder's own output tile; the HIP
+                                            # blend kernels take bf16 tiles, so the product leaves it at None (measured: +0.1 dB for fp32)
         self._streams = []
         self._edges = {}
         sd, dev = state_dict, ops.device

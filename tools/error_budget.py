@@ -153,14 +153,14 @@ def main():
         sd = weights.synth_vae_state_dict(config.VAE_V3, seed=g["seed_weights"])
         run = lambda rounded, **kw: run_vae17(rounded, g, sd, mg, **kw)
     allr = set(sites)
-    rows = [(f"ENGINE store trunk={t} branch={b}", None, dict(trunk_store=t, branch_store=b))
+    rows = [(f"ENGINE store trunk={t} branch={b}" + (" (round 4 as shipped)" if (t, b) == ("h16", "h16") else ""), None, dict(trunk_store=t, branch_store=b))
             for t, b in (("fp32", "h16"), ("h16", "h16"), ("h16", "bf16"), ("fp32", "fp32"))]
     rows += [("ENGINE sample fp32, store trunk=h16 branch=h16", None, dict(trunk_store="h16", branch_store="h16", sample_dtype=torch.float32)),
              ("ENGINE sample fp32, store trunk=fp32 branch=bf16", None, dict(trunk_store="fp32", branch_store="bf16", sample_dtype=torch.float32)),
              ("ENGINE glue fp32 only, store trunk=fp32 branch=bf16", None, dict(trunk_store="fp32", branch_store="bf16"))]
     rows += [("ENGINE, bf16 storage, trunk_fp32=False (round 2)", None, dict(trunk_fp32=False)),
-            ("ENGINE, bf16 storage, trunk_fp32=True, branch_fp32=False", None, dict(trunk_fp32=True, branch_fp32=False)),
-            ("ENGINE, bf16 storage, trunk_fp32=True, branch_fp32=True (product)", None, dict(trunk_fp32=True, branch_fp32=True)),
+            ("ENGINE, bf16 storage, trunk_fp32=True, branch_fp32=False (round 3 as shipped)", None, dict(trunk_fp32=True, branch_fp32=False)),
+            ("ENGINE, bf16 storage, trunk_fp32=True, branch_fp32=True (round 3 with its +2.1 % option)", None, dict(trunk_fp32=True, branch_fp32=True)),
             ("every store bf16 (product)", allr, {}), ("no store rounded (weights bf16 only, sub-pixel merge)", set(), {}),
             ("no store rounded, two-step upsamplers + three-tap head", set(), dict(merge_upsamplers=False, merge_causal_head=False))]
     if not args.quick:
