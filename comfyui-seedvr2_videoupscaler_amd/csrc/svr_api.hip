@@ -47,6 +47,7 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
     if (!strcmp(key, "gemm_epi")) { g_gemm_epi = value; return 0; }
     if (!strcmp(key, "gemm_w4")) { g_gemm_w4 = value; return 0; }
+    if (!strcmp(key, "gemm_w4r")) { g_gemm_w4r = value; return 0; }
     if (!strcmp(key, "conv_rows")) { g_conv_rows = value; return 0; }
     if (!strcmp(key, "conv_band")) { g_conv_band = value; return 0; }
     if (!strcmp(key, "conv_sub")) { g_conv_sub = value; return 0; }
@@ -89,7 +90,7 @@ const char* svr_gemm_kernel_name(int32_t cls) {
     switch (cls) {
         case SVR_KERNEL_NONE: return "none";
         case SVR_KERNEL_GEMM: return "svr::gemm_kernel";
-        case SVR_KERNEL_GEMM_PERSISTENT: return "svr::gemm_w4q_kernel";
+        case SVR_KERNEL_GEMM_PERSISTENT: return "svr::gemm_w4r_kernel";      // (gemm_w4q_kernel when the launch carries no W_frag)
         case SVR_KERNEL_CONV_HALO: return "svr::conv_halo2_kernel";
         case SVR_KERNEL_CONV_SUBPIXEL: return "svr::conv_sub_kernel";
         case SVR_KERNEL_CONV_THIN_IN: return "svr::conv_halo2_kernel<8, 2> (thin input)";
@@ -184,6 +185,15 @@ int svr_conv_pack_frag_taps(const void* W, void* out, int32_t N, int32_t K, int3
     hipLaunchKernelGGL(conv_pack_frag_taps_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)W, (uint4*)out, N, K, kt, kh, kw, Cin);
     return check(hipGetLastError(), "svr_conv_pack_frag_taps");
+}
+
+int svr_gemm_pack_frag(const void* W, void* out, int32_t N, int32_t K, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
+    if (N <= 0 || N % 128 || K <= 0 || K % 64) return fail("svr_gemm_pack_frag: need N % 128 == 0, K % 64 == 0");
+    const int64_t chunks = (int64_t)N * K / 8;
+    hipLaunchKernelGGL(gemm_pack_frag_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)W, (uint4*)out, N, K);
+    return check(hipGetLastError(), "svr_gemm_pack_frag");
 }
 
 int svr_conv_pack_frag(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t Cin, void* stream) {

@@ -49,6 +49,7 @@ class _Lin:
     b: Optional[torch.Tensor]
     n: int
     k: int
+    frag: Optional[torch.Tensor] = None     # fragment-ordered copy of w for the persistent GEMM kernel (ops.pack_gemm_frag), or None
 
 
 def timestep_sinusoid(t: float, dim: int = 256) -> torch.Tensor:
@@ -73,10 +74,13 @@ class NaDiTEngine:
             raise ValueError("the window-attention kernel is built for head_dim 128")
         sd = state_dict
 
-        def lin(name, bias=True):
+        def frag(wp):     # (block weights only: the GEMMs that see every video token)
+            return ops.pack_gemm_frag(wp) if hasattr(ops, "pack_gemm_frag") else None
+
+        def lin(name, bias=True, big=False):
             w = sd[name + ".weight"]
             wp, kpad = pack_matrix(w, dev), (w.shape[1] + 63) // 64 * 64
-            return _Lin(wp, pack_vec(sd[name + ".bias"], dev) if bias else None, w.shape[0], kpad)
+            return _Lin(wp, pack_vec(sd[name + ".bias"], dev) if bias else None, w.shape[0], kpad, frag(wp) if big else None)
 
         self.vid_in = lin("vid_in.proj")
         self.txt_in = lin("txt_in")
@@ -103,18 +107,19 @@ class NaDiTEngine:
                     blk["txt"] = blk["vid"]
                     continue
                 s = {}
-                s["qkv"] = lin(p + f"attn.proj_qkv.{b}", bias=False)
-                s["out"] = lin(p + f"attn.proj_out.{b}")
+                big = stream == "vid"             # (the text stream's 58 rows per window never reach the persistent kernel)
+                s["qkv"] = lin(p + f"attn.proj_qkv.{b}", bias=False, big=big)
+                s["out"] = lin(p + f"attn.proj_out.{b}", big=big)
                 s["wq"] = pack_vec(sd[p + f"attn.norm_q.{b}.weight"], dev)
                 s["wk"] = pack_vec(sd[p + f"attn.norm_k.{b}.weight"], dev)
                 if cfg.mlp_type == "normal":
-                    s["mlp_in"] = lin(p + f"mlp.{b}.proj_in")
-                    s["mlp_out"] = lin(p + f"mlp.{b}.proj_out")
+                    s["mlp_in"] = lin(p + f"mlp.{b}.proj_in", big=big)
+                    s["mlp_out"] = lin(p + f"mlp.{b}.proj_out", big=big)
                 else:
                     wg, wi = sd[p + f"mlp.{b}.proj_in_gate.weight"], sd[p + f"mlp.{b}.proj_in.weight"]
                     wsw = pack_swiglu(wg, wi, dev)
-                    s["mlp_in"] = _Lin(wsw, None, 2 * wg.shape[0], wg.shape[1])
-                    s["mlp_out"] = lin(p + f"mlp.{b}.proj_out", bias=False)
+                    s["mlp_in"] = _Lin(wsw, None, 2 * wg.shape[0], wg.shape[1], frag(wsw) if big else None)
+                    s["mlp_out"] = lin(p + f"mlp.{b}.proj_out", bias=False, big=big)
                 # AdaSingle parameters; slot = l*3 + g with l in (attn, mlp), g in (shift, scale, gate)
                 s["ada"] = {}
                 for l, lname in enumerate(("attn", "mlp")):
@@ -298,9 +303,9 @@ class NaDiTEngine:
                 ops.rmsnorm_mod(hid[N:], xn[N:], eps, scale=mod[st["ada"][("attn", "scale")]],
                                 shift=mod[st["ada"][("attn", "shift")]])
             if shared:
-                ops.gemm(xn, sv["qkv"].w, qkv, N=3 * inner, K=d)
+                ops.gemm(xn, sv["qkv"].w, qkv, N=3 * inner, K=d, W_frag=sv["qkv"].frag)
             else:
-                ops.gemm(xn[:N], sv["qkv"].w, qkv[:N], N=3 * inner, K=d)
+                ops.gemm(xn[:N], sv["qkv"].w, qkv[:N], N=3 * inner, K=d, W_frag=sv["qkv"].frag)
                 ops.gemm(xn[N:], st["qkv"].w, qkv[N:], N=3 * inner, K=d)
             ops.qknorm_rope(qkv[:N], heads, plan["pos"], 0 if rope3d else Lt, cos_t, sin_t, sv["wq"], sv["wk"], eps)
             ops.qknorm_rope(qkv[N:], heads, pos_t, 0, cos_t, sin_t, st["wq"], st["wk"], eps)
@@ -310,10 +315,10 @@ class NaDiTEngine:
             g_v = mod[sv["ada"][("attn", "gate")]]
             if shared and not final:
                 ops.gemm(att[:R], sv["out"].w, hid, N=d, K=inner, bias=sv["out"].b, epilogue=EPI_RESID_GATE,
-                         gate=g_v, resid=hid, out_f32=hf)
+                         gate=g_v, resid=hid, out_f32=hf, W_frag=sv["out"].frag)
             else:
                 ops.gemm(att[:N], sv["out"].w, hid[:N], N=d, K=inner, bias=sv["out"].b, epilogue=EPI_RESID_GATE,
-                         gate=g_v, resid=hid[:N], out_f32=hf)
+                         gate=g_v, resid=hid[:N], out_f32=hf, W_frag=sv["out"].frag)
                 if not final:  # the text stream is dead after the last block's attention
                     ops.gemm(att[N:R], st["out"].w, hid[N:], N=d, K=inner, bias=st["out"].b, out_f32=hf,
                              epilogue=EPI_RESID_GATE, gate=mod[st["ada"][("attn", "gate")]], resid=hid[N:])
@@ -331,12 +336,13 @@ class NaDiTEngine:
             def mlp(rows, s_, gate, dst=None):
                 """``dst``: where the branch's output (residual added) goes instead of back into ``hid``."""
                 if cfg.mlp_type == "normal":
-                    ops.gemm(xn[rows], s_["mlp_in"].w, h1[rows], N=hm, K=d, bias=s_["mlp_in"].b, epilogue=EPI_BIAS_GELU)
+                    ops.gemm(xn[rows], s_["mlp_in"].w, h1[rows], N=hm, K=d, bias=s_["mlp_in"].b, epilogue=EPI_BIAS_GELU,
+                             W_frag=s_["mlp_in"].frag)
                 else:
-                    ops.gemm(xn[rows], s_["mlp_in"].w, h1[rows], N=2 * hm, K=d, epilogue=EPI_SWIGLU)
+                    ops.gemm(xn[rows], s_["mlp_in"].w, h1[rows], N=2 * hm, K=d, epilogue=EPI_SWIGLU, W_frag=s_["mlp_in"].frag)
                 o = hid[rows] if dst is None else dst
                 ops.gemm(h1[rows], s_["mlp_out"].w, o, N=d, K=hm, bias=s_["mlp_out"].b, out_f32=o.dtype == torch.float32,
-                         epilogue=EPI_RESID_GATE, gate=gate, resid=hid[rows])
+                         epilogue=EPI_RESID_GATE, gate=gate, resid=hid[rows], W_frag=s_["mlp_out"].frag)
 
             if shared and not final:
                 mlp(slice(0, R), sv, gm_v)

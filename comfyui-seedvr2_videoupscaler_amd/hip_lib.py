@@ -19,7 +19,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                "-mllvm", "-pragma-unroll-threshold=1000000"]
 
 EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU, EPI_BIAS_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 # svr_gemm_kernel_class() codes (include/seedvr2_hip.h)
 KERNEL_CLASSES = {0: "none", 1: "gemm", 2: "gemm_persistent", 3: "conv_halo", 4: "conv_subpixel", 5: "conv_thin_in",
                   6: "conv_thinout", 7: "conv_generic"}
@@ -66,6 +66,7 @@ class GemmArgs(C.Structure):
 _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
     "svr_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "svr_gemm_pack_frag": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "svr_conv_pack_frag": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "svr_conv_pack_frag_taps": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "svr_gemm_gn_blocks": (C.c_int32, [C.POINTER(GemmArgs)]),

@@ -221,6 +221,18 @@ class HipOps:
                       "svr_conv_pack_frag_taps")
         return out
 
+    def pack_gemm_frag(self, W):
+        """Fragment-ordered copy of a packed plain-GEMM weight W [Npad, K] for gemm(..., W_frag=): the persistent GEMM kernel then
+        streams the weights straight into registers and only the activations pass through LDS (csrc/svr_gemm_w4r.hip; same bits).
+        None for shapes that kernel never serves (it wants whole 256-column tiles and at least two 64-wide K tiles)."""
+        n, k = W.shape
+        if n % 256 or k % 64 or k < 128:
+            return None
+        self._chk(W, BF16, "W")
+        out = torch.empty(n * k, dtype=BF16, device=self.device)
+        hip_lib.check(self.lib.svr_gemm_pack_frag(_ptr(W), _ptr(out), n, k, self._stream()), "svr_gemm_pack_frag")
+        return out
+
     def gemm(self, A, W, out, *, N, K, M=None, bias=None, epilogue=EPI_BIAS, gate=None, resid=None,
              out_f32=False, conv: Optional[Conv3dGeom] = None, ps: Optional[PixelShuffleGeom] = None,
              lda=None, ldc=None, ldr=None, gn_groups: int = 0, W_frag=None, phase: Optional[PhaseScatter] = None,

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SVR_ABI_VERSION 6
+#define SVR_ABI_VERSION 7
 
 /* ---- GEMM / implicit-GEMM convolution epilogues ------------------------------------------ */
 /* Storage kinds of activation tensors that are NOT MFMA operands (svr_gemm_args.out_f32 / .resid_f32, the x_f32 arguments).
@@ -110,7 +110,11 @@ typedef struct svr_gemm_args {
     int32_t gn_groups;
     /* Optional (conv mode, 3x3 spatial taps, stride 1, Cin % 32 == 0, N % 128 == 0): the same weights in
      * MFMA-fragment order as written by svr_conv_pack_frag().  When set, the LDS-halo conv kernel streams the
-     * weights from this copy straight into registers instead of staging W through LDS.  NULL: off; ignored by plain GEMMs. */
+     * weights from this copy straight into registers instead of staging W through LDS.  NULL: off.
+     * Plain GEMMs (ABI v7): the copy written by svr_gemm_pack_frag().  When set and the problem is served by the persistent
+     * GEMM kernel (svr_gemm_kernel_class() == SVR_KERNEL_GEMM_PERSISTENT), that kernel streams the weights from it into
+     * registers and only the activations pass through LDS (by LDS-DMA); same results, bit for bit.  Ignored by every other
+     * plain-GEMM kernel. */
     const void* W_frag;
     svr_phase_scatter phase;            /* conv mode only; not together with ps / SWIGLU / resid                        */
     int32_t resid_f32;                  /* 1: `resid` is fp32 [M, N] (ldr in elements).  Wide residual trunk (ABI v5): with out_f32
@@ -121,6 +125,13 @@ typedef struct svr_gemm_args {
 /* W [N, K = kt * 9 * Cin] (conv weight rows, K order (dt, dy, dx, c)) -> out (same byte size, N * K bf16) in the
  * fragment order svr_gemm_args.W_frag expects.  N % 32 == 0, Cin % 32 == 0.  Done once per checkpoint.     */
 int svr_conv_pack_frag(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t Cin, void* stream);
+
+/* W [N, K] (plain GEMM weight rows, N % 128 == 0 -- rows past the problem's N zero-filled --, K % 64 == 0) -> out (same byte
+ * size) in the fragment order a plain GEMM's svr_gemm_args.W_frag expects: 16-byte unit
+ * (((n / 128) * (K / 32) + k / 32) * 8 + (n % 128) / 16) * 64 + lane holds W[(n & ~15) + (lane & 15)][(k & ~31) + (lane >> 4) * 8 .. + 7],
+ * the first operand of v_mfma_f32_16x16x32_bf16.  Done once per checkpoint (replaces nothing in the reference: its nn.Linear weights,
+ * src/models/dit_3b/nablocks/attention/mmattn.py:173,207-208,269 and mlp.py:60-61, have no kernel-side layout).  ABI v7.          */
+int svr_gemm_pack_frag(const void* W, void* out, int32_t N, int32_t K, void* stream);
 
 /* Same for any spatial tap grid (K = kt * kh * kw * Cin, K order (dt, dy, dx, c)): kh = kw = 3 is svr_conv_pack_frag; kh = kw = 2
  * feeds the sub-pixel upsampler conv kernel (stride 1, pads 0 | 1, same-size output, N % 128 == 0, plain bias epilogue,
@@ -137,7 +148,7 @@ int32_t svr_gemm_gn_blocks(const svr_gemm_args* args);
  * with it (the `roofline` object is the SVR_KERNEL_CONV_HALO launches only), tests pin it on the shapes a VAE tile issues. */
 #define SVR_KERNEL_NONE            0   /* empty problem: nothing is launched                                           */
 #define SVR_KERNEL_GEMM            1   /* gemm_kernel (eight waves, 256x256 / 256x128 tiles)                           */
-#define SVR_KERNEL_GEMM_PERSISTENT 2   /* gemm_w4q_kernel (persistent four-wave workgroups, the NaDiT's big GEMMs)     */
+#define SVR_KERNEL_GEMM_PERSISTENT 2   /* gemm_w4r_kernel / gemm_w4q_kernel (persistent four-wave workgroups, the NaDiT's big GEMMs; with / without W_frag) */
 #define SVR_KERNEL_CONV_HALO       3   /* conv_halo2_kernel: stride-1 3x3 spatial taps, LDS halo (the dominant kernel) */
 #define SVR_KERNEL_CONV_SUBPIXEL   4   /* conv_sub_kernel: (kt, 2, 2)-tap phases of the sub-pixel upsamplers           */
 #define SVR_KERNEL_CONV_THIN_IN    5   /* conv_halo2_kernel<8, thin>: Cin = 4 (encoder.conv_in)                        */
@@ -240,6 +251,9 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * "conv_lds" dynamic LDS bytes to request for the halo kernel (> 80 KiB forces one workgroup per CU),
  * "gemm_w4" 1 (default) plain GEMMs with N % 256 == 0 and >= 256 tiles on the persistent four-wave kernel (256 accumulators per
  * wave, the vendor library's tile shape and MFMA) | 0 on the eight-wave kernel like everything else,
+ * "gemm_w4r" 1 (default) the persistent kernel streams the weights of a launch that carries W_frag from that copy into registers and
+ * brings the activations into LDS by LDS-DMA | 2 the same with the activations staged through registers | 0 it stages both operands
+ * through LDS whether W_frag is given or not,
  * "gemm_epi" epilogue of the GEMM kernel: 0 auto | 1 stores straight from the accumulators | 2 through LDS wherever possible,
  * "attn_impl" 0 auto (second-generation window kernel for head_dim 128 / windows <= 2048 rows) | 1 first kernel everywhere,
  * "attn_variant" build variant of the second-generation window kernel (0 default = 8 waves; 1 / 3 / 4: see svr_attn_win.hip),

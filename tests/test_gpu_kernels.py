@@ -155,6 +155,7 @@ def gemm_big(request, hip):
 
 
 GEMM_W4_DEFAULT = 1
+GEMM_W4R_DEFAULT = 1
 
 
 @pytest.mark.parametrize("M,N,K", [(16384, 4096, 128), (16300, 4096, 192), (9000, 7680, 320), (70000, 256, 2560), (4100, 4096, 6912)])
@@ -180,6 +181,20 @@ def test_gemm_big_tiles_both_main_loops(hip, ref, gemm_big, M, N, K):
         assert not torch.isnan(outs[0].float()).any() and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
         want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, **{k: v for k, v in kw.items() if k != "out_f32"})
         assert rel_err(outs[0].float(), want) < (TOL_F32 if kw.get("out_f32") else TOL_BF16), kw.get("epilogue", 0)
+        if gemm_big == 1:
+            # gemm_w4r_kernel (ABI v7): the same launch with the fragment-ordered weight copy -- weights straight into registers,
+            # only the activations through LDS; same MFMAs in the same k order, so the SAME BITS as gemm_w4q_kernel, launch after launch
+            # (hand-counted vmcnt waits over 24 loads per K tile: a wrong count shows up as a different result)
+            Wf = hip.pack_gemm_frag(W)
+            assert Wf is not None
+            for w4r in (1, 2, 1, 2):      # (1: activations by LDS-DMA, the default; 2: through registers)
+                hip.set_option("gemm_w4r", w4r)
+                try:
+                    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if kw.get("out_f32") else BF16)
+                    hip.gemm(A, W, out, N=N, K=K, W_frag=Wf, **kw)
+                    assert torch.equal(out, outs[0]), ("w4r != w4q", w4r, kw.get("epilogue", 0))
+                finally:
+                    hip.set_option("gemm_w4r", GEMM_W4R_DEFAULT)
     # SwiGLU (interleaved gate | in weights): N = 2 x hidden
     Hd = N // 2
     wg, wi = rnd(Hd, K, scale=1.0 / math.sqrt(K), seed=7), rnd(Hd, K, scale=1.0 / math.sqrt(K), seed=8)
@@ -187,6 +202,44 @@ def test_gemm_big_tiles_both_main_loops(hip, ref, gemm_big, M, N, K):
     hip.gemm(A, packing.pack_swiglu(wg, wi, "cuda"), o, N=N, K=K, epilogue=EPI_SWIGLU)
     want = torch.nn.functional.silu(A.float() @ wg.float().t()) * (A.float() @ wi.float().t())
     assert not torch.isnan(o.float()).any() and rel_err(o.float(), want) < TOL_BF16
+    if gemm_big == 1:
+        Wsw = packing.pack_swiglu(wg, wi, "cuda")
+        o2 = torch.full((M, Hd), float("nan"), device="cuda", dtype=BF16)
+        for w4r in (1, 2):
+            hip.set_option("gemm_w4r", w4r)
+            try:
+                o2 = torch.full((M, Hd), float("nan"), device="cuda", dtype=BF16)
+                hip.gemm(A, Wsw, o2, N=N, K=K, epilogue=EPI_SWIGLU, W_frag=hip.pack_gemm_frag(Wsw))
+                assert torch.equal(o2, o), w4r
+            finally:
+                hip.set_option("gemm_w4r", GEMM_W4R_DEFAULT)
+
+
+def test_gemm_w4r_option_and_routing(hip):
+    """W_frag changes the kernel, not the route: the classifier still says gemm_persistent, svr_set_option("gemm_w4r", 0) sends the
+    launch back through gemm_w4q_kernel, 2 through the register-staged variant (bit-identical all three ways), and a W_frag too small
+    for the problem is refused."""
+    M, N, K = 20000, 2560, 256
+    A = rnd(M, K)
+    w, W = packed(N, K)
+    Wf = hip.pack_gemm_frag(W)
+    outs = []
+    hip.record_kernel_class = True
+    for opt in (1, 0, 2):
+        hip.set_option("gemm_w4r", opt)
+        try:
+            out = torch.empty(M, N, device="cuda", dtype=BF16)
+            hip.gemm(A, W, out, N=N, K=K, W_frag=Wf)
+            assert hip.last_kernel_class == "gemm_persistent"
+            outs.append(out)
+        finally:
+            hip.set_option("gemm_w4r", GEMM_W4R_DEFAULT)
+            hip.record_kernel_class = False
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert rel_err(outs[0].float(), A.float() @ w.float().t()) < TOL_BF16
+    with pytest.raises(ValueError):
+        hip.gemm(A, W, torch.empty(M, N, device="cuda", dtype=BF16), N=N, K=K, W_frag=Wf[: N * K - 8])
+    assert hip.pack_gemm_frag(W[:128]) is None and hip.pack_gemm_frag(W[:, :64].contiguous()) is None
 
 
 # ------------------------------------------------------------------ implicit-GEMM causal conv

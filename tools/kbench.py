@@ -116,13 +116,18 @@ def main():
                 kw = dict(gate=torch.ones(N, dtype=torch.float32, device=dev), resid=rnd(M, N))
             sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, epilogue=epi, **kw), args.reps)
             report(name, sec, flops=2.0 * M * N * K)
+            wf = ops.pack_gemm_frag(w)        # gemm_w4r_kernel: weights from the fragment-ordered copy straight into registers, activations by LDS-DMA
+            sec = timeit(lambda: ops.gemm(a, w, c, N=N, K=K, epilogue=epi, W_frag=wf, **kw), args.reps)
+            report(name + " [W_frag: gemm_w4r_kernel]", sec, flops=2.0 * M * N * K)
             if epi == ops_mod.EPI_RESID_GATE:
                 # the form the NaDiT engine issues (dit.py, wide residual stream): hid fp32, updated in place
                 hid = torch.rand(M, N, generator=g, device=dev, dtype=torch.float32) * 2 - 1
                 sec = timeit(lambda: ops.gemm(a, w, hid, N=N, K=K, epilogue=epi, gate=kw["gate"], resid=hid, out_f32=True), args.reps)
                 report(name.replace("(+gate,resid)", "(+gate, fp32 stream in place)"), sec, flops=2.0 * M * N * K)
+                sec = timeit(lambda: ops.gemm(a, w, hid, N=N, K=K, epilogue=epi, gate=kw["gate"], resid=hid, out_f32=True, W_frag=wf), args.reps)
+                report(name.replace("(+gate,resid)", "(+gate, fp32 stream in place)") + " [W_frag: gemm_w4r_kernel]", sec, flops=2.0 * M * N * K)
                 del hid
-            del a, w, c, kw
+            del a, w, c, kw, wf
     if "ksweep" in only:
         # per-K-tile cost c and per-output-tile overhead o of the big-GEMM main loops: M x N = 4096 tiles of 256 x 256 (16 full rounds of
         # 256 CUs), bias epilogue, K swept; time per round = (K / 64) c + o.  The vendor library on the same shapes for calibration.
