@@ -215,6 +215,24 @@ def test_gemm_big_tiles_both_main_loops(hip, ref, gemm_big, M, N, K):
                 hip.set_option("gemm_w4r", GEMM_W4R_DEFAULT)
 
 
+def test_gemm_pack_frag_layout_is_the_documented_one(hip):
+    """svr_gemm_pack_frag (include/seedvr2_hip.h, ABI v7): 16-byte unit (((n / 128) * (K / 32) + k / 32) * 8 + (n % 128) / 16) * 64 + lane
+    holds W[(n & ~15) + (lane & 15)][(k & ~31) + (lane >> 4) * 8 .. + 7] -- restated with torch index arithmetic."""
+    N, K = 384, 192
+    W = torch.arange(N * K, device="cuda", dtype=torch.int32).remainder(32749).to(torch.int16).view(torch.bfloat16).reshape(N, K).contiguous()
+    got = hip.pack_gemm_frag(torch.cat([W, W[:128]]).contiguous())      # (N must be a multiple of 256 for the persistent kernel: 512 rows)
+    Wp = torch.cat([W, W[:128]])
+    Np = Wp.shape[0]
+    unit = torch.arange(Np * K // 8, device="cuda")
+    lane, u = unit % 64, unit // 64
+    J, v = u % 8, u // 8
+    ks, p = v % (K // 32), v // (K // 32)
+    n = p * 128 + J * 16 + (lane % 16)
+    k0 = ks * 32 + (lane // 16) * 8
+    want = Wp.view(torch.int16)[n[:, None], k0[:, None] + torch.arange(8, device="cuda")[None, :]].reshape(-1)
+    assert torch.equal(got.view(torch.int16), want)
+
+
 def test_gemm_w4r_option_and_routing(hip):
     """W_frag changes the kernel, not the route: the classifier still says gemm_persistent, svr_set_option("gemm_w4r", 0) sends the
     launch back through gemm_w4q_kernel, 2 through the register-staged variant (bit-identical all three ways), and a W_frag too small
