@@ -278,9 +278,15 @@ def main():
             return gathered, ev
 
     def fingerprint(t):
-        """fp64 sum and sum of squares of an output (on the device, OUTSIDE the timed region)."""
-        d = t.double()
-        return torch.stack([d.sum(), (d * d).sum()])
+        """fp64 sum and sum of squares of an output (on the device, OUTSIDE the timed region).  Accumulated over chunks of
+        eight frames in a fixed order: the gathered clip of an 8-rank run is 12.7 GB of bf16, and two fp64 images of it next
+        to the engines' cached activations would not be a safe assumption even on 288 GB."""
+        acc = torch.zeros(2, dtype=torch.float64, device=t.device)
+        for c in (t.split(8, 0) if t.dim() > 1 else (t,)):
+            d = c.double()
+            acc[0] += d.sum()
+            acc[1] += (d * d).sum()
+        return acc
 
     first_print = None
     for _ in range(args.warmup):
@@ -308,7 +314,7 @@ def main():
     # at the real tile size: std 0.58, range about [-3.5, 3]); for the [0, 1] frames of the cfg4 pipeline the band is that of
     # clamped frames; (3) the hot path is deterministic, so the last timed step must reproduce the first warm-up step's
     # output sums bit for bit (same inputs).  On failure: no JSON line, exit code 3.
-    guard = {"finite": bool(torch.isfinite(last_out).all())}
+    guard = {"finite": all(bool(torch.isfinite(c).all()) for c in (last_out.split(8, 0) if last_out.dim() > 1 else (last_out,)))}
     fp_last = fingerprint(last_out)
     n_el = last_out.numel()
     g_mean, g_std = float(fp_last[0]) / n_el, math.sqrt(max(float(fp_last[1]) / n_el - (float(fp_last[0]) / n_el) ** 2, 0.0))
@@ -446,7 +452,7 @@ def main():
                         "allgather_ms": phase["gather"], "dit_tflops": dit_tf,
                         # whole-DiT-step MFMA fraction: algorithmic FLOPs of the forward / its measured time / dense bf16 peak
                         "dit_mfma_frac": dit_tf / PEAK_BF16_TFLOPS})
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (the CPU leg is a 1-GPU line item: the other ranks would idle at the barrier)
             res["cpu_baseline"] = cpu_baseline(f_step / frames_per_step * (world if not sharded else 1))
         print(json.dumps(res))
     if world > 1:

@@ -116,8 +116,14 @@ SVR_DEVICE void aw_wait_lgkm(bf16x4 (&v)[8]) {
 
 // NW: waves per workgroup (4: 128-query tiles, two workgroups per CU; 8: 256-query tiles, one workgroup per CU -- half the
 // LDS-DMA instructions and L2->LDS bytes per MFMA, coarser tiles for ragged windows).  PRIO: s_setprio 1 around MFMA groups.
-template <int NW, bool PRIO>
-__global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
+// QW: 32-query blocks per wave.  QW = 2 (with NW = 4: the same 256-query tile, ONE wave per SIMD) is the structural step the
+// round-2 / round-3 reviews name: every K fragment (ds_read_b128) and every V^T fragment (ds_read_b64_tr_b16) feeds two MFMAs
+// instead of one, so the LDS fragment bytes per MFMA halve while the LDS-DMA bytes per MFMA stay those of the 8-wave build;
+// the two blocks' MFMAs alternate on independent accumulators.  Per query row the arithmetic (MFMA order, rescale decisions
+// -- taken per 32-query block, and the blocks are the same 32-aligned blocks in every build) is unchanged, so all builds
+// agree bit for bit.  192 accumulator + 64 Q registers per wave: one wave per SIMD (launch bound 1).
+template <int NW, bool PRIO, int QW = 1>
+__global__ __launch_bounds__(NW * 64, (QW == 2 ? 1 : 2)) void attn_win_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld_qkv, bf16_t* __restrict__ out, int64_t ld_out,
     const int32_t* __restrict__ seq_rows, const int32_t* __restrict__ out_rows, const int32_t* __restrict__ cu,
     int heads, int n_pairs, int qt_per_pair, float scale_log2) {
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
     const int seq = pair / heads, head = pair - seq * heads;
     const int beg = cu[seq];
     const int L = cu[seq + 1] - beg;
-    constexpr int AW_QB = NW * 32, NP = 16 / NW;      // queries per workgroup; LDS-DMA pieces (1 KiB of K + 1 KiB of V) per wave per tile
+    constexpr int AW_QB = NW * 32 * QW, NP = 16 / NW; // queries per workgroup; LDS-DMA pieces (1 KiB of K + 1 KiB of V) per wave per tile
     const int q0 = (j % qt_per_pair) * AW_QB;
     if (q0 >= L) return;
 
@@ -167,13 +173,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
 #pragma unroll
     for (int it = 0; it < NP; ++it) stage_piece(it, 0);
 
-    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = q0 + 32 wave + l31][16 ds + 8 hi .. + 8]
-    const int qpos = q0 + wave * 32 + l31;
-    bf16x8 qf[8];
-    {
-        const char* qp = qbase + ((uint64_t)srow[min(qpos, L - 1)] << 4) + hi * 16;
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = q0 + 32 (QW wave + b) + l31][16 ds + 8 hi .. + 8]
+    int qpos[QW];
+    bf16x8 qf[QW][8];
 #pragma unroll
-        for (int ds = 0; ds < 8; ++ds) qf[ds] = *(const bf16x8*)(qp + ds * 32);
+    for (int b = 0; b < QW; ++b) {
+        qpos[b] = q0 + (wave * QW + b) * 32 + l31;
+        const char* qp = qbase + ((uint64_t)srow[min(qpos[b], L - 1)] << 4) + hi * 16;
+#pragma unroll
+        for (int ds = 0; ds < 8; ++ds) qf[b][ds] = *(const bf16x8*)(qp + ds * 32);
     }
     next_rows(1);
 
@@ -191,12 +199,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
     for (int m = 0; m < 4; ++m)
         va_[m] = lds_base + 2 * AW_TILE + hi * 1024 + jr * 256 + (((((m ^ jr) << 2) | (2 * G + (c4 >> 1))) << 4)) + (c4 & 1) * 8;
 
-    f32x16 o[4];
-    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o[QW][4];
+    float m_run[QW], l_run[QW];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int b = 0; b < QW; ++b) {
+        m_run[b] = -INFINITY;
+        l_run[b] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[m][r] = 0.f;
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[b][m][r] = 0.f;
+    }
 
     __syncthreads();                                   // tile 0 landed (vmcnt(0) + barrier)
 
@@ -206,9 +219,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
 
         // ---- S^T = K Q^T : 2 key blocks x 8 d-steps.  Fragment reads (asm, counted waits) run 4 k-steps ahead of the
         //      MFMAs; the 8 LDS-DMA pieces of tile t+1 are issued between the MFMA groups, not as a burst.
-        f32x16 sacc[2];
+        f32x16 sacc[QW][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sacc[0][r] = 0.f; sacc[1][r] = 0.f; }
+        for (int b = 0; b < QW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[b][0][r] = 0.f; sacc[b][1][r] = 0.f; }
         bf16x8 kA[4], kB[4];
         bf16x4 vA[8], vB[8];
         aw_k4<0>(kA, ka_[0], ka_[1], ka_[2], ka_[3]);
@@ -216,7 +231,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
 #define AW_QK(K, Q0, S)                                                                                               \
         if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                      \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                 \
-            sacc[S] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(K[e], qf[Q0 + e], sacc[S], 0, 0, 0);                    \
+            _Pragma("unroll") for (int b = 0; b < QW; ++b)                                                            \
+                sacc[b][S] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(K[e], qf[b][Q0 + e], sacc[b][S], 0, 0, 0);       \
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         aw_wait_k<4>(kA);
         AW_QK(kA, 0, 0)
@@ -236,63 +252,67 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
 #undef AW_QK
 
         // ---- online softmax, lane-local over this lane's 32 keys; the other 32 keys of the tile live in lane ^ 32
-        if ((t + 1) * AW_KT > L) {                     // ragged last tile (wave-uniform): mask keys >= L
-            const int kbase = t * AW_KT + 4 * hi;
+        bf16x8 pf[QW][2][2];
+#pragma unroll
+        for (int b = 0; b < QW; ++b) {
+            if ((t + 1) * AW_KT > L) {                 // ragged last tile (wave-uniform): mask keys >= L
+                const int kbase = t * AW_KT + 4 * hi;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= L) sacc[b][kb][r] = -INFINITY;
+            }
+            float mx = sacc[b][0][0];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= L) sacc[kb][r] = -INFINITY;
-        }
-        float mx = sacc[0][0];
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][kb][r]);
+            mx = aw_other_half_max(mx);
+            // Deferred rescale (cdna_hip_programming.md T13): while no row's maximum grew by more than 2^AW_DEFER over the
+            // reference value m_run, keep m_run -- P is then bounded by 2^AW_DEFER instead of 1 (same RELATIVE bf16 precision,
+            // fp32 accumulators) and the O / l rescale is skipped for the whole 32-query block.  Everything exponentiated in
+            // this tile uses the m_run decided HERE, and O, l are rescaled in the same place, so nothing is ever at a stale scale.
+            if (!__all((mx - m_run[b]) * scale_log2 <= AW_DEFER)) {       // also true for the first tile (m_run = -inf)
+                const float m_new = fmaxf(m_run[b], mx);                  // finite: every tile holds at least one valid key
+                const float alpha = fast_exp2((m_run[b] - m_new) * scale_log2);
+                m_run[b] = m_new;
+                l_run[b] *= alpha;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-        mx = aw_other_half_max(mx);
-        // Deferred rescale (cdna_hip_programming.md T13): while no row's maximum grew by more than 2^AW_DEFER over the
-        // reference value m_run, keep m_run -- P is then bounded by 2^AW_DEFER instead of 1 (same RELATIVE bf16 precision,
-        // fp32 accumulators) and the O / l rescale is skipped for the whole wave.  Everything exponentiated in this tile
-        // uses the m_run decided HERE, and O, l are rescaled in the same place, so nothing is ever at a stale scale.
-        if (!__all((mx - m_run) * scale_log2 <= AW_DEFER)) {          // also true for the first tile (m_run = -inf)
-            const float m_new = fmaxf(m_run, mx);                     // finite: every tile holds at least one valid key
-            const float alpha = fast_exp2((m_run - m_new) * scale_log2);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
-        }
-        const float mc = m_run * scale_log2;
-        f32x2 ps = {0.f, 0.f};
-        const f32x2 c2 = {scale_log2, scale_log2}, mc2 = {-mc, -mc};
-        bf16x8 pf[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float p[8];
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const f32x2 sv = {sacc[kb][8 * u + e], sacc[kb][8 * u + e + 1]};
-                    const f32x2 a = __builtin_elementwise_fma(sv, c2, mc2);            // v_pk_fma_f32
-                    p[e] = fast_exp2(a[0]);
-                    p[e + 1] = fast_exp2(a[1]);
-                    const f32x2 pv = {p[e], p[e + 1]};
-                    ps += pv;                                                           // v_pk_add_f32
-                }
-                const uint4 pk = pack8(p);
-                pf[kb][u] = __builtin_bit_cast(bf16x8, pk);
+                    for (int r = 0; r < 16; ++r) o[b][m][r] *= alpha;
             }
-        l_run += ps[0] + ps[1];
+            const float mc = m_run[b] * scale_log2;
+            f32x2 ps = {0.f, 0.f};
+            const f32x2 c2 = {scale_log2, scale_log2}, mc2 = {-mc, -mc};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float p[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 sv = {sacc[b][kb][8 * u + e], sacc[b][kb][8 * u + e + 1]};
+                        const f32x2 a = __builtin_elementwise_fma(sv, c2, mc2);            // v_pk_fma_f32
+                        p[e] = fast_exp2(a[0]);
+                        p[e + 1] = fast_exp2(a[1]);
+                        const f32x2 pv = {p[e], p[e + 1]};
+                        ps += pv;                                                           // v_pk_add_f32
+                    }
+                    const uint4 pk = pack8(p);
+                    pf[b][kb][u] = __builtin_bit_cast(bf16x8, pk);
+                }
+            l_run[b] += ps[0] + ps[1];
+        }
 
         // ---- O^T += V^T P^T : 4 k-steps (16 keys each) x 4 d blocks; the reads of k-step g+1 fly under the MFMAs of g
 #define AW_PV(V, KB, U)                                                                                            \
         if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                     \
         _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                              \
             const bf16x8 vf = __builtin_shufflevector(V[2 * m], V[2 * m + 1], 0, 1, 2, 3, 4, 5, 6, 7);               \
-            o[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[KB][U], o[m], 0, 0, 0);                            \
+            _Pragma("unroll") for (int b = 0; b < QW; ++b)                                                           \
+                o[b][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][KB][U], o[b][m], 0, 0, 0);               \
         }                                                                                                            \
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         aw_tr8<4096>(vB, va_[0], va_[1], va_[2], va_[3]);
@@ -316,42 +336,47 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_win_kernel(
         __syncthreads();                               // tile t+1 landed (vmcnt(0)); everyone is done reading this tile's buffers
     }
 
-    // ---- normalise and scatter.  Lane (q, hi) holds O[q][32 m + 8 rq + 4 hi + 0..3] in o[m][4 rq .. 4 rq + 3]
-    const float l = aw_other_half_sum(l_run);
-    const float inv = 1.0f / l;
-    const bool valid = qpos < L;
-    const int orow = valid ? out_rows[beg + qpos] : 0;
-    char* op = (char*)out + ((int64_t)orow * ld_out + (int64_t)head * AW_D) * 2 + hi * 16;
+    // ---- normalise and scatter.  Lane (q, hi) holds O[q][32 m + 8 rq + 4 hi + 0..3] in o[b][m][4 rq .. 4 rq + 3]
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int b = 0; b < QW; ++b) {
+        const float l = aw_other_half_sum(l_run[b]);
+        const float inv = 1.0f / l;
+        const bool valid = qpos[b] < L;
+        const int orow = valid ? out_rows[beg + qpos[b]] : 0;
+        char* op = (char*)out + ((int64_t)orow * ld_out + (int64_t)head * AW_D) * 2 + hi * 16;
 #pragma unroll
-        for (int rq = 0; rq < 4; rq += 2) {
-            uint32_t ax = pack2bf(o[m][4 * rq + 0] * inv, o[m][4 * rq + 1] * inv);
-            uint32_t ay = pack2bf(o[m][4 * rq + 2] * inv, o[m][4 * rq + 3] * inv);
-            uint32_t bx = pack2bf(o[m][4 * rq + 4] * inv, o[m][4 * rq + 5] * inv);
-            uint32_t by = pack2bf(o[m][4 * rq + 6] * inv, o[m][4 * rq + 7] * inv);
-            // half exchange: lower lanes end up with d = 32 m + 8 rq + 0..7, upper lanes with 32 m + 8 (rq + 1) + 0..7
-            const u32x2 sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-            const u32x2 sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-            if (valid) *(uint4*)(op + (32 * m + 8 * rq) * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-        }
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int rq = 0; rq < 4; rq += 2) {
+                uint32_t ax = pack2bf(o[b][m][4 * rq + 0] * inv, o[b][m][4 * rq + 1] * inv);
+                uint32_t ay = pack2bf(o[b][m][4 * rq + 2] * inv, o[b][m][4 * rq + 3] * inv);
+                uint32_t bx = pack2bf(o[b][m][4 * rq + 4] * inv, o[b][m][4 * rq + 5] * inv);
+                uint32_t by = pack2bf(o[b][m][4 * rq + 6] * inv, o[b][m][4 * rq + 7] * inv);
+                // half exchange: lower lanes end up with d = 32 m + 8 rq + 0..7, upper lanes with 32 m + 8 (rq + 1) + 0..7
+                const u32x2 sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                const u32x2 sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                if (valid) *(uint4*)(op + (32 * m + 8 * rq) * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+    }
 }
 
 // svr_set_option("attn_variant", v): A/B knob over the build variants -- 0 = default (8 waves; measured best on both window
-// families, profiles/r2_attn_kbench.jsonl), 1 = 4 waves + s_setprio, 2 = 8 waves, 3 = 8 waves + s_setprio, 4 = 4 waves
+// families, profiles/r2_attn_kbench.jsonl), 1 = 4 waves + s_setprio, 2 = 8 waves, 3 = 8 waves + s_setprio, 4 = 4 waves,
+// 5 = 4 waves x 64 queries (one wave per SIMD; written at the end of round 4 with no GPU minutes left: opt-in until measured),
+// 6 = 5 + s_setprio
 int g_attn_variant = 0;
 
-template <int NW, bool PRIO>
+template <int NW, bool PRIO, int QW = 1>
 static int launch_attn_win_t(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,
                              const int32_t* out_rows, const int32_t* cu, int n_seq, int max_len, int heads, float scale,
                              hipStream_t s) {
-    auto kern = attn_win_kernel<NW, PRIO>;
+    auto kern = attn_win_kernel<NW, PRIO, QW>;
     static uint64_t lds_attr_done = 0;               // per device (svr_common.h)
     {
         const int e = set_max_dynamic_lds((const void*)kern, AW_LDS, lds_attr_done);
         if (e != 0) return e;
     }
-    constexpr int QB = NW * 32;
+    constexpr int QB = NW * 32 * QW;
     if ((ld_qkv * 2) % 16 != 0) return -3;            // (attn_dispatch only sends 16-byte aligned row pitches here)
     const int qt = (max_len + QB - 1) / QB;
     const int64_t n_pairs = (int64_t)n_seq * heads;
@@ -371,6 +396,8 @@ static int launch_attn_win(const void* qkv, int64_t ld_qkv, void* out, int64_t l
         case 1: return launch_attn_win_t<4, true>(AW_ARGS);
         case 3: return launch_attn_win_t<8, true>(AW_ARGS);
         case 4: return launch_attn_win_t<4, false>(AW_ARGS);
+        case 5: return launch_attn_win_t<4, false, 2>(AW_ARGS);
+        case 6: return launch_attn_win_t<4, true, 2>(AW_ARGS);
         default: return launch_attn_win_t<8, false>(AW_ARGS);
     }
 #undef AW_ARGS

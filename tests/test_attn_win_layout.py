@@ -42,8 +42,9 @@ def tr16_b64(lds, addr):
     return out
 
 
-def run_wave(q, k, v, L, q0, wave, scale, NW=4):
-    """q,k,v: [L, 128] float (bf16-representable not required).  Returns {qpos: out row} for this wave's valid queries."""
+def run_wave(q, k, v, L, q0, wave, scale, NW=4, QW=1, b=0):
+    """q,k,v: [L, 128] float (bf16-representable not required).  Returns {qpos: out row} for this wave's valid queries
+    (QW = 2 builds: of its 32-query block b -- the two blocks of a wave share the K / V fragment reads and nothing else)."""
     nk = (L + KT - 1) // KT
     lds = np.zeros(4 * TILE // 2)                        # element (2-byte) addressed
     lanes = np.arange(64)
@@ -52,7 +53,7 @@ def run_wave(q, k, v, L, q0, wave, scale, NW=4):
     i16, G = lanes & 15, (lanes >> 4) & 1
     jr, c4 = i16 >> 2, i16 & 3
     va_ = [2 * TILE + hi * 1024 + jr * 256 + ((((m ^ jr) << 2) | (2 * G + (c4 >> 1))) << 4) + (c4 & 1) * 8 for m in range(4)]
-    qpos = q0 + wave * 32 + l31
+    qpos = q0 + (wave * QW + b) * 32 + l31
     qrow = np.minimum(qpos, L - 1)
     qf = [np.stack([q[qrow[l], 16 * ds + 8 * hi[l]:16 * ds + 8 * hi[l] + 8] for l in range(64)]) for ds in range(8)]
     o = [np.zeros((64, 16)) for _ in range(4)]
@@ -145,6 +146,26 @@ def test_attn_win_index_algebra(NW):
     assert set(got) == set(range(0, 32)) | set(range(96, 128)) | set(range(128, 150))
     for r, row in got.items():
         assert not np.isnan(row).any()
+        np.testing.assert_allclose(row, want[r], rtol=1e-9, atol=1e-9)
+
+
+def test_attn_win_index_algebra_64_queries_per_wave():
+    """attn_variant 5 / 6 (NW = 4, QW = 2): 256-query workgroup tiles like the 8-wave build, wave w owns the 32-query blocks
+    2 w and 2 w + 1.  Same staging roles as every NW = 4 build, same fragment addresses for both blocks."""
+    rng = np.random.default_rng(1)
+    L = 150
+    q, k, v = (rng.standard_normal((L, D)) for _ in range(3))
+    scale = 1 / np.sqrt(D)
+    s = (q @ k.T) * scale
+    p = np.exp(s - s.max(1, keepdims=True))
+    want = (p / p.sum(1, keepdims=True)) @ v
+    got = {}
+    for wave, b in ((0, 0), (0, 1), (1, 1), (2, 0), (2, 1)):           # blocks 0, 1, 3, 4 (ragged: 128..149), 5 (empty)
+        rows = run_wave(q, k, v, L, 0, wave, scale, NW=4, QW=2, b=b)
+        assert not (set(rows) & set(got))
+        got.update(rows)
+    assert set(got) == set(range(0, 64)) | set(range(96, 150))
+    for r, row in got.items():
         np.testing.assert_allclose(row, want[r], rtol=1e-9, atol=1e-9)
 
 

@@ -261,7 +261,8 @@ def main():
             t_seq, t_out, t_cu = (torch.from_numpy(v).to(dev) for v in (seq, outr, cu))
             fl = sum(4.0 * heads * 128 * float(l + Lt) ** 2 for l in lens)
             for impl, variant, tag in ((0, 0, "gen2 8 waves (default)"), (0, 1, "gen2 4 waves + setprio"), (0, 4, "gen2 4 waves"),
-                                       (0, 3, "gen2 8 waves + setprio"), (1, 0, "gen1 svr_attn")):
+                                       (0, 3, "gen2 8 waves + setprio"), (0, 5, "gen2 4 waves x 64 queries"),
+                                       (0, 6, "gen2 4 waves x 64 queries + setprio"), (1, 0, "gen1 svr_attn")):
                 if variant and args.attn_default_only:
                     continue
                 ops.set_option("attn_impl", impl)
