@@ -109,6 +109,7 @@ int svr_groupnorm_reduce(const void* partial, double* stats, int32_t T, int32_t 
     StreamDeviceGuard on_stream_device(stream);
     if (T <= 0 || nblk <= 0) return 0;
     if (groups <= 0 || groups > 65535) return fail("svr_groupnorm_reduce: 1..65535 groups");
+    if (!partial || !stats) return fail("svr_groupnorm_reduce: null pointer");
     hipLaunchKernelGGL(groupnorm_reduce_kernel, dim3(T, groups), dim3(256), 0, (hipStream_t)stream,
                        (const double2*)partial, stats, (int)nblk, groups);
     return check(hipGetLastError(), "svr_groupnorm_reduce");
@@ -118,7 +119,9 @@ int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps
                     const float* shift, int32_t x_f32, void* stream) {
     StreamDeviceGuard on_stream_device(stream);
     if (rows <= 0) return 0;
-    if (dim % 8 || dim > 64 * 8 * 8) return fail("svr_rmsnorm_mod: dim must be a multiple of 8 and <= 4096");
+    if (dim <= 0 || dim % 8 || dim > 64 * 8 * 8) return fail("svr_rmsnorm_mod: dim must be a multiple of 8 and <= 4096");
+    if (!x || !y) return fail("svr_rmsnorm_mod: null pointer");
+    if ((unsigned)x_f32 > (unsigned)SVR_STORE_FP32) return fail("svr_rmsnorm_mod: x_f32 must be SVR_STORE_BF16 or SVR_STORE_FP32");
     const unsigned grid = (unsigned)(rows < 4 * 2048 ? blocks_for(rows, 4) : 2048);      // 8 blocks per CU, rows strided
     const int nc = (dim + 511) / 512;
 #define SVR_RMS_LAUNCH(NC) do { if (x_f32) hipLaunchKernelGGL((rmsnorm_mod_kernel<NC, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
@@ -137,7 +140,9 @@ int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps
 int svr_ada_combine(const void* emb, const void* params, const int32_t* slot, float* out, int32_t n_vec, int32_t dim,
                     void* stream) {
     StreamDeviceGuard on_stream_device(stream);
-    if (n_vec <= 0) return 0;
+    if (n_vec <= 0 || dim <= 0) return 0;
+    if (n_vec > 65535) return fail("svr_ada_combine: at most 65535 vectors per call");
+    if (!emb || !params || !slot || !out) return fail("svr_ada_combine: null pointer");
     hipLaunchKernelGGL(ada_combine_kernel, dim3(blocks_for(dim, 256), n_vec), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)emb, (const bf16_t*)params, slot, out, n_vec, dim);
     return check(hipGetLastError(), "svr_ada_combine");
@@ -148,7 +153,9 @@ int svr_qknorm_rope(void* qkv, int64_t rows, int32_t heads, const int16_t* pos, 
                     void* stream) {
     StreamDeviceGuard on_stream_device(stream);
     if (rows <= 0) return 0;
-    if (n_freq * 3 > 64) return fail("svr_qknorm_rope: at most 21 frequencies per axis (head_dim 128)");
+    if (n_freq <= 0 || n_freq * 3 > 64) return fail("svr_qknorm_rope: 1..21 frequencies per axis (head_dim 128)");
+    if (heads <= 0 || n_pos <= 0) return fail("svr_qknorm_rope: heads and n_pos must be positive");
+    if (!qkv || !pos || !cos_tab || !sin_tab) return fail("svr_qknorm_rope: null pointer");
     // 8 rows (q and k of each: 16 groups of 16 lanes) per block and step; 16 blocks per CU, the rest in the grid-stride loop
     const int64_t nblk = (rows + 7) / 8;
     const unsigned grid = (unsigned)std::min<int64_t>(nblk, (int64_t)device_cu_count() * 16);
@@ -210,6 +217,8 @@ int svr_softmax_rows(const float* S, void* P, int64_t rows, int32_t cols, int64_
                      void* stream) {
     StreamDeviceGuard on_stream_device(stream);
     if (rows <= 0 || cols <= 0) return 0;
+    if (!S || !P) return fail("svr_softmax_rows: null pointer");
+    if (rows > 0x7fffffff) return fail("svr_softmax_rows: at most 2^31 - 1 rows per call");
     if (cols % 4 || cols > 1024 * SM_MAXV * 4 || ld_s % 4 || ld_p % 4)
         return fail("svr_softmax_rows: cols must be a multiple of 4 and <= 65536, leading dimensions multiples of 4");
     if (cols <= 256 * SM_MAXV * 4)
@@ -223,8 +232,10 @@ int svr_softmax_rows(const float* S, void* P, int64_t rows, int32_t cols, int64_
 
 int svr_rows_mean(const void* src, void* dst, int32_t n_groups, int32_t rows_per_group, int32_t dim, void* stream) {
     StreamDeviceGuard on_stream_device(stream);
-    if (n_groups <= 0 || rows_per_group <= 0) return 0;
+    if (n_groups <= 0 || rows_per_group <= 0 || dim <= 0) return 0;
     if (dim % 8) return fail("svr_rows_mean: dim must be a multiple of 8");
+    if (rows_per_group > 65535) return fail("svr_rows_mean: at most 65535 rows per group");
+    if (!src || !dst) return fail("svr_rows_mean: null pointer");
     hipLaunchKernelGGL(rows_mean_kernel, dim3(blocks_for(dim / 8, 64), rows_per_group), dim3(64), 0,
                        (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, n_groups, rows_per_group, dim);
     return check(hipGetLastError(), "svr_rows_mean");
@@ -232,7 +243,8 @@ int svr_rows_mean(const void* src, void* dst, int32_t n_groups, int32_t rows_per
 
 int svr_patchify(const void* in, void* out, int32_t T, int32_t H, int32_t W, int32_t C, int32_t kpad, void* stream) {
     StreamDeviceGuard on_stream_device(stream);
-    if ((H & 1) || (W & 1) || kpad < 4 * C) return fail("svr_patchify: H, W must be even and kpad >= 4*C");
+    if ((H & 1) || (W & 1) || C <= 0 || kpad < 4 * C) return fail("svr_patchify: H, W must be even, C positive and kpad >= 4*C");
+    if (!in || !out) return fail("svr_patchify: null pointer");
     const int64_t total = (int64_t)T * (H / 2) * (W / 2) * kpad;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(patchify_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -244,6 +256,8 @@ int svr_unpatchify_euler(const void* pred, int64_t ldp, const void* x_t, void* o
                          int32_t C, void* stream) {
     StreamDeviceGuard on_stream_device(stream);
     if ((H & 1) || (W & 1)) return fail("svr_unpatchify_euler: H, W must be even");
+    if (!pred || !out) return fail("svr_unpatchify_euler: null pointer");
+    if (ldp < 4 * (int64_t)C) return fail("svr_unpatchify_euler: ldp must cover the 4*C prediction columns");
     const int64_t total = (int64_t)T * H * W * C;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(unpatchify_euler_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -259,6 +273,8 @@ int svr_groupnorm_stats(const void* x, double* stats, void* workspace, int32_t T
                         int32_t x_f32, void* stream) {
     StreamDeviceGuard on_stream_device(stream);
     if (T <= 0 || HW <= 0) return 0;
+    if (C <= 0 || groups <= 0 || C % groups || T > 65535) return fail("svr_groupnorm_stats: need C > 0, 1 <= groups dividing C, T <= 65535");
+    if (!x || !stats) return fail("svr_groupnorm_stats: null pointer");
     if (C % 8 || C > 512 || groups > 32 || (C / groups) % 4 || (256 % (C / 8)))
         return fail("svr_groupnorm_stats: need C in {128,256,512}-like (C%8==0, C<=512, groups<=32, (C/groups)%4==0)");
     if (!workspace) return fail("svr_groupnorm_stats: workspace missing (svr_groupnorm_workspace_bytes)");
@@ -276,7 +292,9 @@ int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float
                         int64_t HW, int32_t C, int32_t groups, float eps, int32_t apply_silu, int32_t x_f32, void* stream) {
     StreamDeviceGuard on_stream_device(stream);
     if (T <= 0 || HW <= 0) return 0;
-    if (C % 8 || C > 512) return fail("svr_groupnorm_apply: C must be a multiple of 8 and <= 512");
+    if (C <= 0 || C % 8 || C > 512) return fail("svr_groupnorm_apply: C must be a multiple of 8 and <= 512");
+    if (groups <= 0 || C % groups || T > 65535) return fail("svr_groupnorm_apply: need 1 <= groups dividing C, T <= 65535");
+    if (!x || !y || !stats) return fail("svr_groupnorm_apply: null pointer");
     const int64_t nchunks = HW * (C / 8);
     unsigned gx = blocks_for(nchunks, 256 * 4);
     if (gx > 8192) gx = 8192;
@@ -292,8 +310,8 @@ int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float
 
 int svr_im2col_causal(const void* in, void* out, const svr_conv_geom* g, int32_t kpad, void* stream) {
     StreamDeviceGuard on_stream_device(stream);
-    if (!g) return fail("svr_im2col_causal: null geometry");
-    if (g->Cin % 4 || kpad % g->Cin || kpad < g->kt * g->kh * g->kw * g->Cin)
+    if (!g || !in || !out) return fail("svr_im2col_causal: null geometry / pointer");
+    if (g->Cin <= 0 || g->Cin % 4 || kpad % g->Cin || kpad < g->kt * g->kh * g->kw * g->Cin)
         return fail("svr_im2col_causal: Cin % 4 == 0 and kpad a multiple of Cin covering all taps required");
     const int64_t total = (int64_t)g->To * g->Ho * g->Wo * (kpad / g->Cin);
     if (total <= 0) return 0;
@@ -308,6 +326,7 @@ int svr_blend_accumulate(const void* tile, float* acc, float* cnt, const float* 
     const int64_t total = (int64_t)T * h * w * C;
     if (total <= 0) return 0;
     if (y0 < 0 || x0 < 0 || y0 + h > H || x0 + w > W) return fail("svr_blend_accumulate: tile outside the canvas");
+    if (!tile || !acc || !cnt || !wy || !wx) return fail("svr_blend_accumulate: null pointer");
     hipLaunchKernelGGL(blend_accumulate_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)tile, acc, cnt, wy, wx, T, h, w, C, H, W, y0, x0);
     return check(hipGetLastError(), "svr_blend_accumulate");
@@ -318,6 +337,8 @@ int svr_blend_finalize(const float* acc, const float* cnt, void* out, int32_t T,
     StreamDeviceGuard on_stream_device(stream);
     const int64_t total = (int64_t)T * HW * c_take;
     if (total <= 0) return 0;
+    if (c_take > C) return fail("svr_blend_finalize: c_take > C");
+    if (!acc || !cnt || !out) return fail("svr_blend_finalize: null pointer");
     hipLaunchKernelGGL(blend_finalize_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, (hipStream_t)stream, acc, cnt,
                        (bf16_t*)out, T, HW, C, c_take, scale, shift);
     return check(hipGetLastError(), "svr_blend_finalize");
@@ -327,7 +348,8 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
                      void* stream) {
     StreamDeviceGuard on_stream_device(stream);
     if (rows <= 0) return 0;
-    if (c_out > c_in) return fail("svr_affine_slice: c_out > c_in");
+    if (c_out <= 0 || c_out > c_in) return fail("svr_affine_slice: need 0 < c_out <= c_in");
+    if (!in || !out) return fail("svr_affine_slice: null pointer");
     hipLaunchKernelGGL(affine_slice_kernel, dim3(blocks_for(rows * c_out, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)in, (bf16_t*)out, rows, c_in, c_out, scale, shift);
     return check(hipGetLastError(), "svr_affine_slice");

@@ -199,6 +199,15 @@ class HipOps:
             raise ValueError(f"{name} must be contiguous")
         return t
 
+    def _opt(self, t, dtype, name, numel=None):
+        """Optional (or small side) operand: None -> NULL, else device / dtype / contiguity (and element count) checked."""
+        if t is None:
+            return None
+        self._chk(t, dtype, name)
+        if numel is not None and t.numel() != numel:
+            raise ValueError(f"{name} must hold {numel} elements, got {tuple(t.shape)}")
+        return C.c_void_p(t.data_ptr())
+
     def set_option(self, key: str, value: int):
         """Tuning / measurement knob of the library (see svr_set_option in include/seedvr2_hip.h)."""
         hip_lib.check(self.lib.svr_set_option(key.encode(), int(value)), "svr_set_option")
@@ -315,7 +324,11 @@ class HipOps:
     def rmsnorm_mod(self, x, out, eps, w=None, scale=None, shift=None):
         xf = self._xf32(x); self._chk(out, BF16, "out")
         rows, dim = x.shape
-        hip_lib.check(self.lib.svr_rmsnorm_mod(_ptr(x), _ptr(out), rows, dim, eps, _ptr(w), _ptr(scale), _ptr(shift), xf,
+        if xf == STORE_H16 or tuple(out.shape) != (rows, dim):
+            raise ValueError("rmsnorm_mod: x must be bf16 or fp32 [rows, dim] and out bf16 of the same shape")
+        hip_lib.check(self.lib.svr_rmsnorm_mod(_ptr(x), _ptr(out), rows, dim, eps, self._opt(w, torch.float32, "w", dim),
+                                               self._opt(scale, torch.float32, "scale", dim),
+                                               self._opt(shift, torch.float32, "shift", dim), xf,
                                                self._stream()), "svr_rmsnorm_mod")
         return out
 
@@ -334,8 +347,11 @@ class HipOps:
         if qkv.shape[1] != 3 * heads * 128 or pos.shape != (rows, 3):
             raise ValueError("qknorm_rope: bad shapes")
         n_pos, n_freq = cos_tab.shape
+        if sin_tab.shape != cos_tab.shape:
+            raise ValueError("qknorm_rope: cos / sin tables of different shapes")
         hip_lib.check(self.lib.svr_qknorm_rope(_ptr(qkv), rows, heads, _ptr(pos), t_offset, _ptr(cos_tab),
-                                               _ptr(sin_tab), n_pos, n_freq, _ptr(wq), _ptr(wk), eps,
+                                               _ptr(sin_tab), n_pos, n_freq, self._opt(wq, torch.float32, "wq", 128),
+                                               self._opt(wk, torch.float32, "wk", 128), eps,
                                                self._stream()), "svr_qknorm_rope")
         return qkv
 
@@ -343,6 +359,9 @@ class HipOps:
         self._chk(qkv, BF16, "qkv"); self._chk(out, BF16, "out")
         for t, n in ((seq_rows, "seq_rows"), (out_rows, "out_rows"), (cu, "cu")):
             self._chk(t, torch.int32, n)
+        if qkv.dim() != 2 or out.dim() != 2 or qkv.shape[1] != 3 * heads * head_dim or out.shape[1] != heads * head_dim or \
+                seq_rows.numel() != out_rows.numel() or cu.numel() < 1:
+            raise ValueError("attn_varlen: qkv [rows, 3 * heads * head_dim], out [rows', heads * head_dim], one out_row per seq_row")
         hip_lib.check(self.lib.svr_attn_varlen(_ptr(qkv), qkv.stride(0), _ptr(out), out.stride(0), _ptr(seq_rows),
                                                _ptr(out_rows), _ptr(cu), cu.numel() - 1, max_len, heads, head_dim,
                                                scale, self._stream()), "svr_attn_varlen")
@@ -358,6 +377,8 @@ class HipOps:
 
     def rows_mean(self, src, dst, n_groups, rows_per_group):
         self._chk(src, BF16, "src"); self._chk(dst, BF16, "dst")
+        if src.numel() != n_groups * rows_per_group * src.shape[-1] or dst.numel() != rows_per_group * src.shape[-1]:
+            raise ValueError("rows_mean: src [n_groups * rows_per_group, dim], dst [rows_per_group, dim]")
         hip_lib.check(self.lib.svr_rows_mean(_ptr(src), _ptr(dst), n_groups, rows_per_group, src.shape[-1],
                                              self._stream()), "svr_rows_mean")
         return dst
@@ -382,6 +403,8 @@ class HipOps:
     def groupnorm_stats(self, x, stats, groups):
         xf = self._xf32(x); self._chk(stats, torch.float64, "stats")
         T, H, W, Cc = x.shape
+        if stats.numel() != T * groups * 2:
+            raise ValueError("groupnorm_stats: stats must be [T, groups, 2]")
         ws = torch.empty(int(self.lib.svr_groupnorm_workspace_bytes(T, H * W, groups)), dtype=torch.uint8,
                          device=self.device)
         hip_lib.check(self.lib.svr_groupnorm_stats(_ptr(x), _ptr(stats), _ptr(ws), T, H * W, Cc, groups, xf,
@@ -391,7 +414,11 @@ class HipOps:
     def groupnorm_apply(self, x, out, stats, gamma, beta, groups, eps, silu):
         xf = self._xf32(x); self._chk(out, BF16, "out")
         T, H, W, Cc = x.shape
-        hip_lib.check(self.lib.svr_groupnorm_apply(_ptr(x), _ptr(out), _ptr(stats), _ptr(gamma), _ptr(beta), T, H * W,
+        if out.numel() != x.numel():
+            raise ValueError("groupnorm_apply: out must have x's shape")
+        hip_lib.check(self.lib.svr_groupnorm_apply(_ptr(x), _ptr(out), self._opt(stats, torch.float64, "stats", T * groups * 2),
+                                                   self._opt(gamma, torch.float32, "gamma", Cc),
+                                                   self._opt(beta, torch.float32, "beta", Cc), T, H * W,
                                                    Cc, groups, eps, int(silu), xf, self._stream()), "svr_groupnorm_apply")
         return out
 
@@ -415,13 +442,19 @@ class HipOps:
     def blend_accumulate(self, tile, acc, cnt, wy, wx, y0, x0):
         self._chk(tile, BF16, "tile"); self._chk(acc, torch.float32, "acc"); self._chk(cnt, torch.float32, "cnt")
         T, h, w, Cc = tile.shape
-        _, H, W, _ = acc.shape
-        hip_lib.check(self.lib.svr_blend_accumulate(_ptr(tile), _ptr(acc), _ptr(cnt), _ptr(wy), _ptr(wx), T, h, w, Cc,
+        Ta, H, W, Ca = acc.shape
+        if (Ta, Ca) != (T, Cc) or cnt.numel() != H * W:
+            raise ValueError("blend_accumulate: acc [T, H, W, C] for tile [T, h, w, C], cnt [H, W]")
+        hip_lib.check(self.lib.svr_blend_accumulate(_ptr(tile), _ptr(acc), _ptr(cnt), self._opt(wy, torch.float32, "wy", h),
+                                                    self._opt(wx, torch.float32, "wx", w), T, h, w, Cc,
                                                     H, W, y0, x0, self._stream()), "svr_blend_accumulate")
 
     def blend_finalize(self, acc, cnt, out, scale=1.0, shift=0.0):
         self._chk(acc, torch.float32, "acc"); self._chk(out, BF16, "out")
         T, H, W, Cc = acc.shape
+        self._chk(cnt, torch.float32, "cnt")
+        if cnt.numel() != H * W or out.numel() != T * H * W * out.shape[-1]:
+            raise ValueError("blend_finalize: cnt [H, W], out [T, H, W, c_take]")
         hip_lib.check(self.lib.svr_blend_finalize(_ptr(acc), _ptr(cnt), _ptr(out), T, H * W, Cc, out.shape[-1], scale,
                                                   shift, self._stream()), "svr_blend_finalize")
         return out

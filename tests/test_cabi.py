@@ -175,3 +175,44 @@ def test_product_package_never_touches_the_oracle():
     bench = open(os.path.join(ROOT, "bench.py")).read()
     uses = [m.start() for m in re.finditer(r"from oracle import", bench)]
     assert len(uses) == 1 and bench.rfind("def cpu_baseline", 0, uses[0]) > bench.rfind("\ndef ", 0, bench.rfind("def cpu_baseline", 0, uses[0]))
+
+
+def test_entry_points_refuse_invalid_arguments_before_any_launch():
+    """Argument validation of the elementwise entry points runs on the host before the launch, so it is checked here without a
+    GPU: every call below must return non-zero and leave a message naming the entry point (never reach hipLaunchKernelGGL,
+    never divide by a zero group count on the host)."""
+    import ctypes
+    hip_lib = sub("hip_lib")
+    L = hip_lib.lib()
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    pf = ctypes.cast(buf, ctypes.POINTER(ctypes.c_float))
+    pd = ctypes.cast(buf, ctypes.POINTER(ctypes.c_double))
+    pi = ctypes.cast(buf, ctypes.POINTER(ctypes.c_int32))
+    ph = ctypes.cast(buf, ctypes.POINTER(ctypes.c_int16))
+    cases = [
+        ("svr_rmsnorm_mod", lambda: L.svr_rmsnorm_mod(p, p, 4, 2560, 1e-6, None, None, None, 2, None)),      # h16 is not a stream format
+        ("svr_rmsnorm_mod", lambda: L.svr_rmsnorm_mod(None, p, 4, 2560, 1e-6, None, None, None, 0, None)),
+        ("svr_rmsnorm_mod", lambda: L.svr_rmsnorm_mod(p, p, 4, 2564, 1e-6, None, None, None, 0, None)),
+        ("svr_ada_combine", lambda: L.svr_ada_combine(p, p, pi, pf, 70000, 2560, None)),
+        ("svr_qknorm_rope", lambda: L.svr_qknorm_rope(p, 8, 20, ph, 0, pf, pf, 16, 0, pf, pf, 1e-6, None)),
+        ("svr_qknorm_rope", lambda: L.svr_qknorm_rope(p, 8, 20, None, 0, pf, pf, 16, 21, pf, pf, 1e-6, None)),
+        ("svr_rows_mean", lambda: L.svr_rows_mean(p, p, 3, 70000, 2560, None)),
+        ("svr_patchify", lambda: L.svr_patchify(p, p, 2, 4, 6, 33, 128, None)),
+        ("svr_unpatchify_euler", lambda: L.svr_unpatchify_euler(p, 32, None, p, 2, 4, 6, 16, None)),
+        ("svr_groupnorm_stats", lambda: L.svr_groupnorm_stats(p, pd, p, 2, 64, 128, 0, 0, None)),            # zero groups: no host SIGFPE
+        ("svr_groupnorm_stats", lambda: L.svr_groupnorm_stats(p, pd, p, 2, 64, 0, 32, 0, None)),
+        ("svr_groupnorm_apply", lambda: L.svr_groupnorm_apply(p, p, pd, pf, pf, 2, 64, 128, 0, 1e-6, 1, 0, None)),
+        ("svr_groupnorm_apply", lambda: L.svr_groupnorm_apply(p, p, pd, pf, pf, 2, 64, 128, 32, 1e-6, 1, 3, None)),
+        ("svr_groupnorm_reduce", lambda: L.svr_groupnorm_reduce(None, pd, 2, 4, 32, None)),
+        ("svr_softmax_rows", lambda: L.svr_softmax_rows(pf, p, 4, 66000, 66000, 66000, 1.0, None)),
+        ("svr_blend_accumulate", lambda: L.svr_blend_accumulate(p, pf, pf, pf, pf, 1, 8, 8, 4, 8, 8, 1, 0, None)),
+        ("svr_blend_finalize", lambda: L.svr_blend_finalize(pf, pf, p, 1, 64, 4, 8, 1.0, 0.0, None)),
+        ("svr_affine_slice", lambda: L.svr_affine_slice(p, p, 4, 16, 32, 1.0, 0.0, None)),
+        ("svr_gemm_pack_frag", lambda: L.svr_gemm_pack_frag(p, p, 100, 64, None)),
+        ("svr_conv_pack_frag_taps", lambda: L.svr_conv_pack_frag_taps(p, p, 128, 100, 1, 2, 2, 32, None)),
+        ("svr_set_option", lambda: L.svr_set_option(b"no_such_knob", 1)),
+    ]
+    for name, call in cases:
+        assert call() != 0, name
+        assert name.encode() in L.svr_last_error(), (name, L.svr_last_error())
