@@ -30,6 +30,7 @@
 #include "svr_common.h"
 #include "../../include/seedvr2_hip.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace svr {
 
@@ -251,82 +252,175 @@ __global__ __launch_bounds__(NW * 64, (QW == 2 ? 1 : 2)) void attn_win_kernel(
         if (more && NP == 4) stage_piece(3, nxt);
 #undef AW_QK
 
-        // ---- online softmax, lane-local over this lane's 32 keys; the other 32 keys of the tile live in lane ^ 32
         bf16x8 pf[QW][2][2];
+        if constexpr (QW == 1) {
+            // ---- online softmax, lane-local over this lane's 32 keys; the other 32 keys of the tile live in lane ^ 32
 #pragma unroll
-        for (int b = 0; b < QW; ++b) {
-            if ((t + 1) * AW_KT > L) {                 // ragged last tile (wave-uniform): mask keys >= L
-                const int kbase = t * AW_KT + 4 * hi;
+            for (int b = 0; b < QW; ++b) {
+                if ((t + 1) * AW_KT > L) {                 // ragged last tile (wave-uniform): mask keys >= L
+                    const int kbase = t * AW_KT + 4 * hi;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= L) sacc[b][kb][r] = -INFINITY;
+                }
+                float mx = sacc[b][0][0];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= L) sacc[b][kb][r] = -INFINITY;
-            }
-            float mx = sacc[b][0][0];
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][kb][r]);
+                mx = aw_other_half_max(mx);
+                // Deferred rescale (cdna_hip_programming.md T13): while no row's maximum grew by more than 2^AW_DEFER over the
+                // reference value m_run, keep m_run -- P is then bounded by 2^AW_DEFER instead of 1 (same RELATIVE bf16 precision,
+                // fp32 accumulators) and the O / l rescale is skipped for the whole 32-query block.  Everything exponentiated in
+                // this tile uses the m_run decided HERE, and O, l are rescaled in the same place, so nothing is ever at a stale scale.
+                if (!__all((mx - m_run[b]) * scale_log2 <= AW_DEFER)) {       // also true for the first tile (m_run = -inf)
+                    const float m_new = fmaxf(m_run[b], mx);                  // finite: every tile holds at least one valid key
+                    const float alpha = fast_exp2((m_run[b] - m_new) * scale_log2);
+                    m_run[b] = m_new;
+                    l_run[b] *= alpha;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                    for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][kb][r]);
-            mx = aw_other_half_max(mx);
-            // Deferred rescale (cdna_hip_programming.md T13): while no row's maximum grew by more than 2^AW_DEFER over the
-            // reference value m_run, keep m_run -- P is then bounded by 2^AW_DEFER instead of 1 (same RELATIVE bf16 precision,
-            // fp32 accumulators) and the O / l rescale is skipped for the whole 32-query block.  Everything exponentiated in
-            // this tile uses the m_run decided HERE, and O, l are rescaled in the same place, so nothing is ever at a stale scale.
-            if (!__all((mx - m_run[b]) * scale_log2 <= AW_DEFER)) {       // also true for the first tile (m_run = -inf)
-                const float m_new = fmaxf(m_run[b], mx);                  // finite: every tile holds at least one valid key
-                const float alpha = fast_exp2((m_run[b] - m_new) * scale_log2);
-                m_run[b] = m_new;
-                l_run[b] *= alpha;
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[b][m][r] *= alpha;
-            }
-            const float mc = m_run[b] * scale_log2;
-            f32x2 ps = {0.f, 0.f};
-            const f32x2 c2 = {scale_log2, scale_log2}, mc2 = {-mc, -mc};
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    float p[8];
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const f32x2 sv = {sacc[b][kb][8 * u + e], sacc[b][kb][8 * u + e + 1]};
-                        const f32x2 a = __builtin_elementwise_fma(sv, c2, mc2);            // v_pk_fma_f32
-                        p[e] = fast_exp2(a[0]);
-                        p[e + 1] = fast_exp2(a[1]);
-                        const f32x2 pv = {p[e], p[e + 1]};
-                        ps += pv;                                                           // v_pk_add_f32
-                    }
-                    const uint4 pk = pack8(p);
-                    pf[b][kb][u] = __builtin_bit_cast(bf16x8, pk);
+                        for (int r = 0; r < 16; ++r) o[b][m][r] *= alpha;
                 }
-            l_run[b] += ps[0] + ps[1];
-        }
+                const float mc = m_run[b] * scale_log2;
+                f32x2 ps = {0.f, 0.f};
+                const f32x2 c2 = {scale_log2, scale_log2}, mc2 = {-mc, -mc};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        float p[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2 sv = {sacc[b][kb][8 * u + e], sacc[b][kb][8 * u + e + 1]};
+                            const f32x2 a = __builtin_elementwise_fma(sv, c2, mc2);            // v_pk_fma_f32
+                            p[e] = fast_exp2(a[0]);
+                            p[e + 1] = fast_exp2(a[1]);
+                            const f32x2 pv = {p[e], p[e + 1]};
+                            ps += pv;                                                           // v_pk_add_f32
+                        }
+                        const uint4 pk = pack8(p);
+                        pf[b][kb][u] = __builtin_bit_cast(bf16x8, pk);
+                    }
+                l_run[b] += ps[0] + ps[1];
+            }
 
-        // ---- O^T += V^T P^T : 4 k-steps (16 keys each) x 4 d blocks; the reads of k-step g+1 fly under the MFMAs of g
+            // ---- O^T += V^T P^T : 4 k-steps (16 keys each) x 4 d blocks; the reads of k-step g+1 fly under the MFMAs of g
 #define AW_PV(V, KB, U)                                                                                            \
-        if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                     \
-        _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                              \
-            const bf16x8 vf = __builtin_shufflevector(V[2 * m], V[2 * m + 1], 0, 1, 2, 3, 4, 5, 6, 7);               \
-            _Pragma("unroll") for (int b = 0; b < QW; ++b)                                                           \
-                o[b][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][KB][U], o[b][m], 0, 0, 0);               \
-        }                                                                                                            \
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        aw_tr8<4096>(vB, va_[0], va_[1], va_[2], va_[3]);
-        aw_wait_lgkm<8>(vA);
-        AW_PV(vA, 0, 0)
-        aw_tr8<8192>(vA, va_[0], va_[1], va_[2], va_[3]);
-        aw_wait_lgkm<8>(vB);
-        AW_PV(vB, 0, 1)
-        aw_tr8<12288>(vB, va_[0], va_[1], va_[2], va_[3]);
-        aw_wait_lgkm<8>(vA);
-        AW_PV(vA, 1, 0)
-        aw_wait_lgkm<0>(vB);
-        AW_PV(vB, 1, 1)
+            if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                     \
+            _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                              \
+                const bf16x8 vf = __builtin_shufflevector(V[2 * m], V[2 * m + 1], 0, 1, 2, 3, 4, 5, 6, 7);               \
+                _Pragma("unroll") for (int b = 0; b < QW; ++b)                                                           \
+                    o[b][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][KB][U], o[b][m], 0, 0, 0);               \
+            }                                                                                                            \
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            aw_tr8<4096>(vB, va_[0], va_[1], va_[2], va_[3]);
+            aw_wait_lgkm<8>(vA);
+            AW_PV(vA, 0, 0)
+            aw_tr8<8192>(vA, va_[0], va_[1], va_[2], va_[3]);
+            aw_wait_lgkm<8>(vB);
+            AW_PV(vB, 0, 1)
+            aw_tr8<12288>(vB, va_[0], va_[1], va_[2], va_[3]);
+            aw_wait_lgkm<8>(vA);
+            AW_PV(vA, 1, 0)
+            aw_wait_lgkm<0>(vB);
+            AW_PV(vB, 1, 1)
 #undef AW_PV
+        } else {
+            // ---- QW = 2.  One wave per SIMD: nothing but this wave's own instruction stream can run VALU work under its MFMAs, so
+            // the exponentials are cut into four slices (k-step (kb, u): 8 scores per lane and block) and every slice but the
+            // first is placed inside the MFMA group BEFORE the one that consumes it:
+            //   statistics of both blocks (max, rescale decision)  ->  P(0,0)  |  PV(0,0) || P(0,1)  |  PV(0,1) || P(1,0)  |
+            //   PV(1,0) || P(1,1)  |  PV(1,1)
+            // Same values in the same order as the QW = 1 path (the row sums are accumulated slice by slice in its order), so
+            // the result is bit-identical; PRIO builds add sched_group_barrier hints (one MFMA : five VALU / TRANS issues).
+            float mcv[QW];
+            f32x2 psv[QW];
+#pragma unroll
+            for (int b = 0; b < QW; ++b) {
+                if ((t + 1) * AW_KT > L) {             // ragged last tile (wave-uniform): mask keys >= L
+                    const int kbase = t * AW_KT + 4 * hi;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= L) sacc[b][kb][r] = -INFINITY;
+                }
+                float mx = sacc[b][0][0];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][kb][r]);
+                mx = aw_other_half_max(mx);
+                if (!__all((mx - m_run[b]) * scale_log2 <= AW_DEFER)) {   // deferred rescale, per 32-query block (see the QW = 1 path)
+                    const float m_new = fmaxf(m_run[b], mx);
+                    const float alpha = fast_exp2((m_run[b] - m_new) * scale_log2);
+                    m_run[b] = m_new;
+                    l_run[b] *= alpha;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[b][m][r] *= alpha;
+                }
+                mcv[b] = m_run[b] * scale_log2;
+                psv[b] = f32x2{0.f, 0.f};
+            }
+            auto pexp = [&](auto bc, auto kbc, auto uc) {      // P slice (kb, u) of block b: 8 exponentials, packed to bf16
+                constexpr int B = decltype(bc)::value, KB = decltype(kbc)::value, U = decltype(uc)::value;
+                const f32x2 c2 = {scale_log2, scale_log2}, mc2 = {-mcv[B], -mcv[B]};
+                float p[8];
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 sv = {sacc[B][KB][8 * U + e], sacc[B][KB][8 * U + e + 1]};
+                    const f32x2 a = __builtin_elementwise_fma(sv, c2, mc2);
+                    p[e] = fast_exp2(a[0]);
+                    p[e + 1] = fast_exp2(a[1]);
+                    const f32x2 pv = {p[e], p[e + 1]};
+                    psv[B] += pv;
+                }
+                const uint4 pk = pack8(p);
+                pf[B][KB][U] = __builtin_bit_cast(bf16x8, pk);
+            };
+#define AW_I(v) std::integral_constant<int, (v)>{}
+#define AW_P2(KB, U) pexp(AW_I(0), AW_I(KB), AW_I(U)); pexp(AW_I(1), AW_I(KB), AW_I(U))
+#define AW_PV2(V, KB, U)                                                                                           \
+            _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                          \
+                const bf16x8 vf = __builtin_shufflevector(V[2 * m], V[2 * m + 1], 0, 1, 2, 3, 4, 5, 6, 7);           \
+                o[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][KB][U], o[0][m], 0, 0, 0);               \
+                o[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][KB][U], o[1][m], 0, 0, 0);               \
+            }
+#define AW_SGB()                                                                                                   \
+            if (PRIO) { _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                              \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA */                               \
+                __builtin_amdgcn_sched_group_barrier(0x402, 5, 0); } }  /* five VALU / TRANS issues in its shadow */
+            AW_P2(0, 0);
+            aw_tr8<4096>(vB, va_[0], va_[1], va_[2], va_[3]);
+            aw_wait_lgkm<8>(vA);
+            AW_PV2(vA, 0, 0)
+            AW_P2(0, 1);
+            AW_SGB()
+            aw_tr8<8192>(vA, va_[0], va_[1], va_[2], va_[3]);
+            aw_wait_lgkm<8>(vB);
+            AW_PV2(vB, 0, 1)
+            AW_P2(1, 0);
+            AW_SGB()
+            aw_tr8<12288>(vB, va_[0], va_[1], va_[2], va_[3]);
+            aw_wait_lgkm<8>(vA);
+            AW_PV2(vA, 1, 0)
+            AW_P2(1, 1);
+            AW_SGB()
+            aw_wait_lgkm<0>(vB);
+            AW_PV2(vB, 1, 1)
+#undef AW_SGB
+#undef AW_PV2
+#undef AW_P2
+#undef AW_I
+#pragma unroll
+            for (int b = 0; b < QW; ++b) l_run[b] += psv[b][0] + psv[b][1];
+        }
         next_rows(t + 2);                              // (after the last counted wait: hipcc's own lgkmcnt(0) here is harmless)
         const int flip = (t & 1) ? -AW_TILE : AW_TILE;   // the other buffer of the K pair / V pair
 #pragma unroll

@@ -16,16 +16,32 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 @pytest.fixture(scope="module")
-def device_asm(tmp_path_factory):
+def compiled(tmp_path_factory):
+    """Device-only assembly of the product build and of the -DSVR_ABLATIONS measurement build, compiled SIDE BY SIDE (two hipcc
+    processes: the two passes are most of this module's minutes): {"product": (returncode, stderr, asm text), "ablations": ...}."""
     if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
         pytest.skip("hipcc not available")
     hip_lib = sub("hip_lib")
-    out = tmp_path_factory.mktemp("asm") / "svr_api.s"
-    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc"] + [f for f in hip_lib.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + \
-          ["-S", "--cuda-device-only", os.path.join(hip_lib.CSRC, "svr_api.hip"), "-o", str(out)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    return out.read_text()
+    d = tmp_path_factory.mktemp("asm")
+    base = [HIPCC if os.path.exists(HIPCC) else "hipcc"] + [f for f in hip_lib.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    src = os.path.join(hip_lib.CSRC, "svr_api.hip")
+    jobs = {}
+    for tag, extra in (("product", []), ("ablations", ["-DSVR_ABLATIONS"])):
+        out = d / f"svr_api_{tag}.s"
+        jobs[tag] = (subprocess.Popen(base + extra + ["-S", "--cuda-device-only", src, "-o", str(out)],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), out)
+    res = {}
+    for tag, (proc, out) in jobs.items():
+        _, err = proc.communicate()
+        res[tag] = (proc.returncode, err, out.read_text() if proc.returncode == 0 and out.exists() else "")
+    return res
+
+
+@pytest.fixture(scope="module")
+def device_asm(compiled):
+    rc, err, asm = compiled["product"]
+    assert rc == 0, err[-2000:]
+    return asm
 
 
 def _kernels(asm):
@@ -84,18 +100,11 @@ def test_no_kernel_uses_scratch(device_asm):
     assert not bad, bad
 
 
-def test_measurement_build_compiles(tmp_path):
+def test_measurement_build_compiles(compiled):
     """The -DSVR_ABLATIONS build (measurement-only kernel variants behind svr_set_option("pipe_abl"), tools/conv_timeline.py)
-    must keep compiling: its variants instantiate the hand-written inline asm with different surrounding code."""
-    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
-        pytest.skip("hipcc not available")
-    hip_lib = sub("hip_lib")
-    # device pass only (the variants live in device code; the host pass and the link add a minute and prove nothing more)
-    out = tmp_path / "svr_api_abl.s"
-    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc"] + [f for f in hip_lib.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + \
-          ["-DSVR_ABLATIONS", "-S", "--cuda-device-only", os.path.join(hip_lib.CSRC, "svr_api.hip"), "-o", str(out)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
-    asm = out.read_text()
+    must keep compiling: its variants instantiate the hand-written inline asm with different surrounding code.  Device pass only
+    (the variants live in device code; the host pass and the link add a minute and prove nothing more)."""
+    rc, err, asm = compiled["ablations"]
+    assert rc == 0, err[-3000:]
     assert "conv_halo2_kernelILi16ELi3ELi256E" in asm and "gemm_w4p_kernelILb1ELi8E" in asm      # timeline / ablation variants
     assert "gemm_w4r_kernelILi4ELb1E" in asm and "gemm_w4r_kernelILi16ELb0E" in asm               # K-loop ablations of gemm_w4r_kernel
