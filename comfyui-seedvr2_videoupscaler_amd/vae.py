@@ -120,7 +120,7 @@ class VideoVAEEngine:
     def __init__(self, cfg: VAEConfig, state_dict: Dict[str, torch.Tensor], ops,
                  act_budget_bytes: int = 12 << 30, merge_upsamplers: bool = True, merge_causal_head: bool = True,
                  trunk_fp32: Optional[bool] = None, branch_fp32: Optional[bool] = None, tile_streams: int = 1,
-                 trunk_store: Optional[str] = None, branch_store: Optional[str] = None):
+                 trunk_store: Optional[str] = None, branch_store: Optional[str] = None, overflow_guard: bool = True):
         """``tile_streams`` (default 1): spatial tiles of a tiled encode / decode are independent until the blend
         (attn_video_vae.py:1302-1630), so they CAN be issued round-robin onto several HIP streams, the HBM-bound passes of one tile
         (GroupNorm apply, statistics, layout copies) in the shadow of another tile's MFMA-bound convolutions; the blends are issued
@@ -146,7 +146,12 @@ class VideoVAEEngine:
         fp32 / fp32 50.01 dB, h16 / h16 49.99 dB, fp32 / bf16 (round 3's default) 49.76 dB, bf16 / bf16 (round 2) 48.20 dB -- h16 is
         as good as fp32 at half the bytes: GroupNorm-apply reads 2 instead of 4 B per element, conv2 epilogues store half as much
         (round 3's fp32 trunk cost +2.4 % of the BASELINE config 3 step, its fp32 branch another +2.1 %).
-        ``trunk_fp32`` / ``branch_fp32`` (rounds 2-3, kept for A/B): True -> "fp32", False -> "bf16" for the respective tensor."""
+        ``trunk_fp32`` / ``branch_fp32`` (rounds 2-3, kept for A/B): True -> "fp32", False -> "bf16" for the respective tensor.
+        ``overflow_guard`` (default on): h16 ends at +-4.2e6 where bf16 / fp32 (what the reference runs in) go on to 3e38.  The
+        synthetic and fixture weights stay orders of magnitude below that, but an un-normalised activation of a real checkpoint
+        beyond it would turn into inf on store and into NaN behind the next GroupNorm.  encode() / decode() therefore look at ONE
+        fp32 sum of their result (a single reduction over the output, one host sync per call) and, when it is not finite while an
+        h16 store is in use, run the call again with those stores in fp32 -- same kernels, their fp32 instances -- and warn."""
         self.cfg, self.ops = cfg, ops
         kinds = {"bf16": None, "h16": torch.float16, "fp32": torch.float32}      # None: the ops' activation dtype
         # (the exact-arithmetic CPU double of the C ABI -- act_dtype fp32, host-logic tests -- keeps everything in its one dtype)
@@ -158,6 +163,8 @@ class VideoVAEEngine:
                 ("fp32" if (branch_fp32 and trunk_store != "bf16") else "bf16")
         self.trunk_store, self.branch_store = trunk_store, branch_store
         self.trunk_dtype, self.branch_dtype = kinds[trunk_store], kinds[branch_store]
+        self.overflow_guard = bool(overflow_guard)
+        self.overflow_reruns = 0            # calls the guard had to repeat with fp32 stores
         self.device = ops.device
         self.act_budget_bytes = act_budget_bytes
         self.tile_streams = int(tile_streams)
@@ -696,10 +703,35 @@ class VideoVAEEngine:
         x[..., :Cc] = x_cthw.to(device=self.device, dtype=self.ops.act_dtype).permute(1, 2, 3, 0)   # layout only
         return x
 
+    def _guarded(self, call):
+        """Run ``call()``; if its result is not finite and an h16 store is in use, once more with those stores in fp32 (see
+        ``overflow_guard`` in __init__)."""
+        out = call()
+        if not self.overflow_guard or "h16" not in (self.trunk_store, self.branch_store):
+            return out
+        if bool(torch.isfinite(out.sum(dtype=torch.float32))):
+            return out
+        import warnings
+        warnings.warn("VideoVAEEngine: non-finite output with h16 stores (an activation beyond +-4.2e6?); repeating the call with "
+                      "fp32 stores", RuntimeWarning, stacklevel=3)
+        saved = (self.trunk_store, self.trunk_dtype, self.branch_store, self.branch_dtype)
+        if self.trunk_store == "h16":
+            self.trunk_store, self.trunk_dtype = "fp32", torch.float32
+        if self.branch_store == "h16":
+            self.branch_store, self.branch_dtype = "fp32", torch.float32
+        self.overflow_reruns += 1
+        try:
+            return call()
+        finally:
+            self.trunk_store, self.trunk_dtype, self.branch_store, self.branch_dtype = saved
+
     @torch.no_grad()
     def encode(self, x_cthw: torch.Tensor, tiled: bool = False, tile_size=(512, 512), tile_overlap=(64, 64),
                frames_per_slice: Optional[int] = None) -> torch.Tensor:
         """[3, T, H, W] in [-1, 1] -> scaled latent [T', H/8, W/8, 16] = (mean - shift) * scale."""
+        return self._guarded(lambda: self._encode(x_cthw, tiled, tile_size, tile_overlap, frames_per_slice))
+
+    def _encode(self, x_cthw, tiled, tile_size, tile_overlap, frames_per_slice):
         cfg, ops = self.cfg, self.ops
         if x_cthw.dim() == 3:
             x_cthw = x_cthw.unsqueeze(1)
@@ -750,6 +782,9 @@ class VideoVAEEngine:
         after decode, generation_phases.py:953-958): the decoder is causal in time, so the latent frames that only feed
         trimmed output and, at full frame rate, the trimmed frames themselves are not computed -> [3, n, 8h, 8w], equal to
         the first n frames of the full decode."""
+        return self._guarded(lambda: self._decode(latent_thwc, tiled, tile_size, tile_overlap, latents_per_slice, keep_frames))
+
+    def _decode(self, latent_thwc, tiled, tile_size, tile_overlap, latents_per_slice, keep_frames):
         cfg, ops = self.cfg, self.ops
         lat = latent_thwc.to(device=self.device, dtype=self.ops.act_dtype).contiguous()
         if lat.dim() == 3:

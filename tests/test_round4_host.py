@@ -51,6 +51,39 @@ def test_vae_engine_storage_regimes_on_the_cpu_double():
     assert vae.VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=BF16), trunk_fp32=False).branch_store == "bf16"
 
 
+def test_vae_engine_h16_overflow_guard_repeats_the_call_with_fp32_stores():
+    """h16 ends at +-4.2e6.  A decoder whose conv_in is scaled so that the trunk exceeds that (bf16 / fp32, what the reference
+    computes in, hold it easily) turns into inf -> NaN under h16 stores; the engine notices the non-finite result and runs the
+    call again with fp32 stores: same answer as an engine built with fp32 stores, one warning, h16 restored afterwards."""
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    cfg = config.VAE_TINY
+    sd = dict(weights.synth_vae_state_dict(cfg, seed=2))
+    for k in ("decoder.conv_in.weight", "decoder.conv_in.bias", "encoder.conv_in.weight", "encoder.conv_in.bias"):
+        sd[k] = sd[k] * 3.0e8
+    z = (torch.randn(2, 6, 8, 16, generator=torch.Generator().manual_seed(1))).to(BF16)
+    wide = vae.VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=BF16), trunk_store="fp32", branch_store="fp32").decode(z)
+    assert torch.isfinite(wide.float()).all()
+    unguarded = vae.VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=BF16), overflow_guard=False)
+    assert not torch.isfinite(unguarded.decode(z).float()).all()             # the failure the guard exists for
+    eng = vae.VideoVAEEngine(cfg, sd, TorchOps("cpu", act_dtype=BF16))
+    with pytest.warns(RuntimeWarning, match="h16"):
+        got = eng.decode(z)
+    assert torch.equal(got, wide) and eng.overflow_reruns == 1
+    assert (eng.trunk_store, eng.branch_store, eng.trunk_dtype, eng.branch_dtype) == ("h16", "h16", H16, H16)
+    x = (torch.rand(3, 5, 16, 16, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(BF16)
+    with pytest.warns(RuntimeWarning, match="h16"):
+        lat = eng.encode(x)
+    assert torch.isfinite(lat.float()).all() and eng.overflow_reruns == 2
+    # ordinary weights: no rerun, no warning, no change of the result
+    sd0 = weights.synth_vae_state_dict(cfg, seed=2)
+    e0 = vae.VideoVAEEngine(cfg, sd0, TorchOps("cpu", act_dtype=BF16))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        a = e0.decode(z)
+    assert e0.overflow_reruns == 0 and torch.equal(a, vae.VideoVAEEngine(cfg, sd0, TorchOps("cpu", act_dtype=BF16), overflow_guard=False).decode(z))
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="needs the reference checkout (the recipe compiles it)")
 def test_oracle_ref_recipe_compiles_the_reference_without_copying_source(tmp_path):
     """oracle/build_ref.py: a sourceless tree of byte-compiled modules + marshalled definitions; the loader imports the
