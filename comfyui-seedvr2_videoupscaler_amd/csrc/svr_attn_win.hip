@@ -123,7 +123,15 @@ SVR_DEVICE void aw_wait_lgkm(bf16x4 (&v)[8]) {
 // the two blocks' MFMAs alternate on independent accumulators.  Per query row the arithmetic (MFMA order, rescale decisions
 // -- taken per 32-query block, and the blocks are the same 32-aligned blocks in every build) is unchanged, so all builds
 // agree bit for bit.  192 accumulator + 64 Q registers per wave: one wave per SIMD (launch bound 1).
-template <int NW, bool PRIO, int QW = 1>
+// PIPE (QW = 2 only; attn_variant 7 / 8): K Q^T runs ONE TILE AHEAD of the softmax.  Iteration t holds S(t) with its statistics done
+// and computes, in this order,  K(t+1) Q^T -> S(t+1)  with the exponentials of S(t) between its MFMA groups,  V(t)^T P(t)^T,  the
+// row sums, then the statistics (max, deferred rescale) of S(t+1).  LDS protocol: K is staged TWO tiles ahead, V one; with the one
+// barrier at the end of an iteration that is still two buffers each -- in iteration t the waves READ K buffer (t+1)&1 and V buffer
+// t&1 and the LDS-DMA WRITES K(t+2) into K buffer t&1 (last read in iteration t-1, before that iteration's barrier) and V(t+1)
+// into V buffer (t+1)&1 (ditto); the prologue needs one extra barrier, between K(0) Q^T and the first refill of K buffer 0.
+// The operations on O, l and the running max happen in the same order as in every other build (rescale(t), PV(t), rescale(t+1),
+// PV(t+1), ...), so the result is again bit-identical.  The accumulating score set is copied into the one the VALU reads at the end of an iteration.
+template <int NW, bool PRIO, int QW = 1, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64, (QW == 2 ? 1 : 2)) void attn_win_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld_qkv, bf16_t* __restrict__ out, int64_t ld_out,
     const int32_t* __restrict__ seq_rows, const int32_t* __restrict__ out_rows, const int32_t* __restrict__ cu,
@@ -214,6 +222,197 @@ __global__ __launch_bounds__(NW * 64, (QW == 2 ? 1 : 2)) void attn_win_kernel(
 
     __syncthreads();                                   // tile 0 landed (vmcnt(0) + barrier)
 
+    if constexpr (PIPE) {
+        static_assert(QW == 2 && NW == 4 && NP == 4, "the pipelined loop is written for four waves x 64 queries");
+        const char* nsk[NP];                           // source rows of the K tile to stage (two tiles ahead); nsrc: of the V tile (one ahead)
+        auto k_rows = [&](int t) {
+            const int tt = min(t, nk - 1);
+#pragma unroll
+            for (int it = 0; it < NP; ++it) nsk[it] = qbase + ((uint64_t)srow[tt * AW_KT + it * (4 * NW) + st_key] << 4);
+        };
+        auto stage_k = [&](int it, int buf) { glds16(nsk[it] + k_off + st_k, smem + buf * AW_TILE + wave * 1024 + it * (NW * 1024)); };
+        auto stage_v = [&](int it, int buf) { glds16(nsrc[it] + v_off + st_v, smem + (2 + buf) * AW_TILE + wave * 1024 + it * (NW * 1024)); };
+        float mcv[QW];
+        f32x2 psv[QW];
+        bf16x8 kA[4], kB[4];
+        bf16x4 vA[8], vB[8];
+        bf16x8 pf[QW][2][2];
+        f32x16 sA[QW][2], sB[QW][2];
+        // statistics of one score set (tile `tile`): ragged mask, row max, deferred rescale of O and l (per 32-query block)
+        auto stats = [&](f32x16 (&S)[QW][2], int tile) __attribute__((always_inline)) {
+#pragma unroll
+            for (int b = 0; b < QW; ++b) {
+                if ((tile + 1) * AW_KT > L) {          // ragged last tile (wave-uniform): mask keys >= L
+                    const int kbase = tile * AW_KT + 4 * hi;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= L) S[b][kb][r] = -INFINITY;
+                }
+                float mx = S[b][0][0];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[b][kb][r]);
+                mx = aw_other_half_max(mx);
+                if (!__all((mx - m_run[b]) * scale_log2 <= AW_DEFER)) {
+                    const float m_new = fmaxf(m_run[b], mx);
+                    const float alpha = fast_exp2((m_run[b] - m_new) * scale_log2);
+                    m_run[b] = m_new;
+                    l_run[b] *= alpha;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[b][m][r] *= alpha;
+                }
+                mcv[b] = m_run[b] * scale_log2;
+                psv[b] = f32x2{0.f, 0.f};
+            }
+        };
+        auto pexp = [&](f32x16 (&S)[QW][2], auto bc, auto kbc, auto uc) __attribute__((always_inline)) {
+            constexpr int B = decltype(bc)::value, KB = decltype(kbc)::value, U = decltype(uc)::value;
+            const f32x2 c2 = {scale_log2, scale_log2}, mc2 = {-mcv[B], -mcv[B]};
+            float p[8];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 sv = {S[B][KB][8 * U + e], S[B][KB][8 * U + e + 1]};
+                const f32x2 a = __builtin_elementwise_fma(sv, c2, mc2);
+                p[e] = fast_exp2(a[0]);
+                p[e + 1] = fast_exp2(a[1]);
+                const f32x2 pv = {p[e], p[e + 1]};
+                psv[B] += pv;
+            }
+            const uint4 pk = pack8(p);
+            pf[B][KB][U] = __builtin_bit_cast(bf16x8, pk);
+        };
+#define AW_I(v) std::integral_constant<int, (v)>{}
+#define AW_P2(S, KB, U) pexp(S, AW_I(0), AW_I(KB), AW_I(U)); pexp(S, AW_I(1), AW_I(KB), AW_I(U))
+#define AW_QK2(K, Q0, S, KB)                                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                              \
+            S[0][KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(K[e], qf[0][Q0 + e], S[0][KB], 0, 0, 0);              \
+            S[1][KB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(K[e], qf[1][Q0 + e], S[1][KB], 0, 0, 0);              \
+        }
+#define AW_PV2(V, KB, U)                                                                                           \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                              \
+            const bf16x8 vf = __builtin_shufflevector(V[2 * m], V[2 * m + 1], 0, 1, 2, 3, 4, 5, 6, 7);               \
+            o[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][KB][U], o[0][m], 0, 0, 0);                   \
+            o[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][KB][U], o[1][m], 0, 0, 0);                   \
+        }
+#define AW_SGB()                                                                                                   \
+        if (PRIO) { _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x402, 5, 0); } }
+        auto zero_s = [&](f32x16 (&S)[QW][2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int b = 0; b < QW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { S[b][0][r] = 0.f; S[b][1][r] = 0.f; }
+        };
+
+        // ---- prologue: K(1) -> K buffer 1 (rows of tile 1 are in nsrc), S(0) = K(0) Q^T, its statistics; the rows of K(2)
+#pragma unroll
+        for (int it = 0; it < NP; ++it) glds16(nsrc[it] + k_off + st_k, smem + AW_TILE + wave * 1024 + it * (NW * 1024));
+        zero_s(sA);
+        aw_k4<0>(kA, ka_[0], ka_[1], ka_[2], ka_[3]);
+        aw_k4<0>(kB, ka_[4], ka_[5], ka_[6], ka_[7]);
+        aw_wait_k<4>(kA);
+        AW_QK2(kA, 0, sA, 0)
+        aw_k4<8192>(kA, ka_[0], ka_[1], ka_[2], ka_[3]);
+        aw_wait_k<4>(kB);
+        AW_QK2(kB, 4, sA, 0)
+        aw_k4<8192>(kB, ka_[4], ka_[5], ka_[6], ka_[7]);
+        aw_wait_k<4>(kA);
+        AW_QK2(kA, 0, sA, 1)
+        aw_wait_k<0>(kB);
+        AW_QK2(kB, 4, sA, 1)
+        stats(sA, 0);
+        k_rows(2);
+#pragma unroll
+        for (int ds = 0; ds < 8; ++ds) ka_[ds] += AW_TILE;      // iteration 0 reads K(1) from K buffer 1
+        __syncthreads();                               // K(1) landed (vmcnt(0)); every wave is done reading K buffer 0, which iteration 0 refills
+
+        // ---- one tile.  Sc = S(t), statistics done; Sn (not LAST) receives S(t+1).
+        auto iter = [&](auto lastc, f32x16 (&Sc)[QW][2], f32x16 (&Sn)[QW][2], const int t) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(lastc)::value != 0;
+            const int kw = t & 1, vw = kw ^ 1;         // buffers being refilled: K(t+2) -> kw, V(t+1) -> vw
+            if constexpr (!LAST) {
+                // (K(t+2) is staged unconditionally: past the last tile k_rows() clamps to it and the copy lands in a buffer nobody
+                // reads again -- a wave-uniform branch here would cut the MFMA groups and the exponentials into separate blocks)
+                zero_s(Sn);
+                aw_k4<0>(kA, ka_[0], ka_[1], ka_[2], ka_[3]);
+                aw_k4<0>(kB, ka_[4], ka_[5], ka_[6], ka_[7]);
+                aw_wait_k<4>(kA);
+                AW_QK2(kA, 0, Sn, 0)
+                AW_P2(Sc, 0, 0);
+                AW_SGB()
+                stage_k(0, kw);
+                stage_v(0, vw);
+                aw_k4<8192>(kA, ka_[0], ka_[1], ka_[2], ka_[3]);
+                aw_wait_k<4>(kB);
+                AW_QK2(kB, 4, Sn, 0)
+                AW_P2(Sc, 0, 1);
+                AW_SGB()
+                stage_k(1, kw);
+                stage_v(1, vw);
+                aw_k4<8192>(kB, ka_[4], ka_[5], ka_[6], ka_[7]);
+                aw_wait_k<4>(kA);
+                AW_QK2(kA, 0, Sn, 1)
+                AW_P2(Sc, 1, 0);
+                AW_SGB()
+                stage_k(2, kw);
+                stage_v(2, vw);
+                aw_tr8<0>(vA, va_[0], va_[1], va_[2], va_[3]);         // V^T fragments of the first k-step
+                aw_wait_k<8>(kB);
+                AW_QK2(kB, 4, Sn, 1)
+                stage_k(3, kw);
+                stage_v(3, vw);
+            } else {
+                aw_tr8<0>(vA, va_[0], va_[1], va_[2], va_[3]);
+                AW_P2(Sc, 0, 0);
+                AW_P2(Sc, 0, 1);
+                AW_P2(Sc, 1, 0);
+            }
+            aw_tr8<4096>(vB, va_[0], va_[1], va_[2], va_[3]);
+            aw_wait_lgkm<8>(vA);
+            AW_PV2(vA, 0, 0)
+            AW_P2(Sc, 1, 1);
+            AW_SGB()
+            aw_tr8<8192>(vA, va_[0], va_[1], va_[2], va_[3]);
+            aw_wait_lgkm<8>(vB);
+            AW_PV2(vB, 0, 1)
+            aw_tr8<12288>(vB, va_[0], va_[1], va_[2], va_[3]);
+            aw_wait_lgkm<8>(vA);
+            AW_PV2(vA, 1, 0)
+            aw_wait_lgkm<0>(vB);
+            AW_PV2(vB, 1, 1)
+#pragma unroll
+            for (int b = 0; b < QW; ++b) l_run[b] += psv[b][0] + psv[b][1];
+            if constexpr (!LAST) {
+                stats(Sn, t + 1);
+                next_rows(t + 2);                      // V(t+2): staged in iteration t + 1
+                k_rows(t + 3);                         // K(t+3)
+                const int flip = (t & 1) ? -AW_TILE : AW_TILE;
+#pragma unroll
+                for (int ds = 0; ds < 8; ++ds) ka_[ds] -= flip;        // K(t+2) sits in K buffer t & 1
+#pragma unroll
+                for (int m = 0; m < 4; ++m) va_[m] += flip;            // V(t+1) in V buffer (t+1) & 1
+                __syncthreads();                       // K(t+2), V(t+1) landed (vmcnt(0)); everyone is done with K buffer (t+1)&1 and V buffer t&1
+            }
+        };
+        int t = 0;
+        for (; t + 1 < nk; ++t) {
+            iter(AW_I(0), sA, sB, t);
+#pragma unroll
+            for (int b = 0; b < QW; ++b) { sA[b][0] = sB[b][0]; sA[b][1] = sB[b][1]; }   // (the accumulating set lives in AGPRs: this is the read-out the VALU needs anyway)
+        }
+        iter(AW_I(1), sA, sA, t);
+#undef AW_SGB
+#undef AW_PV2
+#undef AW_QK2
+#undef AW_P2
+#undef AW_I
+    } else
     for (int t = 0; t < nk; ++t) {
         const int nxt = (t & 1) ^ 1;
         const bool more = t + 1 < nk;                  // wave-uniform
@@ -456,15 +655,15 @@ __global__ __launch_bounds__(NW * 64, (QW == 2 ? 1 : 2)) void attn_win_kernel(
 
 // svr_set_option("attn_variant", v): A/B knob over the build variants -- 0 = default (8 waves; measured best on both window
 // families, profiles/r2_attn_kbench.jsonl), 1 = 4 waves + s_setprio, 2 = 8 waves, 3 = 8 waves + s_setprio, 4 = 4 waves,
-// 5 = 4 waves x 64 queries (one wave per SIMD; written at the end of round 4 with no GPU minutes left: opt-in until measured),
-// 6 = 5 + s_setprio
+// 5 = 4 waves x 64 queries (one wave per SIMD; 5 .. 8 were written at the end of round 4 with no GPU minutes left: opt-in until measured),
+// 6 = 5 + sched_group_barrier hints, 7 = 5 with K Q^T one tile ahead of the softmax (PIPE), 8 = 7 + hints
 int g_attn_variant = 0;
 
-template <int NW, bool PRIO, int QW = 1>
+template <int NW, bool PRIO, int QW = 1, bool PIPE = false>
 static int launch_attn_win_t(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,
                              const int32_t* out_rows, const int32_t* cu, int n_seq, int max_len, int heads, float scale,
                              hipStream_t s) {
-    auto kern = attn_win_kernel<NW, PRIO, QW>;
+    auto kern = attn_win_kernel<NW, PRIO, QW, PIPE>;
     static uint64_t lds_attr_done = 0;               // per device (svr_common.h)
     {
         const int e = set_max_dynamic_lds((const void*)kern, AW_LDS, lds_attr_done);
@@ -492,6 +691,8 @@ static int launch_attn_win(const void* qkv, int64_t ld_qkv, void* out, int64_t l
         case 4: return launch_attn_win_t<4, false>(AW_ARGS);
         case 5: return launch_attn_win_t<4, false, 2>(AW_ARGS);
         case 6: return launch_attn_win_t<4, true, 2>(AW_ARGS);
+        case 7: return launch_attn_win_t<4, false, 2, true>(AW_ARGS);
+        case 8: return launch_attn_win_t<4, true, 2, true>(AW_ARGS);
         default: return launch_attn_win_t<8, false>(AW_ARGS);
     }
 #undef AW_ARGS

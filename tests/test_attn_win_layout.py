@@ -187,3 +187,39 @@ def test_attn_win_bank_model():
         addr = hi * 1024 + jr * 256 + ((((m ^ jr) << 2) | (2 * G + (c4 >> 1))) << 4) + (c4 & 1) * 8
         for g in (range(0, 32), range(32, 64)):
             assert len({int(a // 8) % 32 for a in addr[list(g)]}) == 32
+
+
+@pytest.mark.parametrize("nk", [1, 2, 3, 4, 7, 32])
+def test_attn_win_pipelined_buffer_protocol(nk):
+    """attn_variant 7 / 8 (K Q^T one tile ahead): K is staged two tiles ahead, V one, into two buffers each, with ONE barrier at
+    the end of an iteration (+ one behind the prologue's K(0) Q^T).  This restates the kernel's buffer rules (which buffer an
+    iteration reads, which it refills, how the read addresses flip) and checks, per barrier interval, that every read sees the tile
+    it means to, that no buffer is refilled in an interval in which it is read, and that what an interval reads was written in an
+    EARLIER interval (the barrier + vmcnt(0) between them is what makes the LDS-DMA data visible)."""
+    K = [None, None]; V = [None, None]                  # tile held by each buffer; writes of the current interval go to `pending`
+    def interval(reads_k, reads_v, writes):
+        for kind, buf, tile in reads_k + reads_v:
+            held = (K if kind == "K" else V)[buf]
+            assert held == tile, (kind, buf, tile, held)
+        read_bufs = {(kind, buf) for kind, buf, _ in reads_k + reads_v}
+        for kind, buf, tile in writes:
+            assert (kind, buf) not in read_bufs, ("refill of a buffer read in the same interval", kind, buf)
+        for kind, buf, tile in writes:                  # land before the closing barrier
+            (K if kind == "K" else V)[buf] = tile
+    clamp = lambda t: min(t, nk - 1)
+    # kernel entry .. first barrier: K(0) -> K0, V(0) -> V0
+    interval([], [], [("K", 0, 0), ("V", 0, 0)])
+    # prologue: K(1) -> K1 (rows of tile 1, clamped), S(0) = K(0) Q^T from K buffer 0; barrier
+    ka, va = 0, 0
+    interval([("K", ka, 0)], [], [("K", 1, clamp(1))])
+    ka = 1                                               # ka_ += AW_TILE
+    t = 0
+    while t + 1 < nk:                                    # iter<not LAST>
+        kw, vw = t & 1, (t & 1) ^ 1
+        interval([("K", ka, t + 1)], [("V", va, t)], [("K", kw, clamp(t + 2)), ("V", vw, t + 1)])
+        flip = -1 if (t & 1) else 1
+        ka -= flip; va += flip
+        assert ka in (0, 1) and va in (0, 1)
+        t += 1
+    interval([], [("V", va, t)], [])                     # iter<LAST>: P V of the last tile, nothing staged
+    assert t == nk - 1
