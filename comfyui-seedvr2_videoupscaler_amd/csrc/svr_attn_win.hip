@@ -131,7 +131,15 @@ SVR_DEVICE void aw_wait_lgkm(bf16x4 (&v)[8]) {
 // into V buffer (t+1)&1 (ditto); the prologue needs one extra barrier, between K(0) Q^T and the first refill of K buffer 0.
 // The operations on O, l and the running max happen in the same order as in every other build (rescale(t), PV(t), rescale(t+1),
 // PV(t+1), ...), so the result is again bit-identical.  The accumulating score set is copied into the one the VALU reads at the end of an iteration.
-template <int NW, bool PRIO, int QW = 1, bool PIPE = false>
+// ASYM (attn_variant 9 / 10; QW = 1): the instruction mix of this kernel is balanced -- per wave and tile 1 024 cycles
+// of MFMAs (K Q^T, then V^T P^T) around ~960 cycles of softmax VALU work -- so two waves per SIMD could keep the MFMA pipe busy all the
+// time, IF they ran in opposite phases.  They do not: every wave leaves the tile barrier at the same moment, both waves of a SIMD
+// issue K Q^T together (sharing the pipe), then both sit in the softmax (sharing the VALU port): ~3 970 cycles per tile pair, which is
+// the 46 % MFMA-busy the counters show.  With one wave of each SIMD at a higher priority that wave's K Q^T goes first and its softmax
+// runs under the other wave's K Q^T, its V^T P^T under the other's softmax: ~2 500 cycles by the same arithmetic.  Nothing but the
+// issue order changes.  ASYM = 1: waves 0 .. NW/2-1 are the favoured ones (waves w and w + NW/2 share a SIMD if the dispatcher deals
+// waves round-robin over the four SIMDs), ASYM = 2: the even waves (if it fills SIMD by SIMD).
+template <int NW, bool PRIO, int QW = 1, bool PIPE = false, int ASYM = 0>
 __global__ __launch_bounds__(NW * 64, (QW == 2 ? 1 : 2)) void attn_win_kernel(
     const bf16_t* __restrict__ qkv, int64_t ld_qkv, bf16_t* __restrict__ out, int64_t ld_out,
     const int32_t* __restrict__ seq_rows, const int32_t* __restrict__ out_rows, const int32_t* __restrict__ cu,
@@ -155,6 +163,9 @@ __global__ __launch_bounds__(NW * 64, (QW == 2 ? 1 : 2)) void attn_win_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int nk = (L + AW_KT - 1) / AW_KT;
+    if constexpr (ASYM != 0) {
+        if (ASYM == 1 ? (wave < NW / 2) : ((wave & 1) == 0)) __builtin_amdgcn_s_setprio(2);
+    }
 
     const int64_t ld_bytes = ld_qkv * 2;                  // (multiple of 16: checked by the launcher)
     for (int i = tid; i < nk * AW_KT; i += NW * 64)
@@ -656,14 +667,15 @@ __global__ __launch_bounds__(NW * 64, (QW == 2 ? 1 : 2)) void attn_win_kernel(
 // svr_set_option("attn_variant", v): A/B knob over the build variants -- 0 = default (8 waves; measured best on both window
 // families, profiles/r2_attn_kbench.jsonl), 1 = 4 waves + s_setprio, 2 = 8 waves, 3 = 8 waves + s_setprio, 4 = 4 waves,
 // 5 = 4 waves x 64 queries (one wave per SIMD; 5 .. 8 were written at the end of round 4 with no GPU minutes left: opt-in until measured),
-// 6 = 5 + sched_group_barrier hints, 7 = 5 with K Q^T one tile ahead of the softmax (PIPE), 8 = 7 + hints
+// 6 = 5 + sched_group_barrier hints, 7 = 5 with K Q^T one tile ahead of the softmax (PIPE), 8 = 7 + hints,
+// 9 / 10 = the default build with one wave of each SIMD at a higher issue priority (waves 0 .. 3 / the even waves)
 int g_attn_variant = 0;
 
-template <int NW, bool PRIO, int QW = 1, bool PIPE = false>
+template <int NW, bool PRIO, int QW = 1, bool PIPE = false, int ASYM = 0>
 static int launch_attn_win_t(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, const int32_t* seq_rows,
                              const int32_t* out_rows, const int32_t* cu, int n_seq, int max_len, int heads, float scale,
                              hipStream_t s) {
-    auto kern = attn_win_kernel<NW, PRIO, QW, PIPE>;
+    auto kern = attn_win_kernel<NW, PRIO, QW, PIPE, ASYM>;
     static uint64_t lds_attr_done = 0;               // per device (svr_common.h)
     {
         const int e = set_max_dynamic_lds((const void*)kern, AW_LDS, lds_attr_done);
@@ -693,6 +705,8 @@ static int launch_attn_win(const void* qkv, int64_t ld_qkv, void* out, int64_t l
         case 6: return launch_attn_win_t<4, true, 2>(AW_ARGS);
         case 7: return launch_attn_win_t<4, false, 2, true>(AW_ARGS);
         case 8: return launch_attn_win_t<4, true, 2, true>(AW_ARGS);
+        case 9: return launch_attn_win_t<8, false, 1, false, 1>(AW_ARGS);
+        case 10: return launch_attn_win_t<8, false, 1, false, 2>(AW_ARGS);
         default: return launch_attn_win_t<8, false>(AW_ARGS);
     }
 #undef AW_ARGS
