@@ -46,6 +46,7 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "pipe_abl")) { g_pipe_abl = value; return 0; }
     if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
     if (!strcmp(key, "gemm_epi")) { g_gemm_epi = value; return 0; }
+    if (!strcmp(key, "gemm_asym")) { if ((unsigned)value > 2u) return fail("svr_set_option: gemm_asym is 0, 1 or 2"); g_gemm_asym = value; return 0; }
     if (!strcmp(key, "gemm_w4")) { g_gemm_w4 = value; return 0; }
     if (!strcmp(key, "gemm_w4r")) { g_gemm_w4r = value; return 0; }
     if (!strcmp(key, "conv_rows")) { g_conv_rows = value; return 0; }

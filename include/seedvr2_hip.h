@@ -255,6 +255,8 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * brings the activations into LDS by LDS-DMA | 2 the same with the activations staged through registers | 0 it stages both operands
  * through LDS whether W_frag is given or not,
  * "gemm_epi" epilogue of the GEMM kernel: 0 auto | 1 stores straight from the accumulators | 2 through LDS wherever possible,
+ * "gemm_asym" issue priorities inside the eight-wave GEMM / generic conv kernel: 0 none (default) | 1 waves 0 .. 3 of a workgroup
+ * favoured | 2 its even waves (one wave of each SIMD goes first out of the K-tile barrier; scheduling only),
  * "attn_impl" 0 auto (second-generation window kernel for head_dim 128 / windows <= 2048 rows) | 1 first kernel everywhere,
  * "attn_variant" build variant of the second-generation window kernel (0 default = 8 waves x 32 queries; 1 / 3 / 4: 4-wave and
  * s_setprio builds; 5 / 6: 4 waves x 64 queries, one wave per SIMD; 7 / 8: the same with K Q^T one tile ahead of the softmax;
