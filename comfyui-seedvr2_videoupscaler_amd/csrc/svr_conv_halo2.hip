@@ -738,6 +738,27 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
         const int kr = RT ? a.resid_f32 : ((F & 8) != 0 ? SVR_STORE_H16 : SVR_STORE_BF16);
         const bool o32 = ko == SVR_STORE_FP32, r32 = kr == SVR_STORE_FP32;
         const bool with_gn = RT ? a.gn_partial != nullptr : F_GN;
+        // 8-row kernel, compiled option sets with a (bf16 / h16) residual: the residual chunks of a pass are loaded ONE PASS AHEAD --
+        // pass 0's before the first parking, pass p + 1's right behind pass p's barrier -- instead of inside the store sweeps that
+        // consume them, so their latency runs under the LDS parking, the barrier and the previous pass's sweeps.  Same values, same
+        // arithmetic: bit-identical, -1.9 % on the 128 -> 128 conv2 form, -0.8 % at 256 / 512 channels (same box, standalone harness:
+        // profiles/r4_conv_epilogue_resid_prefetch_ab.txt).  64 more registers in the epilogue (456 of 512): the kernels that run two
+        // workgroups per CU keep the loads inside their sweeps.
+        constexpr bool PRE = W8 && !RT && F_RESID;
+        uint4 rpre[2][8];
+        auto resid_prefetch = [&](auto pc, uint4 (&dst)[8]) {
+            constexpr int P = decltype(pc)::value;
+            const int n_ = n0 + (tid & 15) * 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int vox = (q * NT + tid) >> 4;
+                const int r = vox >> 5;
+                const int y = y0 + (r >> 1) * MTW + 2 * P + (r & 1), x = x0 + (vox & 31);
+                const int64_t m_ = ((int64_t)to * g.H + min(y, g.H - 1)) * g.W + min(x, g.W - 1);
+                dst[q] = *(const uint4*)((const bf16_t*)a.resid + m_ * a.ldr + n_);
+            }
+        };
+        if constexpr (PRE) resid_prefetch(std::integral_constant<int, 0>{}, rpre[0]);
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             // every wave parks two of its MTW rows per pass (all waves write in every pass): LDS slot row wm * 2 + j
@@ -758,6 +779,13 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             SVR_EP_STAMP(1 + 3 * pass)                     // LDS writes issued
             if constexpr ((DBG & 512) != 0) __syncthreads(); else lds_barrier();      // (512: round 2's barriers, for the A/B)
             SVR_EP_STAMP(2 + 3 * pass)                     // barrier passed
+            if constexpr (PRE) {
+                if (pass + 1 < NPASS) {
+                    if (pass == 0) resid_prefetch(std::integral_constant<int, 1>{}, rpre[1]);
+                    else if (pass == 1) resid_prefetch(std::integral_constant<int, 2>{}, rpre[0]);
+                    else if (pass == 2) resid_prefetch(std::integral_constant<int, 3>{}, rpre[1]);
+                }
+            }
             // store side, branch-free sweeps of four iterations so their LDS reads and residual loads are in flight
             // together (out-of-image voxels read a clamped address and are masked at the store)
             const int n = n0 + (tid & 15) * 8;
@@ -793,8 +821,13 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
                         rf1[it] = *(const f32x4*)(rp + 4);
                     }
                 } else {
+                    if constexpr (PRE) {
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) rr8[it] = *(const uint4*)((const bf16_t*)a.resid + mrow[it] * a.ldr + n);
+                        for (int it = 0; it < 4; ++it) rr8[it] = rpre[pass & 1][half * 4 + it];
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) rr8[it] = *(const uint4*)((const bf16_t*)a.resid + mrow[it] * a.ldr + n);
+                    }
                 }
             }
 #pragma unroll

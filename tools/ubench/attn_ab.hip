@@ -3,7 +3,7 @@
 // 20 heads x 128, qkv [291 658, 7 680] bf16 filled with hashed values.  For every attn_variant on the command line: two warm-up calls,
 // `reps` timed calls (HIP events), TFLOP/s, and a 64-bit checksum of the output -- all builds must print the SAME checksum (same MFMAs
 // in the same order per query row).   usage: attn_ab [reps] [variant ...]      (default: 10 reps, variants 0 9 10)
-// build: tools/ubench/build_attn_ab.sh   (links libseedvr2_hip.so by rpath; measurement aid, not part of the product)
+// build: tools/ubench/build_ubench.sh   (links libseedvr2_hip.so by rpath; measurement aid, not part of the product)
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
