@@ -8,6 +8,9 @@
 //   c256   3x3x3 256->256 @512^2    same          c512   3x3x3 512->512 @256^2   same     c128r / c256s   ragged image borders, 1x3x3 taps
 //   sc256  1x1x1 256->128 @1024^2   decoder shortcut (generic kernel, h16 out)        sc128  1x1x1 128->256 @512^2   encoder shortcut
 //   ds128  3x3x3 128->128 @1024^2 stride (1,2,2) pad (0,1)  encoder downsampler       ds256  3x3x3 256->256 @512^2 stride (2,2,2)
+//   sp256  (3,2,2)-tap phases 256->256 @512^2 -> 1024^2: the four spatial phases of the spatial sub-pixel upsampler as ONE quad launch
+//   sp512  (2,2,2)-tap phases 512->512 @256^2 -> 512^2, output frames interleaved (t_stride 2): one temporal phase of the temporal upsampler
+//          (conv_sub_kernel; bf16 out, fused GroupNorm statistics, a halo tensor for the causal head -- as vae.py::_upsample_subpixel)
 // build: tools/ubench/build_ubench.sh   (measurement aid, not part of the product)
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -45,7 +48,7 @@ __global__ void checksum(const uint16_t* p, int64_t n, unsigned long long* out) 
     atomicAdd(out, s);
 }
 
-struct Case { const char* name; int T, H, W, Cin, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw; bool conv2; };
+struct Case { const char* name; int T, H, W, Cin, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw; bool conv2; int sub_tstride = 0; };
 static const Case CASES[] = {
     {"c128", 5, 1024, 1024, 128, 128, 3, 3, 3, 1, 1, 1, 2, 1, 1, true},
     {"c256", 5, 512, 512, 256, 256, 3, 3, 3, 1, 1, 1, 2, 1, 1, true},
@@ -56,6 +59,8 @@ static const Case CASES[] = {
     {"sc128", 5, 512, 512, 128, 256, 1, 1, 1, 1, 1, 1, 0, 0, 0, false},
     {"ds128", 5, 1024, 1024, 128, 128, 3, 3, 3, 1, 2, 2, 2, 0, 0, false},
     {"ds256", 5, 512, 512, 256, 256, 3, 3, 3, 2, 2, 2, 2, 0, 0, false},
+    {"sp256", 5, 512, 512, 256, 256, 3, 2, 2, 1, 1, 1, 2, 1, 1, false, 1},
+    {"sp512", 5, 256, 256, 512, 512, 2, 2, 2, 1, 1, 1, 1, 1, 1, false, 2},
 };
 
 static int apply_options(const std::string& set) {
@@ -93,8 +98,11 @@ int main(int argc, char** argv) {
         const int To = (c->T + c->pt - c->kt) / c->st + 1;
         const int Ho = c->sh == 1 ? c->H : c->H / 2, Wo = c->sw == 1 ? c->W : c->W / 2;
         const int K = c->kt * c->kh * c->kw * c->Cin, N = c->Cout, Npad = (N + 127) / 128 * 128;
-        const int64_t n_in = (int64_t)c->T * c->H * c->W * c->Cin, n_out = (int64_t)To * Ho * Wo * N, n_w = (int64_t)Npad * K;
-        uint16_t *x, *w, *wf = nullptr, *out;
+        const bool sub = c->sub_tstride > 0;             // quad phase launch: dense [To * t_stride, 2 H, 2 W, N] output
+        const int64_t n_in = (int64_t)c->T * c->H * c->W * c->Cin, n_w = (int64_t)Npad * K;
+        const int64_t n_out = sub ? (int64_t)To * c->sub_tstride * 4 * Ho * Wo * N : (int64_t)To * Ho * Wo * N;
+        uint16_t *x, *w, *wf = nullptr, *out, *halo = nullptr;
+        float* bias_border = nullptr;
         _Float16* resid = nullptr;
         float* bias;
         void* partial = nullptr;
@@ -119,8 +127,24 @@ int main(int argc, char** argv) {
             const int nblk = svr_gemm_gn_blocks(&a);
             if (nblk > 0) { partial_bytes = (int64_t)To * nblk * 32 * 16; CK(hipMalloc(&partial, partial_bytes)); a.gn_partial = partial; } else a.gn_groups = 0;
         }
+        if (sub) {
+            // one weight set for the four phases (timing / checksum do not care), a halo tensor holding the causal head frames
+            const int64_t n_halo = (int64_t)c->pt * c->H * c->W * c->Cin;
+            CK(hipMalloc(&wf, n_w * 2)); CK(hipMalloc(&halo, n_halo * 2)); CK(hipMalloc(&bias_border, 3 * Npad * 4));
+            if (svr_conv_pack_frag_taps(w, wf, Npad, K, c->kt, 2, 2, c->Cin, nullptr) != 0) { fprintf(stderr, "%s\n", svr_last_error()); return 1; }
+            hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, halo, n_halo, 7u, 1.5f);
+            hipLaunchKernelGGL(fill_f32, dim3(4), dim3(256), 0, 0, bias_border, (int64_t)3 * Npad, 0.02f);
+            a.out_f32 = SVR_STORE_BF16; a.ldc = 0;
+            a.conv.halo = halo; a.conv.halo_frames = c->pt;
+            a.phase.enabled = 1; a.phase.t_stride = c->sub_tstride; a.phase.quad = 1;
+            for (int p = 0; p < 4; ++p) { a.phase.W_frag4[p] = wf; a.phase.bias4[p] = bias; a.phase.bias_border4[p] = bias_border; }
+            a.W_frag = wf; a.phase.bias_border = bias_border;
+            a.gn_groups = 32;
+            const int nblk = svr_gemm_gn_blocks(&a);
+            if (nblk > 0) { partial_bytes = (int64_t)To * c->sub_tstride * nblk * 32 * 16; CK(hipMalloc(&partial, partial_bytes)); CK(hipMemset(partial, 0, partial_bytes)); a.gn_partial = partial; } else a.gn_groups = 0;
+        }
         CK(hipDeviceSynchronize());
-        const double flops = 2.0 * c->Cin * N * c->kt * c->kh * c->kw * (double)To * Ho * Wo;
+        const double flops = (sub ? 4.0 : 1.0) * 2.0 * c->Cin * N * c->kt * c->kh * c->kw * (double)To * Ho * Wo;
         for (const std::string& set : sets) {
             if (apply_options(set)) return 1;
             const int cls = svr_gemm_kernel_class(&a);
@@ -152,6 +176,8 @@ int main(int argc, char** argv) {
         hipFree(x); hipFree(w); hipFree(out); hipFree(bias);
         if (wf) hipFree(wf);
         if (resid) hipFree(resid);
+        if (halo) hipFree(halo);
+        if (bias_border) hipFree(bias_border);
         if (partial) hipFree(partial);
     }
     return 0;
