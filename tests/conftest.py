@@ -25,14 +25,55 @@ def pytest_collection_modifyitems(config, items):
     strided / 1x1x1 / ragged-Cout rows of CONV_CASES under conv_impl 0, the run-time conv epilogue body through the fp32-trunk
     option sets of tests/test_gpu_wide_trunk.py.  What `variants` holds is only what no default route selects: conv_impl 1 on
     3x3 stride-1 shapes, conv_rows 4, the LDS-weight halo kernel, attn_impl 1 on windows the second kernel serves."""
-    if "variants" in (config.getoption("-m") or ""):
+    if "variants" not in (config.getoption("-m") or ""):
+        keep, drop = [], []
+        for it in items:
+            (drop if it.get_closest_marker("variants") else keep).append(it)
+        if drop:
+            config.hook.pytest_deselected(items=drop)
+            items[:] = keep
+    _start_measurement_build(config, items)
+
+
+MEASUREMENT_TEST = "test_measurement_build_compiles"
+
+
+def _start_measurement_build(config, items):
+    """The -DSVR_ABLATIONS device pass (tests/test_kernel_resources.py::test_measurement_build_compiles) takes three minutes of one
+    core: when that test is part of the run, its compile is started NOW, in the background, the test is moved to the end of the
+    run and only collects the result -- the suite's other minutes hide it."""
+    if getattr(config, "workerinput", None) is not None:      # (pytest-xdist worker: let the test compile inline)
         return
-    keep, drop = [], []
-    for it in items:
-        (drop if it.get_closest_marker("variants") else keep).append(it)
-    if drop:
-        config.hook.pytest_deselected(items=drop)
-        items[:] = keep
+    mine = [it for it in items if it.name == MEASUREMENT_TEST]
+    marker = config.getoption("-m") or ""
+    if not mine or ("not gpu" not in marker and marker) or config.getoption("collectonly", False):
+        return                                                 # (a GPU-only selection deselects the test later; --collect-only runs nothing)
+    import shutil
+    import subprocess
+    import tempfile
+    hip_lib = importlib.import_module(f"{PKG}.hip_lib")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = shutil.which("hipcc")
+    if not hipcc:
+        return
+    out = os.path.join(tempfile.mkdtemp(prefix="svr_abl_"), "svr_api_ablations.s")
+    cmd = [hipcc] + [f for f in hip_lib.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + \
+          ["-DSVR_ABLATIONS", "-S", "--cuda-device-only", os.path.join(hip_lib.CSRC, "svr_api.hip"), "-o", out]
+    # (own process group: hipcc runs clang++ through a shell, and an interrupted run must be able to take all of them down)
+    config._svr_measurement_build = (subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                                      start_new_session=True), out)
+    items[:] = [it for it in items if it.name != MEASUREMENT_TEST] + mine
+
+
+def pytest_unconfigure(config):
+    job = getattr(config, "_svr_measurement_build", None)
+    if job is not None and job[0].poll() is None:              # (run interrupted before the test collected it: do not leave it behind)
+        import signal
+        try:
+            os.killpg(job[0].pid, signal.SIGTERM)
+        except OSError:
+            job[0].kill()
 
 
 def sub(name):
