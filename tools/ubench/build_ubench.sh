@@ -8,3 +8,4 @@ for t in attn_ab conv_ab gemm_ab; do
         -L../../comfyui-seedvr2_videoupscaler_amd/csrc -lseedvr2_hip -Wl,-rpath,'$ORIGIN/../../comfyui-seedvr2_videoupscaler_amd/csrc'
     echo built tools/ubench/$t
 done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 stream_ab.hip -o stream_ab && echo built tools/ubench/stream_ab
