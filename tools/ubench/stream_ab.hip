@@ -2,7 +2,9 @@
 // svr_groupnorm_apply (6.8 % of a BASELINE config 3 step at 5.0 TB/s; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy) cost on top?
 // The kernel below is that pass re-stated with its knobs as template arguments -- same per-element arithmetic (svr_common.h: h16 unpack,
 // x * a_c + b_c, SiLU by v_exp_f32 + v_rcp_f32, hardware bf16 pack), so every variant of a MATH level writes the SAME BITS (checksum printed):
-//   MATH      0 plain copy of the 16-byte chunks | 1 unpack + affine + pack | 2 + SiLU (the product's hot form)
+//   MATH      0 plain copy of the 16-byte chunks | 1 unpack + affine + pack | 2 + SiLU compiled in | 4 + SiLU behind a run-time flag (the product's
+//             hot form: 115 full-rate + 32 quarter-rate VALU instructions per two chunks = 972 issue cycles per wave, 16 of them v_cndmask)
+//             | 3 = 2 on packed fp32 (v_pk_fma / v_pk_mul / v_pk_add: same bits, half the issue slots for those operations)
 //   NT        0 default cache policy | 1 non-temporal loads and stores (the product) | 2 non-temporal stores only
 //   PATTERN   0 grid-stride over a frame's chunks, grid (8192, T) (the product) | 1 every workgroup owns ONE contiguous span of its frame
 //             | 2 persistent: 8 workgroups per CU walk contiguous spans of the whole tensor
@@ -34,22 +36,38 @@ template <int NT> __device__ __forceinline__ void st16(uint4* p, const uint4& v)
     else *p = v;
 }
 
-// one 16-byte chunk = 8 consecutive channels of one voxel; channel block = chunk index % (C / 8)
-template <int MATH> __device__ __forceinline__ uint4 transform(const uint4& v, const float* a_s, const float* b_s, int c0) {
+// one 16-byte chunk = 8 consecutive channels of one voxel; channel block = chunk index % (C / 8).
+// MATH 2: SiLU compiled in;  4: behind a run-time flag, as in the product (a v_cndmask per element on top);  3: the same arithmetic on
+// float2 vectors -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue two lanes' worth per slot, IEEE-identical to the scalar forms.
+typedef __attribute__((ext_vector_type(2))) float f32x2_s;
+template <int MATH> __device__ __forceinline__ uint4 transform(const uint4& v, const float* a_s, const float* b_s, int c0, int apply_silu) {
     if constexpr (MATH == 0) return v;
     float f[8];
     unpack8h_raw(v, f);
+    if constexpr (MATH == 3) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float u = f[e] * a_s[c0 + e] + b_s[c0 + e];
-        f[e] = MATH == 2 ? silu(u) : u;
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2_s x = {f[e], f[e + 1]}, a = {a_s[c0 + e], a_s[c0 + e + 1]}, b = {b_s[c0 + e], b_s[c0 + e + 1]};
+            const f32x2_s u = __builtin_elementwise_fma(x, a, b);
+            const f32x2_s t = u * f32x2_s{-1.4426950408889634f, -1.4426950408889634f};
+            const f32x2_s d = f32x2_s{fast_exp2(t[0]), fast_exp2(t[1])} + f32x2_s{1.0f, 1.0f};
+            const f32x2_s r = u * f32x2_s{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            f[e] = r[0]; f[e + 1] = r[1];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float u = f[e] * a_s[c0 + e] + b_s[c0 + e];
+            f[e] = MATH == 2 ? silu(u) : MATH == 4 ? (apply_silu ? silu(u) : u) : u;
+        }
     }
     return pack8(f);
 }
 
 template <int MATH, int NT, int PATTERN, int INFLIGHT>
 __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, const float* __restrict__ scale,
-                                                     const float* __restrict__ offset, int64_t chunks_per_frame, int cchunks, int frames) {
+                                                     const float* __restrict__ offset, int64_t chunks_per_frame, int cchunks, int frames,
+                                                     int apply_silu) {
     __shared__ float a_s[512], b_s[512];
     for (int c = threadIdx.x; c < cchunks * 8; c += 256) { a_s[c] = scale[c]; b_s[c] = offset[c]; }
     __syncthreads();
@@ -76,8 +94,8 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ x
             for (int e = 0; e < 8; ++e) { sa[e] = a_s[c0 + e]; sb[e] = b_s[c0 + e]; }
         }
         auto tf = [&](const uint4& v, int64_t idx) {
-            if constexpr (FIXED) return transform<MATH>(v, sa, sb, 0);
-            else return transform<MATH>(v, a_s, b_s, (int)(idx % cchunks) * 8);
+            if constexpr (FIXED) return transform<MATH>(v, sa, sb, 0, apply_silu);
+            else return transform<MATH>(v, a_s, b_s, (int)(idx % cchunks) * 8, apply_silu);
         };
         int64_t i = first;
         for (; i + (INFLIGHT - 1) * step < last; i += INFLIGHT * step) {
@@ -106,11 +124,11 @@ __global__ void checksum(const uint16_t* p, int64_t n, unsigned long long* out) 
     atomicAdd(out, s);
 }
 
-struct Variant { int math, nt, pattern, inflight; void (*fn)(const uint4*, uint4*, const float*, const float*, int64_t, int, int); };
+struct Variant { int math, nt, pattern, inflight; void (*fn)(const uint4*, uint4*, const float*, const float*, int64_t, int, int, int); };
 #define V(M, N, P, I) {M, N, P, I, stream_kernel<M, N, P, I>}
 static const Variant VARIANTS[] = {
-    // the product's knobs at the three math levels
-    V(0, 1, 0, 2), V(1, 1, 0, 2), V(2, 1, 0, 2),
+    // the product's knobs: copy, affine, + SiLU compiled in, + SiLU behind the run-time flag (the product), + SiLU on packed fp32
+    V(0, 1, 0, 2), V(1, 1, 0, 2), V(2, 1, 0, 2), V(4, 1, 0, 2), V(3, 1, 0, 2), V(3, 1, 0, 4), V(3, 1, 1, 4), V(3, 1, 2, 4),
     // cache policy
     V(0, 0, 0, 2), V(0, 2, 0, 2), V(2, 0, 0, 2), V(2, 2, 0, 2),
     // chunks in flight
@@ -150,7 +168,7 @@ int main(int argc, char** argv) {
             unsigned gx = (unsigned)((chunks_per_frame + 1023) / 1024);
             if (gx > 8192) gx = 8192;                      // (the product's launch: svr_api.hip svr_groupnorm_apply)
             const dim3 grid = v.pattern == 2 ? dim3(prop.multiProcessorCount * 8) : dim3(gx, c->T);
-            auto launch = [&]() { hipLaunchKernelGGL(v.fn, grid, dim3(256), 0, 0, (const uint4*)x, (uint4*)y, scale, offset, chunks_per_frame, c->C / 8, c->T); };
+            auto launch = [&]() { hipLaunchKernelGGL(v.fn, grid, dim3(256), 0, 0, (const uint4*)x, (uint4*)y, scale, offset, chunks_per_frame, c->C / 8, c->T, 1); };
             CK(hipMemset(y, 0, n * 2));
             launch(); launch();
             CK(hipDeviceSynchronize());
