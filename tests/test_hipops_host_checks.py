@@ -63,7 +63,81 @@ def recorded():
     veng.decode(torch.randn_like(lat.float()).to(lat.dtype))
     veng.encode(x, tiled=True, tile_size=(32, 32), tile_overlap=(8, 8))
     veng.decode(torch.randn_like(lat.float()).to(lat.dtype), tiled=True, tile_size=(32, 32), tile_overlap=(8, 8))
+    # the call patterns the first four do not reach: several temporal slices with their carried halos, a decode that skips trimmed
+    # frames, the other storage regimes of the residual trunk (fp32 / bf16: other operand kinds in every GroupNorm / epilogue call),
+    # the reference's two-step upsampler and three-tap head, and the 7B family's block (GELU MLP, rope3d tables, no output norm)
+    x9 = torch.rand(3, 9, 32, 48).to(torch.bfloat16)
+    lat9 = veng.encode(x9, frames_per_slice=4)
+    veng.decode(torch.randn_like(lat9.float()).to(lat9.dtype), latents_per_slice=1, keep_frames=6)
+    veng.decode(torch.randn_like(lat9.float()).to(lat9.dtype), tiled=True, tile_size=(32, 32), tile_overlap=(8, 8), keep_frames=7)
+    for kw in (dict(trunk_store="fp32", branch_store="bf16"), dict(trunk_store="bf16"), dict(trunk_store="fp32", branch_store="fp32"),
+               dict(merge_upsamplers=False, merge_causal_head=False)):
+        v2 = sub("vae").VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg), ops, overflow_guard=False, **kw)
+        l2 = v2.encode(x)
+        v2.decode(torch.randn_like(l2.float()).to(l2.dtype))
+    cfg7 = config.DIT_7B_TINY
+    eng7 = sub("dit").NaDiTEngine(cfg7, weights.synth_dit_state_dict(cfg7), ops)
+    eng7.forward(vid, weights.synth_text_embedding(), 1000.0, x_t=vid[..., :16].contiguous())
     return lib.calls, n_dit
+
+
+class RoutedFakeLib(FakeLib):
+    """FakeLib whose ROUTING answers are the real library's: svr_gemm_kernel_class / svr_gemm_gn_blocks are pure host functions of
+    libseedvr2_hip.so (no GPU needed), so HipOps takes the branches it takes on the GPU -- fused GroupNorm statistics (partial
+    buffers, svr_groupnorm_reduce, the shared buffer of a sub-pixel upsampler's launches) and the four phases as ONE quad launch."""
+
+    def __init__(self, real):
+        super().__init__()
+        self.real = real
+
+    def __getattr__(self, name):
+        if name in ("svr_gemm_kernel_class", "svr_gemm_gn_blocks"):
+            real_fn = getattr(self.real, name)
+
+            def fn(*args):
+                self.calls.append((name, args))
+                return real_fn(*args)
+            return fn
+        return super().__getattr__(name)
+
+
+@pytest.fixture(scope="module")
+def recorded_routed():
+    hip_lib = sub("hip_lib")
+    try:
+        real = hip_lib.lib()
+    except hip_lib.HipLibraryError as e:
+        pytest.skip(f"libseedvr2_hip.so not built: {e}")
+    config, weights = sub("config"), sub("weights")
+    lib = RoutedFakeLib(real)
+    ops = fake_hipops(lib)
+    torch.manual_seed(0)
+    vcfg = config.VAE_V3
+    veng = sub("vae").VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg), ops, overflow_guard=False)
+    x = torch.rand(3, 9, 64, 96).to(torch.bfloat16)
+    lat = veng.encode(x, frames_per_slice=4)
+    veng.decode(torch.randn_like(lat.float()).to(lat.dtype), latents_per_slice=1, keep_frames=7)
+    veng.decode(torch.randn_like(lat.float()).to(lat.dtype), tiled=True, tile_size=(32, 48), tile_overlap=(8, 8))
+    cfg = config.DIT_TINY
+    eng = sub("dit").NaDiTEngine(cfg, weights.synth_dit_state_dict(cfg), ops)
+    vid = torch.randn(3, 16, 24, 33).to(torch.bfloat16)
+    eng.forward(vid, weights.synth_text_embedding(), 1000.0, x_t=vid[..., :16].contiguous())
+    return lib.calls
+
+
+def test_engines_pass_hipops_validation_on_the_routes_the_library_picks(recorded_routed):
+    """Same engines, the library's own routing: the launches that fuse GroupNorm statistics and the quad phase launches go through
+    HipOps' bookkeeping (partial buffers sized from svr_gemm_gn_blocks, svr_groupnorm_reduce, gn_shared) without tripping a check."""
+    calls = recorded_routed
+    names = [c[0] for c in calls]
+    assert "svr_groupnorm_reduce" in names                        # fused statistics were taken and reduced
+    gemms = [c[1][0]._obj for c in calls if c[0] == "svr_gemm_bf16"]
+    assert any(a.gn_partial for a in gemms) and any(a.phase.enabled and a.phase.quad for a in gemms)
+    assert any(a.W_frag for a in gemms)
+    for name, a in calls:
+        if name == "svr_groupnorm_reduce":
+            T, nblk, groups = a[2], a[3], a[4]
+            assert T > 0 and nblk > 0 and groups == 32, a
 
 
 def test_engines_pass_hipops_validation_and_reach_every_entry_point(recorded):
