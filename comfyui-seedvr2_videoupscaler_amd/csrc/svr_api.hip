@@ -300,6 +300,16 @@ int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float
     unsigned gx = blocks_for(nchunks, 256 * 4);
     if (gx > 8192) gx = 8192;
     if ((unsigned)x_f32 > (unsigned)SVR_STORE_H16) return fail("svr_groupnorm_apply: x_f32 must be SVR_STORE_BF16 / _FP32 / _H16");
+#if SVR_GN_PACKED
+    if (x_f32 != SVR_STORE_FP32 && (256 % (C / 8)) == 0) {     // experiment build: 2-byte inputs take the packed-fp32 kernel (svr_elementwise.hip)
+#define SVR_GN_P(K, S) hipLaunchKernelGGL((groupnorm_apply_packed_kernel<K, S>), dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x, \
+                                          (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps)
+        if (x_f32 == SVR_STORE_H16) { if (apply_silu) SVR_GN_P(2, true); else SVR_GN_P(2, false); }
+        else { if (apply_silu) SVR_GN_P(0, true); else SVR_GN_P(0, false); }
+#undef SVR_GN_P
+        return check(hipGetLastError(), "svr_groupnorm_apply");
+    }
+#endif
     if (x_f32 == SVR_STORE_FP32) hipLaunchKernelGGL(groupnorm_apply_kernel<1>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,
                                                     (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
     else if (x_f32 == SVR_STORE_H16) hipLaunchKernelGGL(groupnorm_apply_kernel<2>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,

@@ -410,6 +410,87 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __rest
     }
 }
 
+#ifndef SVR_GN_PACKED
+#define SVR_GN_PACKED 0
+#endif
+#if SVR_GN_PACKED
+// Experiment build only (tools/ubench/build_variant.sh -DSVR_GN_PACKED=1; the product does not contain this kernel): the same pass for
+// the 2-byte inputs with (a) SiLU a template argument instead of a run-time flag -- the flag costs one v_cndmask per element -- and
+// (b) the affine + SiLU arithmetic on float2 vectors: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue two elements per slot and are
+// the same IEEE operations in the same order (x * a + b contracted to one FMA exactly as in groupnorm_apply_kernel; silu(u) =
+// u * rcp(1 + exp2(-log2(e) * u))), so the output is BIT-IDENTICAL.  By static count the hot loop goes from 956 to 764 VALU issue cycles
+// per two chunks (512 of them the 32 quarter-rate transcendentals); the pass runs at 5.0 TB/s with the VALU port ~60 % busy, so the
+// arithmetic is a suspect.  A/B: tools/ubench/gn_ab (product) vs gn_ab_x (this build), equal checksums expected.
+template <bool SILU> SVR_DEVICE void gn_affine_act8(float* f, const float* sa, const float* sb) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_p;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const f32x2_p x = {f[e], f[e + 1]}, a = {sa[e], sa[e + 1]}, b = {sb[e], sb[e + 1]};
+        f32x2_p u = __builtin_elementwise_fma(x, a, b);
+        if constexpr (SILU) {
+            const f32x2_p t = u * f32x2_p{-1.4426950408889634f, -1.4426950408889634f};
+            const f32x2_p d = f32x2_p{1.0f, 1.0f} + f32x2_p{fast_exp2(t[0]), fast_exp2(t[1])};
+            u = u * f32x2_p{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        }
+        f[e] = u[0]; f[e + 1] = u[1];
+    }
+}
+
+template <int XF32, bool SILU>    // XF32: 0 bf16 | 2 h16 input
+__global__ __launch_bounds__(256) void groupnorm_apply_packed_kernel(const void* __restrict__ x, bf16_t* __restrict__ y,
+                                                                     const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, int64_t HW, int C, int groups, float eps) {
+    static_assert(XF32 == 0 || XF32 == 2, "2-byte inputs");
+    __shared__ float a_s[512], b_s[512];
+    const int t = blockIdx.y;
+    const int cpg = C / groups;
+    for (int c = threadIdx.x; c < C; c += 256) {         // (per-channel scale / offset exactly as groupnorm_apply_kernel computes them)
+        const int gidx = c / cpg;
+        const double n = (double)HW * (double)cpg;
+        const double mean = stats[((int64_t)t * groups + gidx) * 2] / n;
+        double var = stats[((int64_t)t * groups + gidx) * 2 + 1] / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float ga = gamma[c] * rstd;
+        a_s[c] = XF32 == 2 ? ga * H16_INV : ga;
+        b_s[c] = beta[c] - (float)mean * ga;
+    }
+    __syncthreads();
+    const int cchunks = C >> 3;
+    const int64_t nchunks = HW * cchunks;
+    const bf16_t* xb = (const bf16_t*)x + (int64_t)t * HW * C;
+    bf16_t* yb = y + (int64_t)t * HW * C;
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    auto raw8 = [&](const uint4& v, float* o) { if constexpr (XF32 == 2) unpack8h_raw(v, o); else unpack8(v, o); };
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    if ((256 % cchunks) == 0) {                          // (the launcher sends only this case here)
+        const int c0 = (threadIdx.x % cchunks) * 8;
+        float sa[8], sb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sa[e] = a_s[c0 + e]; sb[e] = b_s[c0 + e]; }
+        int64_t i = i0;
+        for (; i + stride < nchunks; i += 2 * stride) {
+            float f[8], h[8];
+            const u32x4 v0 = __builtin_nontemporal_load((const u32x4*)(xb + i * 8));
+            const u32x4 v1 = __builtin_nontemporal_load((const u32x4*)(xb + (i + stride) * 8));
+            raw8(make_uint4(v0.x, v0.y, v0.z, v0.w), f);
+            raw8(make_uint4(v1.x, v1.y, v1.z, v1.w), h);
+            gn_affine_act8<SILU>(f, sa, sb);
+            gn_affine_act8<SILU>(h, sa, sb);
+            const uint4 o0 = pack8(f), o1 = pack8(h);
+            __builtin_nontemporal_store(u32x4{o0.x, o0.y, o0.z, o0.w}, (u32x4*)(yb + i * 8));
+            __builtin_nontemporal_store(u32x4{o1.x, o1.y, o1.z, o1.w}, (u32x4*)(yb + (i + stride) * 8));
+        }
+        for (; i < nchunks; i += stride) {
+            float f[8];
+            raw8(*(const uint4*)(xb + i * 8), f);
+            gn_affine_act8<SILU>(f, sa, sb);
+            *(uint4*)(yb + i * 8) = pack8(f);
+        }
+    }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Row softmax of fp32 scores -> bf16 probabilities: P[r, :] = softmax(scale * S[r, :]).  One 256-thread block
 // per row, the row lives in registers (cols <= 16384), one read and one write of the matrix.  Used by the VAE
