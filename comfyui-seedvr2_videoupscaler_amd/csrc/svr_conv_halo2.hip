@@ -44,6 +44,11 @@ namespace svr {
 #ifndef SVR_EP_ADDR
 #define SVR_EP_ADDR 0
 #endif
+// Second experiment switch (-DSVR_GN_TAIL_LDS=1): the first barrier of the fused-GroupNorm-statistics reduction at the end of a tile
+// orders LDS only instead of being a __syncthreads() (whose fence makes every wave wait for all of the tile's output stores).
+#ifndef SVR_GN_TAIL_LDS
+#define SVR_GN_TAIL_LDS 0
+#endif
 constexpr int CG_TX = 32, CG_HX = CG_TX + 2;
 constexpr int CG_BUNIT = 128 * 64;                        // 128 couts x 32 k = 8 KiB
 constexpr int CG_NB = 8;                                  // weight ring
@@ -970,7 +975,14 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
         ep_body(std::integral_constant<int, -1>{});
     }
     if (a.gn_partial) {                                   // fixed-order reduction: thread -> quad -> group
+#if SVR_GN_TAIL_LDS
+        // (experiment builds: __syncthreads() carries a memory fence -- hipcc emits s_waitcnt vmcnt(0) in front of the barrier, so every
+        // tile with fused statistics waits here until ALL its output stores are acknowledged, with the CU's only workgroup slot
+        // occupied.  The reduction below touches LDS and its own 16-byte result only: an LDS-ordering barrier is enough.)
+        lds_barrier();
+#else
         __syncthreads();
+#endif
         float4* red = (float4*)smem;                      // [NT]
         double2* qsum = (double2*)(smem + 8192);          // [32 quads]
         red[tid] = make_float4(gs0, gq0, gs1, gq1);

@@ -37,8 +37,11 @@ constexpr int CS_EP_PITCH = 528;                             // 128 floats + 16 
 constexpr int CS_EP_BYTES = 4 * 32 * CS_EP_PITCH;            // four patch rows per epilogue pass
 constexpr int CS_LDS = CS_NBUF * CS_ABUF;                    // 147 456 B (the epilogue parks in the same space)
 static_assert(CS_PIECES == 9 && CS_EP_BYTES <= CS_LDS, "piece schedule / epilogue parking");
-#ifndef SVR_EP_ADDR                                          // experiment switch, see svr_conv_halo2.hip (0 = the product)
+#ifndef SVR_EP_ADDR                                          // experiment switches, see svr_conv_halo2.hip (0 = the product)
 #define SVR_EP_ADDR 0
+#endif
+#ifndef SVR_GN_TAIL_LDS
+#define SVR_GN_TAIL_LDS 0
 #endif
 
 template <int OFF> SVR_DEVICE void cs_rd2(bf16x8 (&r)[2], unsigned a0) {   // both k-steps of one halo row: chunk c and c ^ 2
@@ -418,7 +421,11 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
         // fixed-order reduction thread -> quad -> group (svr_conv_halo2.hip's); the (sum, sum of squares) of this patch go to
         // gn_partial[output frame][phase (py, px)][block][group]: the four phase launches of an upsampled frame fill one row of
         // 4 x blocks entries, which svr_groupnorm_reduce() adds up (a dense launch: [frame][block][group])
+#if SVR_GN_TAIL_LDS
+        lds_barrier();                                    // (experiment builds, see svr_conv_halo2.hip: no wait for the tile's output stores)
+#else
         __syncthreads();
+#endif
         float4* red = (float4*)smem;                      // [NT]
         double2* qsum = (double2*)(smem + 8192);          // [32 quads]
         red[tid] = make_float4(gs0, gq0, gs1, gq1);
