@@ -49,6 +49,10 @@ namespace svr {
 #ifndef SVR_GN_TAIL_LDS
 #define SVR_GN_TAIL_LDS 0
 #endif
+// Third (-DSVR_ACC_EARLY=1): the zeroed accumulators of conv_halo2_kernel<16, 3> are pinned in front of the prologue's wait for the first halo.
+#ifndef SVR_ACC_EARLY
+#define SVR_ACC_EARLY 0
+#endif
 constexpr int CG_TX = 32, CG_HX = CG_TX + 2;
 constexpr int CG_BUNIT = 128 * 64;                        // 128 couts x 32 k = 8 KiB
 constexpr int CG_NB = 8;                                  // weight ring
@@ -527,6 +531,16 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             wload(w0, 0);
             wload(w1, 1);
             if constexpr (ABL_NO_W) wload(w2, 2);
+#if SVR_ACC_EARLY
+            // (experiment builds: hipcc materialises the 256 zeroed accumulators where the first MFMA needs them -- 249 v_accvgpr_write
+            // BEHIND this wait and barrier, ~1 000 issue cycles per tile with nothing in flight.  Pinning them here puts the writes under
+            // the latency of the first halo and weight loads -- behind the sched_barrier, so that they do not delay the loads' issue.)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int y = 0; y < MTW; ++y)
+#pragma unroll
+                for (int z = 0; z < NTW; ++z) asm volatile("" : "+a"(acc[y][z]));
+#endif
             cg_wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
