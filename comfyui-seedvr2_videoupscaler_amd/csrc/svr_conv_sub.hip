@@ -43,6 +43,9 @@ static_assert(CS_PIECES == 9 && CS_EP_BYTES <= CS_LDS, "piece schedule / epilogu
 #ifndef SVR_GN_TAIL_LDS
 #define SVR_GN_TAIL_LDS 0
 #endif
+#ifndef SVR_ACC_EARLY
+#define SVR_ACC_EARLY 0
+#endif
 
 template <int OFF> SVR_DEVICE void cs_rd2(bf16x8 (&r)[2], unsigned a0) {   // both k-steps of one halo row: chunk c and c ^ 2
     const unsigned a1 = a0 ^ 32u;
@@ -278,6 +281,13 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
     stage_all(frame_ptr(2), 2);
     wload(w0, 0);
     wload(w1, 1);
+#if SVR_ACC_EARLY
+    __builtin_amdgcn_sched_barrier(0);                   // (experiment builds, see svr_conv_halo2.hip: the zeroed accumulators are
+#pragma unroll                                            //  materialised under the latency of the first loads, not behind the wait)
+    for (int y = 0; y < MTW; ++y)
+#pragma unroll
+        for (int z = 0; z < NTW; ++z) asm volatile("" : "+a"(acc[y][z]));
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
