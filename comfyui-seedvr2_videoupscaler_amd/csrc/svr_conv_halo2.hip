@@ -778,7 +778,9 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
         // of the pass's 4 x 32 voxels: parked row r = q >> 1 = patch row k(P, r) = (r >> 1) MTW + 2 P + (r & 1), column x0 + (q & 1) 16 +
         // (tid >> 4).  Element offset of a chunk = [(to H + y0 + min(k, kmax)) W ld]  +  [min(x, W - 1) ld + n]: the first term is
         // wave-uniform (four per pass), the second one of two per-thread constants of the tile.
-        constexpr bool EA = (SVR_EP_ADDR != 0) && W8 && !RT && DBG == 0;
+        // (also the thin-input kernel, whose run time IS its epilogue: 8 x 32 voxels x 128 couts stored per two MFMA steps; its compiled
+        // bodies with a residual -- never launched: conv_in has none -- keep the shipped form, they have no prefetch to take the row terms)
+        constexpr bool EA = (SVR_EP_ADDR != 0) && (W8 || (THIN && !F_RESID)) && NT == 256 && !RT && DBG == 0;
         int64_t colc[2] = {0, 0}, colr[2] = {0, 0};
         bool okx[2] = {false, false};
         const int ea_kmax = g.H - 1 - y0;
