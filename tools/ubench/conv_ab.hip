@@ -9,6 +9,7 @@
 //   sc256  1x1x1 256->128 @1024^2   decoder shortcut (generic kernel, h16 out)        sc128  1x1x1 128->256 @512^2   encoder shortcut
 //   ds128  3x3x3 128->128 @1024^2 stride (1,2,2) pad (0,1)  encoder downsampler       ds256  3x3x3 256->256 @512^2 stride (2,2,2)
 //   sp256  (3,2,2)-tap phases 256->256 @512^2 -> 1024^2: the four spatial phases of the spatial sub-pixel upsampler as ONE quad launch
+//   cin    3x3x3 4->128 @1024^2 (encoder.conv_in: the thin-input kernel, h16 out, fused GroupNorm statistics; its run time is its epilogue)
 //   sp512  (2,2,2)-tap phases 512->512 @256^2 -> 512^2, output frames interleaved (t_stride 2): one temporal phase of the temporal upsampler
 //          (conv_sub_kernel; bf16 out, fused GroupNorm statistics, a halo tensor for the causal head -- as vae.py::_upsample_subpixel)
 // build: tools/ubench/build_ubench.sh   (measurement aid, not part of the product)
@@ -48,7 +49,7 @@ __global__ void checksum(const uint16_t* p, int64_t n, unsigned long long* out) 
     atomicAdd(out, s);
 }
 
-struct Case { const char* name; int T, H, W, Cin, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw; bool conv2; int sub_tstride = 0; };
+struct Case { const char* name; int T, H, W, Cin, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw; bool conv2; int sub_tstride = 0; bool thin = false; };
 static const Case CASES[] = {
     {"c128", 5, 1024, 1024, 128, 128, 3, 3, 3, 1, 1, 1, 2, 1, 1, true},
     {"c256", 5, 512, 512, 256, 256, 3, 3, 3, 1, 1, 1, 2, 1, 1, true},
@@ -61,6 +62,7 @@ static const Case CASES[] = {
     {"ds256", 5, 512, 512, 256, 256, 3, 3, 3, 2, 2, 2, 2, 0, 0, false},
     {"sp256", 5, 512, 512, 256, 256, 3, 2, 2, 1, 1, 1, 2, 1, 1, false, 1},
     {"sp512", 5, 256, 256, 512, 512, 2, 2, 2, 1, 1, 1, 1, 1, 1, false, 2},
+    {"cin", 5, 1024, 1024, 4, 128, 3, 3, 3, 1, 1, 1, 2, 1, 1, false, 0, true},      // encoder.conv_in: RGB padded to 4 channels, K padded to 128
 };
 
 static int apply_options(const std::string& set) {
@@ -97,7 +99,7 @@ int main(int argc, char** argv) {
         if (!c) { fprintf(stderr, "unknown case %s\n", nm.c_str()); return 2; }
         const int To = (c->T + c->pt - c->kt) / c->st + 1;
         const int Ho = c->sh == 1 ? c->H : c->H / 2, Wo = c->sw == 1 ? c->W : c->W / 2;
-        const int K = c->kt * c->kh * c->kw * c->Cin, N = c->Cout, Npad = (N + 127) / 128 * 128;
+        const int K = c->thin ? 128 : c->kt * c->kh * c->kw * c->Cin, N = c->Cout, Npad = (N + 127) / 128 * 128;
         const bool sub = c->sub_tstride > 0;             // quad phase launch: dense [To * t_stride, 2 H, 2 W, N] output
         const int64_t n_in = (int64_t)c->T * c->H * c->W * c->Cin, n_w = (int64_t)Npad * K;
         const int64_t n_out = sub ? (int64_t)To * c->sub_tstride * 4 * Ho * Wo * N : (int64_t)To * Ho * Wo * N;
@@ -124,6 +126,11 @@ int main(int argc, char** argv) {
             if (svr_conv_pack_frag(w, wf, Npad, K, c->kt, c->Cin, nullptr) != 0) { fprintf(stderr, "%s\n", svr_last_error()); return 1; }
             hipLaunchKernelGGL(fill_h16, dim3(4096), dim3(256), 0, 0, resid, n_out, 3u, 2.0f);
             a.W_frag = wf; a.epilogue = SVR_EPI_RESID_GATE; a.resid = resid; a.ldr = N; a.resid_f32 = SVR_STORE_H16; a.gn_groups = 32;
+            const int nblk = svr_gemm_gn_blocks(&a);
+            if (nblk > 0) { partial_bytes = (int64_t)To * nblk * 32 * 16; CK(hipMalloc(&partial, partial_bytes)); a.gn_partial = partial; } else a.gn_groups = 0;
+        }
+        if (c->thin) {
+            a.gn_groups = 32;
             const int nblk = svr_gemm_gn_blocks(&a);
             if (nblk > 0) { partial_bytes = (int64_t)To * nblk * 32 * 16; CK(hipMalloc(&partial, partial_bytes)); a.gn_partial = partial; } else a.gn_groups = 0;
         }
