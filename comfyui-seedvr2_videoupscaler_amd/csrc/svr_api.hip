@@ -41,6 +41,11 @@ int svr_abi_version(void) { return SVR_ABI_VERSION; }
 static const char g_build_id[] = "SVR_BUILD_ID=" SVR_BUILD_ID;
 const char* svr_build_id(void) { return g_build_id + 13; }
 
+// workgroups per frame of svr_groupnorm_apply (svr_set_option("gn_grid_cap"); default 8192 = every launch so far).  A/B knob: each workgroup
+// derives the per-channel scale / offset from the fp64 statistics before it streams (two fp64 divisions and a square root per channel), so
+// fewer, longer workgroups amortise that prologue; the pass is elementwise, the result does not depend on the grid.
+static int g_gn_grid_cap = 8192;
+
 int svr_set_option(const char* key, int32_t value) {
     if (!key) return fail("svr_set_option: null key");
     if (!strcmp(key, "pipe_abl")) { g_pipe_abl = value; return 0; }
@@ -56,6 +61,10 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "conv_thinout16")) { g_conv_thinout16 = value; return 0; }
     if (!strcmp(key, "attn_impl")) { g_attn_impl = value; return 0; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return 0; }
+    if (!strcmp(key, "gn_grid_cap")) {
+        if (value < 64 || value > 65535) return fail("svr_set_option: gn_grid_cap is 64 .. 65535 workgroups per frame");
+        g_gn_grid_cap = value; return 0;
+    }
     return fail("svr_set_option: unknown key");
 }
 
@@ -298,7 +307,7 @@ int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float
     if (!x || !y || !stats) return fail("svr_groupnorm_apply: null pointer");
     const int64_t nchunks = HW * (C / 8);
     unsigned gx = blocks_for(nchunks, 256 * 4);
-    if (gx > 8192) gx = 8192;
+    if (gx > (unsigned)g_gn_grid_cap) gx = (unsigned)g_gn_grid_cap;
     if ((unsigned)x_f32 > (unsigned)SVR_STORE_H16) return fail("svr_groupnorm_apply: x_f32 must be SVR_STORE_BF16 / _FP32 / _H16");
 #if SVR_GN_PACKED
     if (x_f32 != SVR_STORE_FP32 && (256 % (C / 8)) == 0) {     // experiment build: 2-byte inputs take the packed-fp32 kernel (svr_elementwise.hip)

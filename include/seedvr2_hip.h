@@ -261,6 +261,7 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * "attn_variant" build variant of the second-generation window kernel (0 default = 8 waves x 32 queries; 1 / 3 / 4: 4-wave and
  * s_setprio builds; 5 / 6: 4 waves x 64 queries, one wave per SIMD; 7 / 8: the same with K Q^T one tile ahead of the softmax;
  * 9 / 10: the default build with one wave of each SIMD at a higher issue priority -- see svr_attn_win.hip),
+ * "gn_grid_cap" workgroups per frame of svr_groupnorm_apply, 64 .. 65535 (default 8192; the pass is elementwise: same result for any value),
  * "pipe_abl" measurement-only ablations in -DSVR_ABLATIONS builds (non-zero values give garbage). */
 int svr_set_option(const char* key, int32_t value);
 const char* svr_last_error(void);

@@ -1,5 +1,5 @@
 // Standalone A/B of svr_groupnorm_apply (GroupNorm apply + SiLU over an NDHWC tensor: 6.8 % of a BASELINE config 3 step) through the C ABI.
-//   usage: gn_ab [reps] [case ...]     cases (h16 trunk input -> bf16 output, 32 groups, as a VAE tile issues them):
+//   usage: gn_ab [reps] [case ...] [key=value ...]     (key=value: svr_set_option before the runs, e.g. gn_grid_cap=2048)     cases (h16 trunk input -> bf16 output, 32 groups, as a VAE tile issues them):
 //     gn128  5 x 1024^2 x 128 (default)    gn256  5 x 512^2 x 256    gn512  5 x 256^2 x 512    gn128b  the same tensor as bf16 input
 // Each case runs with SiLU and without; prints microseconds, TB/s over the algorithmic bytes (2 B read + 2 B written per element) and a
 // 64-bit checksum of the output -- an experiment library (tools/ubench/build_variant.sh -DSVR_GN_PACKED=1 -> gn_ab_x) must print the same.
@@ -44,11 +44,18 @@ static const Case CASES[] = {{"gn128", 5, 1024, 1024, 128, SVR_STORE_H16}, {"gn2
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 10;
     std::vector<std::string> names;
-    for (int i = 2; i < argc; ++i) names.push_back(argv[i]);
+    std::string opts;
+    for (int i = 2; i < argc; ++i) {
+        const std::string arg = argv[i];
+        const size_t eq = arg.find('=');
+        if (eq == std::string::npos) { names.push_back(arg); continue; }
+        if (svr_set_option(arg.substr(0, eq).c_str(), atoi(arg.c_str() + eq + 1)) != 0) { fprintf(stderr, "%s\n", svr_last_error()); return 1; }
+        opts += (opts.empty() ? "" : ",") + arg;
+    }
     if (names.empty()) names.push_back("gn128");
     char info[256];
     svr_device_info(info, 256);
-    printf("# %s | build %s\n", info, svr_build_id());
+    printf("# %s | build %s | options %s\n", info, svr_build_id(), opts.empty() ? "-" : opts.c_str());
     unsigned long long* d_sum; CK(hipMalloc(&d_sum, 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int groups = 32;

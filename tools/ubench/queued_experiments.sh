@@ -12,6 +12,6 @@ SVR_VARIANT_DIR=variant2 SVR_VARIANT_SUFFIX=_y bash build_variant.sh -DSVR_EP_AD
 cat <<'CMD'
 
 /usr/local/graft/bin/gpurun --timeout 60 -- 'mkdir -p gpurun_out; cd tools/ubench; C=c128,c256,c512,c128r,c256s,sp256,sp512,cin; G="gn128 gn256 gn512 gn128b";
- (for b in conv_ab conv_ab_x conv_ab_y conv_ab; do timeout 8 ./$b 5 $C; done; for b in gn_ab gn_ab_y gn_ab; do timeout 6 ./$b 10 $G; done;
+ (for b in conv_ab conv_ab_x conv_ab_y conv_ab; do timeout 8 ./$b 5 $C; done; for b in gn_ab gn_ab_y gn_ab; do timeout 6 ./$b 10 $G; done; for cap in 4096 2048 1024; do timeout 6 ./gn_ab 10 gn128 gn256 gn_grid_cap=$cap; done;
   timeout 10 ./stream_ab 5 gn128) > ../../gpurun_out/queued_experiments.txt 2>&1; tail -n 80 ../../gpurun_out/queued_experiments.txt'
 CMD
