@@ -19,6 +19,10 @@ GPUs are visible).  cfg3/cfg2/cfg1/cfg5: every rank upscales its own temporal ba
 collective) and the upscaled bf16 frames are all-gathered over RCCL/xGMI inside the step.
 Rank 0 prints ONE JSON line.  `value` = frames all ranks produced / max-over-ranks wall time; `n_gpus` is the
 all-reduced count of ranks that ran.
+--cpu-double (TESTS ONLY, refused unless SVR_BENCH_ALLOW_CPU_DOUBLE=1; tests/test_bench_launcher.py): the same script end to end --
+self-launch under torch.distributed.run, rendezvous, the step, gather, guards, predicted_s, the JSON line -- on CPU ranks over gloo
+with the torch double of the C ABI (tests/ops_reference.py) and reduced-width models, so that launcher plumbing cannot be what
+fails the first multi-GPU run.  Its line carries "test_mode": true and its numbers mean nothing.
 """
 import argparse
 import importlib
@@ -56,6 +60,44 @@ PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16 peak, MI355X_MICROARCH.md
 
 def sub(name):
     return importlib.import_module(f"{PKG}.{name}")
+
+
+class _HostTick:
+    """torch.cuda.Event's two methods on the host clock (--cpu-double only)."""
+    def __init__(self, enable_timing=True):
+        self.t = None
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def make_double_ops():
+    """--cpu-double (tests only): the fp32 torch restatement of every C-ABI op (tests/ops_reference.py) with the recording
+    interface of ProfiledOps, so that the rest of this script runs unchanged on CPU ranks."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ops_reference import TorchOps
+
+    class DoubleOps(TorchOps):
+        def __init__(self):
+            super().__init__("cpu")
+            self.recording, self.events = False, []
+
+        def gemm(self, A, W, out, **kw):
+            t0 = time.perf_counter()
+            r = super().gemm(A, W, out, **kw)
+            if self.recording:
+                self.events.append(("gemm", 2.0 * out.numel() * kw["K"], time.perf_counter() - t0))
+            return r
+
+        def summary(self):
+            n, f, sec = len(self.events), sum(e[1] for e in self.events), sum(e[2] for e in self.events)
+            return {"gemm": {"launches": n, "flops": f, "seconds": sec, "avg_us": sec / max(n, 1) * 1e6,
+                             "tflops": f / max(sec, 1e-12) / 1e12}}
+
+    return DoubleOps()
 
 
 def make_profiled_ops(device):
@@ -169,7 +211,7 @@ def cpu_baseline(flops_per_frame: float) -> dict:
 
 def respawn_under_torchrun(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: run N ranks of this script on this node (one per GPU, RCCL)."""
-    if not torch.cuda.is_available() or torch.cuda.device_count() < n:
+    if "--cpu-double" not in sys.argv and (not torch.cuda.is_available() or torch.cuda.device_count() < n):
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         print(f"[bench] --gpus {n} requested but only {have} GPU(s) are visible: refusing to report a {n}-GPU number",
               file=sys.stderr)
@@ -205,10 +247,18 @@ def main():
                     help="A/B: storage of the VAE's residual trunk (VideoVAEEngine(trunk_store=...)); default: the engine's (h16; round 3: fp32)")
     ap.add_argument("--tile-streams", type=int, default=None,
                     help="A/B: HIP streams the VAE's spatial tiles are issued on (VideoVAEEngine(tile_streams=...); default: the "
-                         "engine's, 2; 1 = every launch on one stream)")
+                         "engine's, 1 = every launch on one stream)")
     ap.add_argument("--branch", choices=["h16", "fp32", "bf16"], default=None,
                     help="A/B: storage of conv1's output inside a VAE block (VideoVAEEngine(branch_store=...)); default: the engine's (h16; round 3: bf16)")
+    ap.add_argument("--cpu-double", action="store_true",
+                    help="TESTS ONLY (needs SVR_BENCH_ALLOW_CPU_DOUBLE=1): CPU ranks over gloo with the torch double of the C ABI and "
+                         "reduced-width models -- exercises this script's launcher / gather / guard / JSON plumbing, measures nothing")
     args = ap.parse_args()
+    double = args.cpu_double
+    if double and os.environ.get("SVR_BENCH_ALLOW_CPU_DOUBLE") != "1":
+        print("[bench] --cpu-double is a test mode (tests/test_bench_launcher.py); the product path needs the HIP library and a GPU",
+              file=sys.stderr)
+        sys.exit(2)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(respawn_under_torchrun(args.gpus))
@@ -217,17 +267,27 @@ def main():
               file=sys.stderr)
         sys.exit(2)
     dist_mod = sub("dist")
-    rank, world, local = dist_mod.init_from_env()
-    if local >= torch.cuda.device_count():
+    rank, world, local = dist_mod.init_from_env(backend="gloo" if double else None)
+    if not double and local >= torch.cuda.device_count():
         print(f"[bench] rank {rank}: LOCAL_RANK {local} has no GPU ({torch.cuda.device_count()} visible)", file=sys.stderr)
         sys.exit(2)
-    device = torch.device(f"cuda:{local}")
-    torch.cuda.set_device(device)
+    device = torch.device("cpu" if double else f"cuda:{local}")
+    if not double:
+        torch.cuda.set_device(device)
+    Tick = _HostTick if double else torch.cuda.Event
+    sync = (lambda: None) if double else torch.cuda.synchronize
 
     config, weights, flops = sub("config"), sub("weights"), sub("flops")
     frames, H, W, tiled, desc = WORKLOADS[args.workload]
-    ops = make_profiled_ops(device)
+    ops = make_double_ops() if double else make_profiled_ops(device)
     dcfg, vcfg = (config.DIT_7B if args.workload == "cfg5" else config.DIT_3B), config.VAE_V3
+    if double:                                            # reduced width, same graphs: the plumbing is what runs here
+        dcfg, vcfg = config.DIT_TINY, config.VAE_TINY
+        if args.workload == "cfg4":
+            frames = 10
+            CFG4.update(in_hw=(24, 40), resolution=48, batch_size=5, temporal_overlap=1)
+        else:
+            frames, H, W = min(frames, 5), min(H, 32), min(W, 48)
     # random-init weights of the exact architecture, generated on the GPU (no checkpoints available offline)
     dit = sub("dit").NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, device=device), ops, hid_fp32=not args.bf16_trunk)
     vae = sub("vae").VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, device=device), ops,
@@ -235,9 +295,10 @@ def main():
                                     trunk_store="bf16" if args.bf16_trunk else args.trunk, branch_store=args.branch,
                                     **({} if args.tile_streams is None else {"tile_streams": args.tile_streams}))
     runner_mod = sub("runner")
+    tile, tile_ov = ((32, 32), (8, 8)) if double else ((1024, 1024), (128, 128))
     runner = runner_mod.VideoDiffusionInfer(
-        runner_mod.default_config(), encode_tiled=tiled, encode_tile_size=(1024, 1024), encode_tile_overlap=(128, 128),
-        decode_tiled=tiled, decode_tile_size=(1024, 1024), decode_tile_overlap=(128, 128))
+        runner_mod.default_config(dcfg, vcfg), encode_tiled=tiled, encode_tile_size=tile, encode_tile_overlap=tile_ov,
+        decode_tiled=tiled, decode_tile_size=tile, decode_tile_overlap=tile_ov)
     runner.dit, runner.vae = dit, vae
     runner.configure_diffusion(device=device, dtype=torch.bfloat16)
 
@@ -261,7 +322,7 @@ def main():
         noise = torch.randn(Tl, hl, wl, 16, generator=g, device=device).to(torch.bfloat16)
 
         def step(timed: bool):
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timed else None
+            ev = [Tick(enable_timing=True) for _ in range(5)] if timed else None
             if timed: ev[0].record()
             lat = runner.vae_encode([x])[0]
             if timed: ev[1].record()
@@ -294,7 +355,7 @@ def main():
         if first_print is None:
             first_print = fingerprint(out)
         del out
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         torch.distributed.barrier()
     ops.recording = True
@@ -303,7 +364,7 @@ def main():
     for _ in range(args.steps):
         last_out, ev = step(True)
         evs.append(ev)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
@@ -323,7 +384,9 @@ def main():
         ref_mean, ref_std = float(gold["dec_mean"]), float(gold["dec_std"])
     except (OSError, KeyError):
         ref_mean, ref_std = 0.0, 0.58
-    if sharded:
+    if double:
+        band_ok = True                                       # (reduced-width stand-in models: the band of the real decoder does not apply)
+    elif sharded:
         band_ok = 0.05 <= g_std <= 0.6 and 0.2 <= g_mean <= 0.8          # [0, 1] frames after clamp and colour fix
     else:
         band_ok = 0.5 * ref_std <= g_std <= 2.0 * ref_std and abs(g_mean - ref_mean) <= ref_std
@@ -433,26 +496,39 @@ def main():
             "vae_tile_streams": getattr(vae, "tile_streams", 1),
             "output_guard": guard,
         }
-        # DESIGN.md section 6's falsifiable prediction for THIS launch (from the 1-GPU phase times of rounds 3-4): compute is
-        # perfectly parallel over ranks, communication = direct xGMI transfers at ~64 GB/s per direction and link
+        # DESIGN.md section 6's falsifiable prediction for THIS launch: compute is perfectly parallel over ranks, communication =
+        # direct xGMI transfers at ~64 GB/s per direction and link.  The compute term is THIS run's own measurement wherever the run
+        # has one (weak scaling: rank 0's encode + DiT + decode events), so what the line predicts is the communication.
         if world > 1 or sharded:
             frame_bytes = H * W * 3 * (4 if sharded else 2)      # (the pipeline's frames are fp32, the runner's decode output bf16)
             if sharded:
-                per_batch_s, n_b = 41.2 / 8, len(plans)
+                n_b, per_batch_s, src = len(plans), 41.2 / 8, "41.2 s / 8 on one GPU, profiles/r4_bench_cfg4_1gpu.json"
+                for name in ("r5_bench_cfg4_1gpu.json", "r4_bench_cfg4_1gpu.json"):      # the newest committed 1-GPU line of this workload
+                    try:
+                        one = json.load(open(os.path.join(ROOT, "profiles", name)))
+                        per_batch_s, src = float(one["ms_per_step"]) / 1e3 / 8, f"{one['ms_per_step'] / 1e3:.1f} s / 8 on one GPU, profiles/{name}"
+                        break
+                    except (OSError, KeyError, ValueError):
+                        continue
                 comm = (frames * frame_bytes / max(world, 1)) / 64e9 + 0.001 * (n_b - 1)
                 res["predicted_s"] = {"per_step": math.ceil(n_b / world) * per_batch_s + (comm if world > 1 else 0.0),
-                                      "model": f"ceil({n_b} batches / {world} ranks) x 5.15 s per 17-frame batch (41.2 s / 8 on one GPU, "
-                                               "profiles/r4_bench_cfg4_1gpu.json) + gather of the clip over xGMI"}
+                                      "model": f"ceil({n_b} batches / {world} ranks) x {per_batch_s:.2f} s per batch ({src}) "
+                                               "+ gather of the clip over xGMI"}
             else:
-                res["predicted_s"] = {"per_step": 9.45 + (world - 1) * useful * frame_bytes / 64e9 / max(world - 1, 1) + 0.003,
-                                      "model": "the 1-GPU step (9.36-9.60 s on four boxes, round 4) + all-gather: each link carries one rank's frames once"}
+                compute_s = (phase["encode"] + phase["dit"] + phase["decode"]) / 1e3
+                res["predicted_s"] = {"per_step": compute_s + useful * frame_bytes / 64e9 + 0.003,
+                                      "model": "this run's own encode + DiT + decode (rank 0, HIP events) + all-gather: each link carries "
+                                               "one rank's frames once at 64 GB/s"}
         if not sharded:
             dit_tf = f_dit["total"] / max(phase["dit"], 1e-9) / 1e9
             res.update({"dit_ms_per_step": phase["dit"], "vae_encode_ms": phase["encode"], "vae_decode_ms": phase["decode"],
                         "allgather_ms": phase["gather"], "dit_tflops": dit_tf,
                         # whole-DiT-step MFMA fraction: algorithmic FLOPs of the forward / its measured time / dense bf16 peak
                         "dit_mfma_frac": dit_tf / PEAK_BF16_TFLOPS})
-        if not args.no_cpu_baseline and world == 1:      # (the CPU leg is a 1-GPU line item: the other ranks would idle at the barrier)
+        if double:
+            res.update(test_mode=True, data="synthetic; TEST MODE (--cpu-double): torch double of the C ABI on CPU ranks over gloo, "
+                                            "reduced-width models -- plumbing only, the numbers mean nothing")
+        if not args.no_cpu_baseline and world == 1 and not double:      # (the CPU leg is a 1-GPU line item: the other ranks would idle at the barrier)
             res["cpu_baseline"] = cpu_baseline(f_step / frames_per_step * (world if not sharded else 1))
         print(json.dumps(res))
     if world > 1:

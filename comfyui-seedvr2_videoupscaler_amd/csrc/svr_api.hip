@@ -41,17 +41,12 @@ int svr_abi_version(void) { return SVR_ABI_VERSION; }
 static const char g_build_id[] = "SVR_BUILD_ID=" SVR_BUILD_ID;
 const char* svr_build_id(void) { return g_build_id + 13; }
 
-// workgroups per frame of svr_groupnorm_apply (svr_set_option("gn_grid_cap"); default 8192 = every launch so far).  A/B knob: each workgroup
-// derives the per-channel scale / offset from the fp64 statistics before it streams (two fp64 divisions and a square root per channel), so
-// fewer, longer workgroups amortise that prologue; the pass is elementwise, the result does not depend on the grid.
-static int g_gn_grid_cap = 8192;
 
 int svr_set_option(const char* key, int32_t value) {
     if (!key) return fail("svr_set_option: null key");
     if (!strcmp(key, "pipe_abl")) { g_pipe_abl = value; return 0; }
     if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
     if (!strcmp(key, "gemm_epi")) { g_gemm_epi = value; return 0; }
-    if (!strcmp(key, "gemm_asym")) { if ((unsigned)value > 2u) return fail("svr_set_option: gemm_asym is 0, 1 or 2"); g_gemm_asym = value; return 0; }
     if (!strcmp(key, "gemm_w4")) { g_gemm_w4 = value; return 0; }
     if (!strcmp(key, "gemm_w4r")) { g_gemm_w4r = value; return 0; }
     if (!strcmp(key, "conv_rows")) { g_conv_rows = value; return 0; }
@@ -61,10 +56,6 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "conv_thinout16")) { g_conv_thinout16 = value; return 0; }
     if (!strcmp(key, "attn_impl")) { g_attn_impl = value; return 0; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return 0; }
-    if (!strcmp(key, "gn_grid_cap")) {
-        if (value < 64 || value > 65535) return fail("svr_set_option: gn_grid_cap is 64 .. 65535 workgroups per frame");
-        g_gn_grid_cap = value; return 0;
-    }
     return fail("svr_set_option: unknown key");
 }
 
@@ -165,7 +156,7 @@ int svr_qknorm_rope(void* qkv, int64_t rows, int32_t heads, const int16_t* pos, 
     if (rows <= 0) return 0;
     if (n_freq <= 0 || n_freq * 3 > 64) return fail("svr_qknorm_rope: 1..21 frequencies per axis (head_dim 128)");
     if (heads <= 0 || n_pos <= 0) return fail("svr_qknorm_rope: heads and n_pos must be positive");
-    if (!qkv || !pos || !cos_tab || !sin_tab) return fail("svr_qknorm_rope: null pointer");
+    if (!qkv || !pos || !cos_tab || !sin_tab || !wq || !wk) return fail("svr_qknorm_rope: null pointer (wq / wk are required)");
     // 8 rows (q and k of each: 16 groups of 16 lanes) per block and step; 16 blocks per CU, the rest in the grid-stride loop
     const int64_t nblk = (rows + 7) / 8;
     const unsigned grid = (unsigned)std::min<int64_t>(nblk, (int64_t)device_cu_count() * 16);
@@ -304,27 +295,19 @@ int svr_groupnorm_apply(const void* x, void* y, const double* stats, const float
     if (T <= 0 || HW <= 0) return 0;
     if (C <= 0 || C % 8 || C > 512) return fail("svr_groupnorm_apply: C must be a multiple of 8 and <= 512");
     if (groups <= 0 || C % groups || T > 65535) return fail("svr_groupnorm_apply: need 1 <= groups dividing C, T <= 65535");
-    if (!x || !y || !stats) return fail("svr_groupnorm_apply: null pointer");
+    if (!x || !y || !stats || !gamma || !beta) return fail("svr_groupnorm_apply: null pointer");
     const int64_t nchunks = HW * (C / 8);
+    // workgroups per frame, each streaming one contiguous span of >= 4 x 4 KiB (measured: spans of 16 KiB 6.4 TB/s, 32 KiB 6.25,
+    // 64 KiB 5.65, 128 KiB 5.2 on 5 x 1024^2 x 128: profiles/r5_gn_apply_ab.txt)
     unsigned gx = blocks_for(nchunks, 256 * 4);
-    if (gx > (unsigned)g_gn_grid_cap) gx = (unsigned)g_gn_grid_cap;
+    if (gx > 65535u) gx = 65535u;
     if ((unsigned)x_f32 > (unsigned)SVR_STORE_H16) return fail("svr_groupnorm_apply: x_f32 must be SVR_STORE_BF16 / _FP32 / _H16");
-#if SVR_GN_PACKED
-    if (x_f32 != SVR_STORE_FP32 && (256 % (C / 8)) == 0) {     // experiment build: 2-byte inputs take the packed-fp32 kernel (svr_elementwise.hip)
-#define SVR_GN_P(K, S) hipLaunchKernelGGL((groupnorm_apply_packed_kernel<K, S>), dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x, \
-                                          (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps)
-        if (x_f32 == SVR_STORE_H16) { if (apply_silu) SVR_GN_P(2, true); else SVR_GN_P(2, false); }
-        else { if (apply_silu) SVR_GN_P(0, true); else SVR_GN_P(0, false); }
-#undef SVR_GN_P
-        return check(hipGetLastError(), "svr_groupnorm_apply");
-    }
-#endif
-    if (x_f32 == SVR_STORE_FP32) hipLaunchKernelGGL(groupnorm_apply_kernel<1>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,
-                                                    (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
-    else if (x_f32 == SVR_STORE_H16) hipLaunchKernelGGL(groupnorm_apply_kernel<2>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,
-                                                        (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
-    else hipLaunchKernelGGL(groupnorm_apply_kernel<0>, dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x,
-                            (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps, apply_silu);
+#define SVR_GN(K, S) hipLaunchKernelGGL((groupnorm_apply_kernel<K, S>), dim3(gx, T), dim3(256), 0, (hipStream_t)stream, x, \
+                                        (bf16_t*)y, stats, gamma, beta, HW, C, groups, eps)
+    if (x_f32 == SVR_STORE_FP32) { if (apply_silu) SVR_GN(1, true); else SVR_GN(1, false); }
+    else if (x_f32 == SVR_STORE_H16) { if (apply_silu) SVR_GN(2, true); else SVR_GN(2, false); }
+    else { if (apply_silu) SVR_GN(0, true); else SVR_GN(0, false); }
+#undef SVR_GN
     return check(hipGetLastError(), "svr_groupnorm_apply");
 }
 

@@ -34,25 +34,6 @@
 
 namespace svr {
 
-// Experiment switch (tools/ubench/build_variant.sh -DSVR_EP_ADDR=1; 0 = the product): the store sweeps of conv_halo2_kernel<16, 3>'s
-// compiled epilogue bodies take their global addresses from per-tile column terms (two per thread) plus per-pass row terms (four,
-// wave-uniform: scalar registers) instead of recomputing ((to H + min(y, H-1)) W + min(x, W-1)) ldc + n per 16-byte store.  Why: by
-// static count the epilogue issues ~390 VALU cycles per stored chunk, 235 of them integer address arithmetic (v_mul_lo_u32 /
-// v_mad_u64_u32 are quarter rate), and the epilogue's duration (13 % of a 128-channel tile) is its VALU issue time -- which is why
-// neither dropping its LDS round trip nor its barriers moved it (profiles/r4_conv_epilogue_*_ab.txt).  Same addresses, same values:
-// bit-identical.
-#ifndef SVR_EP_ADDR
-#define SVR_EP_ADDR 0
-#endif
-// Second experiment switch (-DSVR_GN_TAIL_LDS=1): the first barrier of the fused-GroupNorm-statistics reduction at the end of a tile
-// orders LDS only instead of being a __syncthreads() (whose fence makes every wave wait for all of the tile's output stores).
-#ifndef SVR_GN_TAIL_LDS
-#define SVR_GN_TAIL_LDS 0
-#endif
-// Third (-DSVR_ACC_EARLY=1): the zeroed accumulators of conv_halo2_kernel<16, 3> are pinned in front of the prologue's wait for the first halo.
-#ifndef SVR_ACC_EARLY
-#define SVR_ACC_EARLY 0
-#endif
 constexpr int CG_TX = 32, CG_HX = CG_TX + 2;
 constexpr int CG_BUNIT = 128 * 64;                        // 128 couts x 32 k = 8 KiB
 constexpr int CG_NB = 8;                                  // weight ring
@@ -531,16 +512,15 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             wload(w0, 0);
             wload(w1, 1);
             if constexpr (ABL_NO_W) wload(w2, 2);
-#if SVR_ACC_EARLY
-            // (experiment builds: hipcc materialises the 256 zeroed accumulators where the first MFMA needs them -- 249 v_accvgpr_write
-            // BEHIND this wait and barrier, ~1 000 issue cycles per tile with nothing in flight.  Pinning them here puts the writes under
-            // the latency of the first halo and weight loads -- behind the sched_barrier, so that they do not delay the loads' issue.)
+            // hipcc materialises the 256 zeroed accumulators where the first MFMA needs them -- 249 v_accvgpr_write BEHIND this wait
+            // and barrier, ~1 000 issue cycles per tile with nothing in flight.  Pinning them here puts the writes under the latency
+            // of the first halo and weight loads (behind the sched_barrier, so that they do not delay the loads' issue): bit-identical,
+            // -0.9 / -1.2 % on the 128-channel forms, -0.2 % at 256, 0 at 512 channels (profiles/r5_conv_queue_ab.txt).
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int y = 0; y < MTW; ++y)
 #pragma unroll
                 for (int z = 0; z < NTW; ++z) asm volatile("" : "+a"(acc[y][z]));
-#endif
             cg_wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -774,44 +754,9 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
         // profiles/r4_conv_epilogue_resid_prefetch_ab.txt).  64 more registers in the epilogue (456 of 512): the kernels that run two
         // workgroups per CU keep the loads inside their sweeps.
         constexpr bool PRE = W8 && !RT && F_RESID;
-        // (experiment builds, see SVR_EP_ADDR at the top of the file) store slot q = half * 4 + it of a pass is voxel q * 16 + (tid >> 4)
-        // of the pass's 4 x 32 voxels: parked row r = q >> 1 = patch row k(P, r) = (r >> 1) MTW + 2 P + (r & 1), column x0 + (q & 1) 16 +
-        // (tid >> 4).  Element offset of a chunk = [(to H + y0 + min(k, kmax)) W ld]  +  [min(x, W - 1) ld + n]: the first term is
-        // wave-uniform (four per pass), the second one of two per-thread constants of the tile.
-        // (also the thin-input kernel, whose run time IS its epilogue: 8 x 32 voxels x 128 couts stored per two MFMA steps; its compiled
-        // bodies with a residual -- never launched: conv_in has none -- keep the shipped form, they have no prefetch to take the row terms)
-        constexpr bool EA = (SVR_EP_ADDR != 0) && (W8 || (THIN && !F_RESID)) && NT == 256 && !RT && DBG == 0;
-        int64_t colc[2] = {0, 0}, colr[2] = {0, 0};
-        bool okx[2] = {false, false};
-        const int ea_kmax = g.H - 1 - y0;
-        const int64_t ea_row0 = (int64_t)to * g.H + y0, ea_wldc = (int64_t)g.W * a.ldc, ea_wldr = (int64_t)g.W * a.ldr;
-        if constexpr (EA) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int xq = x0 + j * 16 + (tid >> 4);
-                okx[j] = xq < g.W;
-                const int64_t xc = min(xq, g.W - 1);
-                colc[j] = xc * a.ldc + n0 + (tid & 15) * 8;
-                colr[j] = xc * a.ldr + n0 + (tid & 15) * 8;
-            }
-        }
-        auto ea_rows = [&](int P, int64_t ld_w, int64_t (&row)[4]) {       // the four wave-uniform row terms of pass P for a row pitch
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = (r >> 1) * MTW + 2 * P + (r & 1);
-                row[r] = (ea_row0 + min(k, ea_kmax)) * ld_w;
-            }
-        };
         uint4 rpre[2][8];
         auto resid_prefetch = [&](auto pc, uint4 (&dst)[8]) {
             constexpr int P = decltype(pc)::value;
-            if constexpr (EA) {
-                int64_t rowr[4];
-                ea_rows(P, ea_wldr, rowr);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) dst[q] = *(const uint4*)((const bf16_t*)a.resid + (rowr[q >> 1] + colr[q & 1]));
-                return;
-            }
             const int n_ = n0 + (tid & 15) * 8;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -853,33 +798,21 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
             // store side, branch-free sweeps of four iterations so their LDS reads and residual loads are in flight
             // together (out-of-image voxels read a clamped address and are masked at the store)
             const int n = n0 + (tid & 15) * 8;
-            int64_t ea_rowc[4] = {0, 0, 0, 0};
-            if constexpr (EA) ea_rows(pass, ea_wldc, ea_rowc);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
             f32x4 lo[4], hi_[4];
             uint4 rr8[4];
             f32x4 rf0[4], rf1[4];
             int64_t mrow[4];
-            int64_t offc[4];                                            // (EA) element offset of the chunk in C
             bool ok[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int vox = ((half * 4 + it) * NT + tid) >> 4;      // voxel slot of this pass
                 const int r = vox >> 5;
-                if constexpr (EA) {
-                    const int q = half * 4 + it, rq = q >> 1;           // (r == q >> 1 for every lane; column slot q & 1)
-                    const int k = (rq >> 1) * MTW + 2 * pass + (rq & 1);    // patch row: wave-uniform
-                    ok[it] = k <= ea_kmax && okx[q & 1];
-                    offc[it] = ea_rowc[q >> 1] + colc[q & 1];
-                    mrow[it] = 0;
-                } else {
                 const int y = y0 + (r >> 1) * MTW + 2 * pass + (r & 1), x = x0 + (vox & 31);
                 ok[it] = y < g.H && x < g.W;
                 if constexpr ((DBG & 4) != 0) ok[it] = false;
                 mrow[it] = ((int64_t)to * g.H + min(y, g.H - 1)) * g.W + min(x, g.W - 1);
-                offc[it] = 0;
-                }
                 lo[it] = *(const f32x4*)(smem + vox * EP_PITCH + (tid & 15) * 32);
                 hi_[it] = *(const f32x4*)(smem + vox * EP_PITCH + (tid & 15) * 32 + 16);
             }
@@ -952,8 +885,6 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
                     }
                 } else {
                     const uint4 pk = ko == SVR_STORE_H16 ? pack8h(f) : pack8(f);
-                    if constexpr (EA) { if (ok[it]) *(uint4*)((bf16_t*)a.C + offc[it]) = pk; }
-                    else
                     if (ok[it]) *(uint4*)((bf16_t*)a.C + mrow[it] * a.ldc + n) = pk;
                     if (with_gn && ok[it]) {
                         float r[8];
@@ -991,14 +922,7 @@ __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void 
         ep_body(std::integral_constant<int, -1>{});
     }
     if (a.gn_partial) {                                   // fixed-order reduction: thread -> quad -> group
-#if SVR_GN_TAIL_LDS
-        // (experiment builds: __syncthreads() carries a memory fence -- hipcc emits s_waitcnt vmcnt(0) in front of the barrier, so every
-        // tile with fused statistics waits here until ALL its output stores are acknowledged, with the CU's only workgroup slot
-        // occupied.  The reduction below touches LDS and its own 16-byte result only: an LDS-ordering barrier is enough.)
-        lds_barrier();
-#else
         __syncthreads();
-#endif
         float4* red = (float4*)smem;                      // [NT]
         double2* qsum = (double2*)(smem + 8192);          // [32 quads]
         red[tid] = make_float4(gs0, gq0, gs1, gq1);

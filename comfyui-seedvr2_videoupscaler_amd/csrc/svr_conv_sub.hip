@@ -37,15 +37,6 @@ constexpr int CS_EP_PITCH = 528;                             // 128 floats + 16 
 constexpr int CS_EP_BYTES = 4 * 32 * CS_EP_PITCH;            // four patch rows per epilogue pass
 constexpr int CS_LDS = CS_NBUF * CS_ABUF;                    // 147 456 B (the epilogue parks in the same space)
 static_assert(CS_PIECES == 9 && CS_EP_BYTES <= CS_LDS, "piece schedule / epilogue parking");
-#ifndef SVR_EP_ADDR                                          // experiment switches, see svr_conv_halo2.hip (0 = the product)
-#define SVR_EP_ADDR 0
-#endif
-#ifndef SVR_GN_TAIL_LDS
-#define SVR_GN_TAIL_LDS 0
-#endif
-#ifndef SVR_ACC_EARLY
-#define SVR_ACC_EARLY 0
-#endif
 
 template <int OFF> SVR_DEVICE void cs_rd2(bf16x8 (&r)[2], unsigned a0) {   // both k-steps of one halo row: chunk c and c ^ 2
     const unsigned a1 = a0 ^ 32u;
@@ -281,13 +272,11 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
     stage_all(frame_ptr(2), 2);
     wload(w0, 0);
     wload(w1, 1);
-#if SVR_ACC_EARLY
-    __builtin_amdgcn_sched_barrier(0);                   // (experiment builds, see svr_conv_halo2.hip: the zeroed accumulators are
-#pragma unroll                                            //  materialised under the latency of the first loads, not behind the wait)
+    __builtin_amdgcn_sched_barrier(0);                   // (see svr_conv_halo2.hip: the zeroed accumulators are materialised
+#pragma unroll                                            //  under the latency of the first loads, not behind the wait)
     for (int y = 0; y < MTW; ++y)
 #pragma unroll
         for (int z = 0; z < NTW; ++z) asm volatile("" : "+a"(acc[y][z]));
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -325,23 +314,6 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
     const float* btab = a.phase.enabled ? bias_border_p : nullptr;
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;      // fused GroupNorm statistics of the stored values (columns n .. n + 3, n + 4 .. n + 7)
     // (the body is instantiated per output kind -- bf16 | fp32 | h16, the wide residual trunk -- so its loops carry no option branches)
-#if SVR_EP_ADDR
-    // (experiment builds: the phase-scattered store offset ((F up H + up yc + py) (up W) + up xc + px) N + n split into a wave-uniform
-    // row term per parked row and one of two per-thread column terms of the tile, as in svr_conv_halo2.hip; the border code likewise)
-    int64_t ea_col[2];
-    int ea_bx[2];
-    bool ea_okx[2];
-    const int ea_kmax = g.H - 1 - y0;
-    const int64_t ea_rowbase = (int64_t)to * ts * (up * g.H) + up * y0 + py, ea_rowpitch = (int64_t)(up * g.W) * a.N;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int xq = x0 + j * 16 + (tid >> 4);
-        ea_okx[j] = xq < g.W;
-        const int xc = min(xq, g.W - 1);
-        ea_bx[j] = xc == xb ? 2 : 0;
-        ea_col[j] = (int64_t)(up * xc + px) * a.N + n;
-    }
-#endif
     auto ep_body = [&](auto o32c) {
     constexpr int OKIND = decltype(o32c)::value;
     constexpr bool O32 = OKIND == SVR_STORE_FP32;
@@ -371,21 +343,12 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int vox = ((half * 4 + it) * NT + tid) >> 4;          // voxel slot of this pass
-#if SVR_EP_ADDR
-                const int q = half * 4 + it, rq = q >> 1;                   // (vox >> 5 == q >> 1 for every lane; column slot q & 1)
-                const int k = (rq >> 1) * MTW + 2 * pass + (rq & 1);        // patch row: wave-uniform
-                const int kk = min(k, ea_kmax);
-                ok[it] = k <= ea_kmax && ea_okx[q & 1];
-                border[it] = (y0 + kk == yb ? 1 : 0) | ea_bx[q & 1];
-                off[it] = (ea_rowbase + up * kk) * ea_rowpitch + ea_col[q & 1];
-#else
                 const int r = vox >> 5;
                 const int y = y0 + (r >> 1) * MTW + 2 * pass + (r & 1), x = x0 + (vox & 31);
                 ok[it] = y < g.H && x < g.W;
                 const int yc = min(y, g.H - 1), xc = min(x, g.W - 1);
                 border[it] = (yc == yb ? 1 : 0) | (xc == xb ? 2 : 0);
                 off[it] = (((int64_t)to * ts * (up * g.H) + up * yc + py) * (up * g.W) + up * xc + px) * a.N + n;
-#endif
                 lo[it] = *(const f32x4*)(smem + vox * CS_EP_PITCH + (tid & 15) * 32);
                 hi_[it] = *(const f32x4*)(smem + vox * CS_EP_PITCH + (tid & 15) * 32 + 16);
             }
@@ -431,11 +394,7 @@ __global__ __launch_bounds__(CS_NT, 1) void conv_sub_kernel(const svr_gemm_args 
         // fixed-order reduction thread -> quad -> group (svr_conv_halo2.hip's); the (sum, sum of squares) of this patch go to
         // gn_partial[output frame][phase (py, px)][block][group]: the four phase launches of an upsampled frame fill one row of
         // 4 x blocks entries, which svr_groupnorm_reduce() adds up (a dense launch: [frame][block][group])
-#if SVR_GN_TAIL_LDS
-        lds_barrier();                                    // (experiment builds, see svr_conv_halo2.hip: no wait for the tile's output stores)
-#else
         __syncthreads();
-#endif
         float4* red = (float4*)smem;                      // [NT]
         double2* qsum = (double2*)(smem + 8192);          // [32 quads]
         red[tid] = make_float4(gs0, gq0, gs1, gq1);

@@ -322,105 +322,16 @@ __global__ __launch_bounds__(256) void groupnorm_reduce_kernel(const double2* __
     }
 }
 
-template <int XF32>    // storage kind of x (SVR_STORE_*: 0 bf16, 1 fp32, 2 h16)
-__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __restrict__ x, bf16_t* __restrict__ y,
-                                                              const double* __restrict__ stats,
-                                                              const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, int64_t HW, int C,
-                                                              int groups, float eps, int apply_silu) {
-    __shared__ float a_s[512], b_s[512];            // per-channel scale / offset (C <= 512)
-    const int t = blockIdx.y;
-    const int cpg = C / groups;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const int gidx = c / cpg;
-        const double n = (double)HW * (double)cpg;
-        const double mean = stats[((int64_t)t * groups + gidx) * 2] / n;
-        double var = stats[((int64_t)t * groups + gidx) * 2 + 1] / n - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float ga = gamma[c] * rstd;
-        a_s[c] = XF32 == 2 ? ga * H16_INV : ga;         // (h16 input: the stored value is x * 2^-6 -- the factor absorbs the 2^6)
-        b_s[c] = beta[c] - (float)mean * ga;
-    }
-    __syncthreads();
-    const int cchunks = C >> 3;
-    const int64_t nchunks = HW * cchunks;
-    const int64_t xo = (int64_t)t * HW * C;              // element offset of this frame
-    const bf16_t* xb = (const bf16_t*)x + xo;            // (bf16 input)
-    const float* xf = (const float*)x + xo;              // (XF32 input)
-    bf16_t* yb = y + (int64_t)t * HW * C;
-    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
-    auto act = [&](float u) { return apply_silu ? silu(u) : u; };
-    auto raw8 = [&](const uint4& v, float* o) {         // 16 bytes of a 2-byte format -> 8 floats (h16: still scaled by 2^-6)
-        if constexpr (XF32 == 2) {
-            unpack8h_raw(v, o);
-        } else {
-            unpack8(v, o);
-        }
-    };
-    auto ld8 = [&](int64_t e8, float* o) {              // (tails / odd channel counts)
-        if constexpr (XF32 == 1) load8<1>(x, e8, o); else raw8(*(const uint4*)((const bf16_t*)x + e8), o);
-    };
-    if ((256 % cchunks) == 0) {
-        // every chunk this thread touches starts at the same channel (the grid stride is a multiple of C / 8):
-        // its 8 scale / offset pairs live in registers, no per-chunk index arithmetic or LDS reads
-        const int c0 = (threadIdx.x % cchunks) * 8;
-        float sa[8], sb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sa[e] = a_s[c0 + e]; sb[e] = b_s[c0 + e]; }
-        // streaming pass (the tensor is far larger than L2): non-temporal accesses, two chunks in flight per thread
-        // (four in flight measured 8-11 % SLOWER on MI355X -- 577-597 us against 532-535 us for 5 x 1024^2 x 128, gpurun r4n)
-        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-        int64_t i = i0;
-        for (; i + stride < nchunks; i += 2 * stride) {
-            float f[8], h[8];
-            if constexpr (XF32 == 1) {
-                const f32x4 a0 = __builtin_nontemporal_load((const f32x4*)(xf + i * 8)), a1 = __builtin_nontemporal_load((const f32x4*)(xf + i * 8 + 4));
-                const f32x4 b0 = __builtin_nontemporal_load((const f32x4*)(xf + (i + stride) * 8)), b1 = __builtin_nontemporal_load((const f32x4*)(xf + (i + stride) * 8 + 4));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { f[e] = a0[e]; f[4 + e] = a1[e]; h[e] = b0[e]; h[4 + e] = b1[e]; }
-            } else {
-                const u32x4 v0 = __builtin_nontemporal_load((const u32x4*)(xb + i * 8));
-                const u32x4 v1 = __builtin_nontemporal_load((const u32x4*)(xb + (i + stride) * 8));
-                raw8(make_uint4(v0.x, v0.y, v0.z, v0.w), f);
-                raw8(make_uint4(v1.x, v1.y, v1.z, v1.w), h);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { f[e] = act(f[e] * sa[e] + sb[e]); h[e] = act(h[e] * sa[e] + sb[e]); }
-            const uint4 o0 = pack8(f), o1 = pack8(h);
-            __builtin_nontemporal_store(u32x4{o0.x, o0.y, o0.z, o0.w}, (u32x4*)(yb + i * 8));
-            __builtin_nontemporal_store(u32x4{o1.x, o1.y, o1.z, o1.w}, (u32x4*)(yb + (i + stride) * 8));
-        }
-        for (; i < nchunks; i += stride) {
-            float f[8];
-            ld8(xo + i * 8, f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = act(f[e] * sa[e] + sb[e]);
-            *(uint4*)(yb + i * 8) = pack8(f);
-        }
-    } else {
-        for (int64_t i = i0; i < nchunks; i += stride) {
-            const int c0 = (int)(i % cchunks) * 8;
-            float f[8];
-            ld8(xo + i * 8, f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = act(f[e] * a_s[c0 + e] + b_s[c0 + e]);
-            *(uint4*)(yb + i * 8) = pack8(f);
-        }
-    }
-}
-
-#ifndef SVR_GN_PACKED
-#define SVR_GN_PACKED 0
-#endif
-#if SVR_GN_PACKED
-// Experiment build only (tools/ubench/build_variant.sh -DSVR_GN_PACKED=1; the product does not contain this kernel): the same pass for
-// the 2-byte inputs with (a) SiLU a template argument instead of a run-time flag -- the flag costs one v_cndmask per element -- and
-// (b) the affine + SiLU arithmetic on float2 vectors: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue two elements per slot and are
-// the same IEEE operations in the same order (x * a + b contracted to one FMA exactly as in groupnorm_apply_kernel; silu(u) =
-// u * rcp(1 + exp2(-log2(e) * u))), so the output is BIT-IDENTICAL.  By static count the hot loop goes from 956 to 764 VALU issue cycles
-// per two chunks (512 of them the 32 quarter-rate transcendentals); the pass runs at 5.0 TB/s with the VALU port ~60 % busy, so the
-// arithmetic is a suspect.  A/B: tools/ubench/gn_ab (product) vs gn_ab_x (this build), equal checksums expected.
+// GroupNorm apply (+ SiLU): y = act(x * a_c + b_c) with a_c = gamma_c * rstd_g (times 2^6 for an h16 input), b_c = beta_c - mean_g * a_c.
+// A streaming pass over a tensor far larger than L2, 2 B (or 4 B) in and 2 B out per element.  Round 5 form, chosen by measurement
+// (tools/ubench/stream_ab, profiles/r5_gn_stream_ab.txt: 27 variants of this pass on 5 x 1024^2 x 128):
+//   * every workgroup owns ONE CONTIGUOUS SPAN of its frame (256 threads x 16 B = 4 KiB per sweep) instead of a grid-stride walk over
+//     the frame: 6.1-6.2 TB/s against 4.9-5.0 (the open DRAM pages of a span are used up by the workgroup that opened them);
+//   * four chunks in flight per thread (with the grid-stride walk four were SLOWER than two; with contiguous spans they are faster);
+//   * SiLU is a template argument (the run-time flag cost a v_cndmask per element) and the affine + SiLU arithmetic runs on float2
+//     vectors (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations in the same order, two elements per issue slot);
+//   * mean / rstd are derived once per GROUP (one fp64 division chain on `groups` lanes), not once per channel.
+// All of it is bit-identical to the round 1-4 kernel (tools/ubench/gn_ab prints the same output checksums).
 template <bool SILU> SVR_DEVICE void gn_affine_act8(float* f, const float* sa, const float* sb) {
     typedef __attribute__((ext_vector_type(2))) float f32x2_p;
 #pragma unroll
@@ -436,60 +347,97 @@ template <bool SILU> SVR_DEVICE void gn_affine_act8(float* f, const float* sa, c
     }
 }
 
-template <int XF32, bool SILU>    // XF32: 0 bf16 | 2 h16 input
-__global__ __launch_bounds__(256) void groupnorm_apply_packed_kernel(const void* __restrict__ x, bf16_t* __restrict__ y,
-                                                                     const double* __restrict__ stats, const float* __restrict__ gamma,
-                                                                     const float* __restrict__ beta, int64_t HW, int C, int groups, float eps) {
-    static_assert(XF32 == 0 || XF32 == 2, "2-byte inputs");
-    __shared__ float a_s[512], b_s[512];
+template <int XF32, bool SILU>    // XF32: storage kind of x (SVR_STORE_*: 0 bf16, 1 fp32, 2 h16)
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const void* __restrict__ x, bf16_t* __restrict__ y,
+                                                              const double* __restrict__ stats,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int64_t HW, int C,
+                                                              int groups, float eps) {
+    __shared__ float a_s[512], b_s[512];            // per-channel scale / offset (C <= 512); first: per-group mean / rstd
     const int t = blockIdx.y;
     const int cpg = C / groups;
-    for (int c = threadIdx.x; c < C; c += 256) {         // (per-channel scale / offset exactly as groupnorm_apply_kernel computes them)
-        const int gidx = c / cpg;
+    for (int gidx = threadIdx.x; gidx < groups; gidx += 256) {
         const double n = (double)HW * (double)cpg;
         const double mean = stats[((int64_t)t * groups + gidx) * 2] / n;
         double var = stats[((int64_t)t * groups + gidx) * 2 + 1] / n - mean * mean;
         var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float ga = gamma[c] * rstd;
-        a_s[c] = XF32 == 2 ? ga * H16_INV : ga;
-        b_s[c] = beta[c] - (float)mean * ga;
+        a_s[gidx] = (float)(1.0 / sqrt(var + (double)eps));
+        b_s[gidx] = (float)mean;
+    }
+    __syncthreads();
+    float ga[2], gb[2];                              // (C <= 512: at most two channels per thread)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < C) {
+            const float g = gamma[c] * a_s[c / cpg];
+            ga[j] = XF32 == 2 ? g * H16_INV : g;     // (h16 input: the stored value is x * 2^-6 -- the factor absorbs the 2^6)
+            gb[j] = beta[c] - b_s[c / cpg] * g;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < C) { a_s[c] = ga[j]; b_s[c] = gb[j]; }
     }
     __syncthreads();
     const int cchunks = C >> 3;
-    const int64_t nchunks = HW * cchunks;
-    const bf16_t* xb = (const bf16_t*)x + (int64_t)t * HW * C;
-    bf16_t* yb = y + (int64_t)t * HW * C;
-    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
-    auto raw8 = [&](const uint4& v, float* o) { if constexpr (XF32 == 2) unpack8h_raw(v, o); else unpack8(v, o); };
+    const int64_t nchunks = HW * cchunks;            // 8-channel chunks of this frame
+    const int64_t xo = (int64_t)t * HW * C;          // element offset of this frame
+    bf16_t* yb = y + xo;
+    // this workgroup's contiguous span of the frame's chunks
+    const int64_t span = (nchunks + gridDim.x - 1) / gridDim.x;
+    const int64_t first = (int64_t)blockIdx.x * span + threadIdx.x;
+    const int64_t last = min((int64_t)(blockIdx.x + 1) * span, nchunks);
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-    if ((256 % cchunks) == 0) {                          // (the launcher sends only this case here)
-        const int c0 = (threadIdx.x % cchunks) * 8;
+    auto load = [&](int64_t i, float* o) {           // chunk i of the frame -> 8 floats (h16: still scaled by 2^-6)
+        if constexpr (XF32 == 1) {
+            const float* xf = (const float*)x + xo + i * 8;
+            const f32x4 v0 = __builtin_nontemporal_load((const f32x4*)xf), v1 = __builtin_nontemporal_load((const f32x4*)(xf + 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = v0[e]; o[4 + e] = v1[e]; }
+        } else {
+            const u32x4 v = __builtin_nontemporal_load((const u32x4*)((const bf16_t*)x + xo + i * 8));
+            if constexpr (XF32 == 2) unpack8h_raw(make_uint4(v.x, v.y, v.z, v.w), o); else unpack8(make_uint4(v.x, v.y, v.z, v.w), o);
+        }
+    };
+    auto store = [&](int64_t i, const float* f) {
+        const uint4 o = pack8(f);
+        __builtin_nontemporal_store(u32x4{o.x, o.y, o.z, o.w}, (u32x4*)(yb + i * 8));
+    };
+    if ((256 % cchunks) == 0) {
+        // every chunk of this thread starts at the same channel (the sweep of 256 chunks is a multiple of C / 8): its 8 scale /
+        // offset pairs live in registers, no per-chunk index arithmetic or LDS reads
+        const int c0 = (int)(first % cchunks) * 8;
         float sa[8], sb[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sa[e] = a_s[c0 + e]; sb[e] = b_s[c0 + e]; }
-        int64_t i = i0;
-        for (; i + stride < nchunks; i += 2 * stride) {
-            float f[8], h[8];
-            const u32x4 v0 = __builtin_nontemporal_load((const u32x4*)(xb + i * 8));
-            const u32x4 v1 = __builtin_nontemporal_load((const u32x4*)(xb + (i + stride) * 8));
-            raw8(make_uint4(v0.x, v0.y, v0.z, v0.w), f);
-            raw8(make_uint4(v1.x, v1.y, v1.z, v1.w), h);
-            gn_affine_act8<SILU>(f, sa, sb);
-            gn_affine_act8<SILU>(h, sa, sb);
-            const uint4 o0 = pack8(f), o1 = pack8(h);
-            __builtin_nontemporal_store(u32x4{o0.x, o0.y, o0.z, o0.w}, (u32x4*)(yb + i * 8));
-            __builtin_nontemporal_store(u32x4{o1.x, o1.y, o1.z, o1.w}, (u32x4*)(yb + (i + stride) * 8));
+        constexpr int INF = XF32 == 1 ? 2 : 4;       // chunks in flight per thread
+        int64_t i = first;
+        for (; i + (INF - 1) * 256 < last; i += INF * 256) {
+            float f[INF][8];
+#pragma unroll
+            for (int k = 0; k < INF; ++k) load(i + k * 256, f[k]);
+#pragma unroll
+            for (int k = 0; k < INF; ++k) { gn_affine_act8<SILU>(f[k], sa, sb); store(i + k * 256, f[k]); }
         }
-        for (; i < nchunks; i += stride) {
+        for (; i < last; i += 256) {
             float f[8];
-            raw8(*(const uint4*)(xb + i * 8), f);
+            load(i, f);
             gn_affine_act8<SILU>(f, sa, sb);
-            *(uint4*)(yb + i * 8) = pack8(f);
+            store(i, f);
+        }
+    } else {
+        for (int64_t i = first; i < last; i += 256) {
+            const int c0 = (int)(i % cchunks) * 8;
+            float f[8];
+            load(i, f);
+            gn_affine_act8<SILU>(f, a_s + c0, b_s + c0);
+            store(i, f);
         }
     }
 }
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // Row softmax of fp32 scores -> bf16 probabilities: P[r, :] = softmax(scale * S[r, :]).  One 256-thread block

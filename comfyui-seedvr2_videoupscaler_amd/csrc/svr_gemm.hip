@@ -716,14 +716,6 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // svr_set_option("gemm_asym") (written by launch() into the reserved word of its private copy of the arguments; 0 = off, the
-    // default): one wave of each SIMD at a higher issue priority, so that the two waves of a SIMD -- which leave the K-tile barrier
-    // together and would read their fragments and then issue their MFMAs at the same time -- fall half a K step apart, one wave's
-    // LDS reads under the other's MFMAs (DESIGN.md 3.3 found window attention phase-locked the same way).  1: waves 0 .. 3, 2: the even waves.
-    if (a.phase.reserved_ != 0) {
-        if (a.phase.reserved_ == 1 ? (wave < 4) : ((wave & 1) == 0)) __builtin_amdgcn_s_setprio(2);
-    }
-
     // ---- tile id: XCD-contiguous bands, then grouped (4 row panels x all column panels) order
     const int tiles_m = (a.M + BM - 1) / BM;
     const int tiles_n = (a.N + BN - 1) / BN;
@@ -1708,11 +1700,9 @@ static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-extern int g_gemm_asym;  // (defined below)
 template <int BM, int BN, int WM, int WN, bool CONV, bool EPI_LDS = false>
 static int launch(const svr_gemm_args& a_in, hipStream_t s) {
-    svr_gemm_args a = a_in;
-    a.phase.reserved_ = g_gemm_asym;                  // (the caller's value of the reserved word is never looked at)
+    const svr_gemm_args& a = a_in;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = gemm_lds_bytes<BM, BN, WM, WN, EPI_LDS>();
     auto kern = gemm_kernel<BM, BN, WM, WN, CONV, EPI_LDS>;
@@ -1746,8 +1736,6 @@ int g_pipe_abl = 0;
 // Auto = through LDS except for long-K SwiGLU (measured, profiles/r2_gemm_epilogue.txt: pixel-shuffle upsamplers x2.2-2.5,
 // 1x1 convs x1.5, DiT attn-out x1.12, qkv / mlp-out x1.02-1.03, mlp-in SwiGLU x0.98).
 int g_gemm_epi = 0;
-// wave priorities inside gemm_kernel (svr_set_option("gemm_asym")): 0 none (default), 1 waves 0 .. 3 favoured, 2 the even waves
-int g_gemm_asym = 0;
 constexpr int GEMM_EPI_LDS_MAX_K_SWIGLU = 1024;
 static bool gemm_epi_lds_aligned(const svr_gemm_args& a) {
     return (a.N % 8) == 0 && ((uintptr_t)a.C % 16) == 0 && (!a.resid || (((uintptr_t)a.resid % 16) == 0 && (a.ldr % 8) == 0)) &&

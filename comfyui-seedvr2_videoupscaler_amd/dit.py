@@ -135,6 +135,7 @@ class NaDiTEngine:
         self.ada_slots = torch.tensor(ada_slots, dtype=torch.int32, device=dev)
         self._plan_cache = {}
         self._rope_cache = {}
+        self.tap = None     # tests only: callable(tag, tensor) shown the residual stream in front of every block and behind the last
 
     # ------------------------------------------------------------------ nn.Module-shaped probes
     # The reference's phase code asks its models where and what they are the nn.Module way -- next(model.parameters()).device
@@ -283,6 +284,8 @@ class NaDiTEngine:
         if rope3d:
             pos_t = torch.zeros(Lt, 3, dtype=torch.int16, device=self.device)           # table row 0: no rotation
         for li, blk in enumerate(self.blocks):
+            if self.tap is not None:
+                self.tap(f"hid{li}", hid)
             final = li == cfg.num_layers - 1          # after this block's attention the text stream is dead
             last = final and cfg.last_vid_only        # 3B: the last block's text branch is not modulated
             shared = blk["shared"]
@@ -354,6 +357,8 @@ class NaDiTEngine:
                     mlp(slice(N, R), st, mod[st["ada"][("mlp", "gate")]])
 
         # ---- output head
+        if self.tap is not None:
+            self.tap(f"hid{cfg.num_layers}", xn if (not cfg.out_norm and hf) else hid)
         pred = ops.empty(N, cfg.patch_out_dim)
         if cfg.out_norm:
             ops.rmsnorm_mod(hid[:N], xn[:N], eps, w=self.out_norm_w, scale=mod[self.ada_out_scale],

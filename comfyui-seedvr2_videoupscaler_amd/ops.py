@@ -349,6 +349,8 @@ class HipOps:
         n_pos, n_freq = cos_tab.shape
         if sin_tab.shape != cos_tab.shape:
             raise ValueError("qknorm_rope: cos / sin tables of different shapes")
+        if wq is None or wk is None:
+            raise ValueError("qknorm_rope: the q / k norm weights are required (fp32 [128] each)")
         hip_lib.check(self.lib.svr_qknorm_rope(_ptr(qkv), rows, heads, _ptr(pos), t_offset, _ptr(cos_tab),
                                                _ptr(sin_tab), n_pos, n_freq, self._opt(wq, torch.float32, "wq", 128),
                                                self._opt(wk, torch.float32, "wk", 128), eps,
@@ -416,6 +418,8 @@ class HipOps:
         T, H, W, Cc = x.shape
         if out.numel() != x.numel():
             raise ValueError("groupnorm_apply: out must have x's shape")
+        if stats is None or gamma is None or beta is None:
+            raise ValueError("groupnorm_apply: stats, gamma and beta are required")
         hip_lib.check(self.lib.svr_groupnorm_apply(_ptr(x), _ptr(out), self._opt(stats, torch.float64, "stats", T * groups * 2),
                                                    self._opt(gamma, torch.float32, "gamma", Cc),
                                                    self._opt(beta, torch.float32, "beta", Cc), T, H * W,

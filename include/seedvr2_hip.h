@@ -255,13 +255,9 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * brings the activations into LDS by LDS-DMA | 2 the same with the activations staged through registers | 0 it stages both operands
  * through LDS whether W_frag is given or not,
  * "gemm_epi" epilogue of the GEMM kernel: 0 auto | 1 stores straight from the accumulators | 2 through LDS wherever possible,
- * "gemm_asym" issue priorities inside the eight-wave GEMM / generic conv kernel: 0 none (default) | 1 waves 0 .. 3 of a workgroup
- * favoured | 2 its even waves (one wave of each SIMD goes first out of the K-tile barrier; scheduling only),
  * "attn_impl" 0 auto (second-generation window kernel for head_dim 128 / windows <= 2048 rows) | 1 first kernel everywhere,
  * "attn_variant" build variant of the second-generation window kernel (0 default = 8 waves x 32 queries; 1 / 3 / 4: 4-wave and
- * s_setprio builds; 5 / 6: 4 waves x 64 queries, one wave per SIMD; 7 / 8: the same with K Q^T one tile ahead of the softmax;
- * 9 / 10: the default build with one wave of each SIMD at a higher issue priority -- see svr_attn_win.hip),
- * "gn_grid_cap" workgroups per frame of svr_groupnorm_apply, 64 .. 65535 (default 8192; the pass is elementwise: same result for any value),
+ * s_setprio builds -- see svr_attn_win.hip),
  * "pipe_abl" measurement-only ablations in -DSVR_ABLATIONS builds (non-zero values give garbage). */
 int svr_set_option(const char* key, int32_t value);
 const char* svr_last_error(void);

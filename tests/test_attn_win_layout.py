@@ -42,9 +42,8 @@ def tr16_b64(lds, addr):
     return out
 
 
-def run_wave(q, k, v, L, q0, wave, scale, NW=4, QW=1, b=0):
-    """q,k,v: [L, 128] float (bf16-representable not required).  Returns {qpos: out row} for this wave's valid queries
-    (QW = 2 builds: of its 32-query block b -- the two blocks of a wave share the K / V fragment reads and nothing else)."""
+def run_wave(q, k, v, L, q0, wave, scale, NW=4):
+    """q,k,v: [L, 128] float (bf16-representable not required).  Returns {qpos: out row} for this wave's valid queries."""
     nk = (L + KT - 1) // KT
     lds = np.zeros(4 * TILE // 2)                        # element (2-byte) addressed
     lanes = np.arange(64)
@@ -53,7 +52,7 @@ def run_wave(q, k, v, L, q0, wave, scale, NW=4, QW=1, b=0):
     i16, G = lanes & 15, (lanes >> 4) & 1
     jr, c4 = i16 >> 2, i16 & 3
     va_ = [2 * TILE + hi * 1024 + jr * 256 + ((((m ^ jr) << 2) | (2 * G + (c4 >> 1))) << 4) + (c4 & 1) * 8 for m in range(4)]
-    qpos = q0 + (wave * QW + b) * 32 + l31
+    qpos = q0 + wave * 32 + l31
     qrow = np.minimum(qpos, L - 1)
     qf = [np.stack([q[qrow[l], 16 * ds + 8 * hi[l]:16 * ds + 8 * hi[l] + 8] for l in range(64)]) for ds in range(8)]
     o = [np.zeros((64, 16)) for _ in range(4)]
@@ -149,26 +148,6 @@ def test_attn_win_index_algebra(NW):
         np.testing.assert_allclose(row, want[r], rtol=1e-9, atol=1e-9)
 
 
-def test_attn_win_index_algebra_64_queries_per_wave():
-    """attn_variant 5 / 6 (NW = 4, QW = 2): 256-query workgroup tiles like the 8-wave build, wave w owns the 32-query blocks
-    2 w and 2 w + 1.  Same staging roles as every NW = 4 build, same fragment addresses for both blocks."""
-    rng = np.random.default_rng(1)
-    L = 150
-    q, k, v = (rng.standard_normal((L, D)) for _ in range(3))
-    scale = 1 / np.sqrt(D)
-    s = (q @ k.T) * scale
-    p = np.exp(s - s.max(1, keepdims=True))
-    want = (p / p.sum(1, keepdims=True)) @ v
-    got = {}
-    for wave, b in ((0, 0), (0, 1), (1, 1), (2, 0), (2, 1)):           # blocks 0, 1, 3, 4 (ragged: 128..149), 5 (empty)
-        rows = run_wave(q, k, v, L, 0, wave, scale, NW=4, QW=2, b=b)
-        assert not (set(rows) & set(got))
-        got.update(rows)
-    assert set(got) == set(range(0, 64)) | set(range(96, 150))
-    for r, row in got.items():
-        np.testing.assert_allclose(row, want[r], rtol=1e-9, atol=1e-9)
-
-
 def test_attn_win_bank_model():
     """LDS bank model of MI355X_MICROARCH.md (LDS table): ds_read_b128 is served in 4 groups of 16 lanes, each must hit 16
     distinct 16-byte slots of the 256-byte bank row; ds_read_b64_tr_b16 in 2 groups of 32 lanes, each must cover 32
@@ -187,39 +166,3 @@ def test_attn_win_bank_model():
         addr = hi * 1024 + jr * 256 + ((((m ^ jr) << 2) | (2 * G + (c4 >> 1))) << 4) + (c4 & 1) * 8
         for g in (range(0, 32), range(32, 64)):
             assert len({int(a // 8) % 32 for a in addr[list(g)]}) == 32
-
-
-@pytest.mark.parametrize("nk", [1, 2, 3, 4, 7, 32])
-def test_attn_win_pipelined_buffer_protocol(nk):
-    """attn_variant 7 / 8 (K Q^T one tile ahead): K is staged two tiles ahead, V one, into two buffers each, with ONE barrier at
-    the end of an iteration (+ one behind the prologue's K(0) Q^T).  This restates the kernel's buffer rules (which buffer an
-    iteration reads, which it refills, how the read addresses flip) and checks, per barrier interval, that every read sees the tile
-    it means to, that no buffer is refilled in an interval in which it is read, and that what an interval reads was written in an
-    EARLIER interval (the barrier + vmcnt(0) between them is what makes the LDS-DMA data visible)."""
-    K = [None, None]; V = [None, None]                  # tile held by each buffer; writes of the current interval go to `pending`
-    def interval(reads_k, reads_v, writes):
-        for kind, buf, tile in reads_k + reads_v:
-            held = (K if kind == "K" else V)[buf]
-            assert held == tile, (kind, buf, tile, held)
-        read_bufs = {(kind, buf) for kind, buf, _ in reads_k + reads_v}
-        for kind, buf, tile in writes:
-            assert (kind, buf) not in read_bufs, ("refill of a buffer read in the same interval", kind, buf)
-        for kind, buf, tile in writes:                  # land before the closing barrier
-            (K if kind == "K" else V)[buf] = tile
-    clamp = lambda t: min(t, nk - 1)
-    # kernel entry .. first barrier: K(0) -> K0, V(0) -> V0
-    interval([], [], [("K", 0, 0), ("V", 0, 0)])
-    # prologue: K(1) -> K1 (rows of tile 1, clamped), S(0) = K(0) Q^T from K buffer 0; barrier
-    ka, va = 0, 0
-    interval([("K", ka, 0)], [], [("K", 1, clamp(1))])
-    ka = 1                                               # ka_ += AW_TILE
-    t = 0
-    while t + 1 < nk:                                    # iter<not LAST>
-        kw, vw = t & 1, (t & 1) ^ 1
-        interval([("K", ka, t + 1)], [("V", va, t)], [("K", kw, clamp(t + 2)), ("V", vw, t + 1)])
-        flip = -1 if (t & 1) else 1
-        ka -= flip; va += flip
-        assert ka in (0, 1) and va in (0, 1)
-        t += 1
-    interval([], [("V", va, t)], [])                     # iter<LAST>: P V of the last tile, nothing staged
-    assert t == nk - 1

@@ -1,5 +1,5 @@
 // Standalone A/B of svr_groupnorm_apply (GroupNorm apply + SiLU over an NDHWC tensor: 6.8 % of a BASELINE config 3 step) through the C ABI.
-//   usage: gn_ab [reps] [case ...] [key=value ...]     (key=value: svr_set_option before the runs, e.g. gn_grid_cap=2048)     cases (h16 trunk input -> bf16 output, 32 groups, as a VAE tile issues them):
+//   usage: gn_ab [reps] [case ...] [key=value ...]     (key=value: svr_set_option before the runs)     cases (h16 trunk input -> bf16 output, 32 groups, as a VAE tile issues them):
 //     gn128  5 x 1024^2 x 128 (default)    gn256  5 x 512^2 x 256    gn512  5 x 256^2 x 512    gn128b  the same tensor as bf16 input
 // Each case runs with SiLU and without; prints microseconds, TB/s over the algorithmic bytes (2 B read + 2 B written per element) and a
 // 64-bit checksum of the output -- an experiment library (tools/ubench/build_variant.sh -DSVR_GN_PACKED=1 -> gn_ab_x) must print the same.
