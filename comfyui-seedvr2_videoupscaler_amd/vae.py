@@ -703,15 +703,22 @@ class VideoVAEEngine:
         x[..., :Cc] = x_cthw.to(device=self.device, dtype=self.ops.act_dtype).permute(1, 2, 3, 0)   # layout only
         return x
 
-    def _guarded(self, call):
-        """Run ``call()``; if its result is not finite and an h16 store is in use, once more with those stores in fp32 (see
-        ``overflow_guard`` in __init__)."""
+    def _guarded(self, call, inp: torch.Tensor):
+        """Run ``call()``; if its result is not finite although its input ``inp`` was, and an h16 store is in use, once more with
+        those stores in fp32 (see ``overflow_guard`` in __init__).  Cost: one fp32 reduction over the output and ONE HOST SYNC per
+        encode() / decode() call (the pipeline makes one such call per temporal batch: microseconds against seconds); the input is
+        only looked at when the output failed.  A non-finite INPUT (e.g. NaN latents from upstream) is not an h16 overflow: the call
+        is not repeated, the non-finite result is returned as the reference would return it, with a warning naming the input."""
         out = call()
         if not self.overflow_guard or "h16" not in (self.trunk_store, self.branch_store):
             return out
         if bool(torch.isfinite(out.sum(dtype=torch.float32))):
             return out
         import warnings
+        if not bool(torch.isfinite(inp.float().sum())):
+            warnings.warn("VideoVAEEngine: the input of this call is not finite; its output is returned as computed (not an h16 "
+                          "range problem, no fp32 re-run)", RuntimeWarning, stacklevel=3)
+            return out
         warnings.warn("VideoVAEEngine: non-finite output with h16 stores (an activation beyond +-4.2e6?); repeating the call with "
                       "fp32 stores", RuntimeWarning, stacklevel=3)
         saved = (self.trunk_store, self.trunk_dtype, self.branch_store, self.branch_dtype)
@@ -729,7 +736,7 @@ class VideoVAEEngine:
     def encode(self, x_cthw: torch.Tensor, tiled: bool = False, tile_size=(512, 512), tile_overlap=(64, 64),
                frames_per_slice: Optional[int] = None) -> torch.Tensor:
         """[3, T, H, W] in [-1, 1] -> scaled latent [T', H/8, W/8, 16] = (mean - shift) * scale."""
-        return self._guarded(lambda: self._encode(x_cthw, tiled, tile_size, tile_overlap, frames_per_slice))
+        return self._guarded(lambda: self._encode(x_cthw, tiled, tile_size, tile_overlap, frames_per_slice), x_cthw)
 
     def _encode(self, x_cthw, tiled, tile_size, tile_overlap, frames_per_slice):
         cfg, ops = self.cfg, self.ops
@@ -782,7 +789,8 @@ class VideoVAEEngine:
         after decode, generation_phases.py:953-958): the decoder is causal in time, so the latent frames that only feed
         trimmed output and, at full frame rate, the trimmed frames themselves are not computed -> [3, n, 8h, 8w], equal to
         the first n frames of the full decode."""
-        return self._guarded(lambda: self._decode(latent_thwc, tiled, tile_size, tile_overlap, latents_per_slice, keep_frames))
+        return self._guarded(lambda: self._decode(latent_thwc, tiled, tile_size, tile_overlap, latents_per_slice, keep_frames),
+                             latent_thwc)
 
     def _decode(self, latent_thwc, tiled, tile_size, tile_overlap, latents_per_slice, keep_frames):
         cfg, ops = self.cfg, self.ops

@@ -143,9 +143,13 @@ int svr_conv_pack_frag_taps(const void* W, void* out, int32_t N, int32_t K, int3
  * (0: the kernel that serves this problem does not produce fused statistics -- use svr_groupnorm_stats). */
 int32_t svr_gemm_gn_blocks(const svr_gemm_args* args);
 
-/* Which kernel svr_gemm_bf16 would launch for `args` (no launch, no GPU needed): one of SVR_KERNEL_*, or -1 with
- * svr_last_error() set when svr_gemm_bf16 would refuse the arguments.  ABI v6.  bench.py attributes launch times to kernels
- * with it (the `roofline` object is the SVR_KERNEL_CONV_HALO launches only), tests pin it on the shapes a VAE tile issues. */
+/* Which kernel svr_gemm_bf16 would launch for `args` (no launch): one of SVR_KERNEL_*, or -1 with svr_last_error() set when
+ * svr_gemm_bf16 would refuse the arguments.  ABI v6.  bench.py attributes launch times to kernels with it (the `roofline`
+ * object is the SVR_KERNEL_CONV_HALO launches only), tests pin it on the shapes a VAE tile issues.
+ * One class depends on the DEVICE: SVR_KERNEL_GEMM_PERSISTENT needs at least 8 compute units (one workgroup per CU in multiples of
+ * the 8 XCDs; a smaller partition gets SVR_KERNEL_GEMM), and this function reads the CU count of the calling thread's CURRENT
+ * device (256 when there is no GPU), whereas svr_gemm_bf16 launches on the device of its stream.  Callers that attribute by it
+ * (bench.py) make the stream's device current first, as torch.cuda.set_device does; every other class is a function of `args` alone. */
 #define SVR_KERNEL_NONE            0   /* empty problem: nothing is launched                                           */
 #define SVR_KERNEL_GEMM            1   /* gemm_kernel (eight waves, 256x256 / 256x128 tiles)                           */
 #define SVR_KERNEL_GEMM_PERSISTENT 2   /* gemm_w4r_kernel / gemm_w4q_kernel (persistent four-wave workgroups, the NaDiT's big GEMMs; with / without W_frag) */

@@ -82,6 +82,12 @@ def test_vae_engine_h16_overflow_guard_repeats_the_call_with_fp32_stores():
         warnings.simplefilter("error")
         a = e0.decode(z)
     assert e0.overflow_reruns == 0 and torch.equal(a, vae.VideoVAEEngine(cfg, sd0, TorchOps("cpu", act_dtype=BF16), overflow_guard=False).decode(z))
+    # a non-finite INPUT (NaN latents from upstream) is not an h16 overflow: no fp32 re-run, the warning names the input
+    zn = z.clone()
+    zn[0, 0, 0, 0] = float("nan")
+    with pytest.warns(RuntimeWarning, match="input of this call is not finite"):
+        bad = e0.decode(zn)
+    assert e0.overflow_reruns == 0 and not torch.isfinite(bad.float()).all()
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="needs the reference checkout (the recipe compiles it)")

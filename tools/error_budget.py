@@ -7,6 +7,7 @@ rounded to bf16 or left exact by a switch.  One line per experiment: all stores 
 class left exact in turn (what fixing THAT store would buy), then cumulative candidates.  Test/measurement tooling only.
 
     python tools/error_budget.py [--fixture vae_tiled17|pipeline_small] [--quick]
+    python tools/error_budget.py --fixture pipeline_prod --fp8      # BASELINE config 5's "fp8 MFMA weight path", priced (see Fp8DitOps)
 """
 import argparse
 import math
@@ -95,6 +96,49 @@ class BudgetOps(TorchOps):
         return self._r(super().affine_slice(inp, out, *a, **k), "io")
 
 
+E4M3 = torch.float8_e4m3fn
+
+
+def quant_e4m3(x: torch.Tensor, mode: str) -> torch.Tensor:
+    """fp32 values -> what an e4m3 MFMA operand would hold (returned as fp32), K along the last axis.
+    "tensor": one scale amax / 448 per tensor;  "row": one per row (token / output channel);  "mx": the OCP MX format of
+    v_mfma_scale_f32_16x16x128_f8f6f4 -- blocks of 32 along K share a power-of-two scale 2^(floor(log2 amax) - 8);
+    "raw": no scale at all (how the reference's fp8 checkpoints hold the weights, compatibility.py:895-938)."""
+    x = x.float()
+    if mode == "raw":
+        return x.clamp(-448, 448).to(E4M3).float()
+    if mode == "mx":
+        k = x.shape[-1]
+        pad = (-k) % 32
+        xb = torch.nn.functional.pad(x, (0, pad)).reshape(*x.shape[:-1], -1, 32)
+        amax = xb.abs().amax(-1, keepdim=True).clamp_min(2.0 ** -120)
+        sc = torch.exp2(torch.floor(torch.log2(amax)) - 8)
+        q = ((xb / sc).clamp(-448, 448).to(E4M3).float() * sc).reshape(*x.shape[:-1], -1)
+        return q[..., :k]
+    amax = (x.abs().amax() if mode == "tensor" else x.abs().amax(-1, keepdim=True)).clamp_min(1e-30)
+    sc = amax / 448.0
+    return (x / sc).to(E4M3).float() * sc
+
+
+class Fp8DitOps(TorchOps):
+    """The product's storage regime (bf16 stores, fp32 stream) with the operands of the NaDiT's four big GEMMs per block (qkv,
+    attn-out, mlp-in, mlp-out: every GEMM with K >= 2048 that sees the video tokens) rounded to e4m3 the way an fp8 MFMA path would
+    have to: ``act`` / ``wgt`` in (None, "tensor", "row", "mx", "raw").  Arithmetic stays fp32 (the MFMA accumulates in fp32)."""
+
+    def __init__(self, act, wgt):
+        super().__init__("cpu", act_dtype=BF16)
+        self.act, self.wgt, self.hits = act, wgt, 0
+
+    def gemm(self, A, W, out, *, N, K, conv=None, **kw):
+        if conv is None and K >= 2048 and N >= 2048 and A.shape[0] > 64:
+            self.hits += 1
+            if self.act:
+                A = quant_e4m3(A.reshape(-1, A.shape[-1])[:, :K], self.act)
+            if self.wgt:
+                W = quant_e4m3(W[:N, :K], self.wgt)
+        return super().gemm(A, W, out, N=N, K=K, conv=conv, **kw)
+
+
 def psnr_nominal(a, b, peak):
     mse = float((a.double() - b.double()).pow(2).mean())
     return 10 * math.log10(peak * peak / max(mse, 1e-30))
@@ -111,13 +155,15 @@ def run_vae17(rounded, g, sd, mg, **eng_kw):
     return rel_err(y, g["dec_tiled"][0]), psnr_nominal(y, g["dec_tiled"][0], 2.0)
 
 
-def run_pipeline(rounded, g, mg, **eng_kw):
+def run_pipeline(rounded, g, mg, dit_ops=None, **eng_kw):
     config, weights, dit, vae, runner, pipeline = (sub(n) for n in ("config", "weights", "dit", "vae", "runner", "pipeline"))
     dcfg, vcfg = getattr(config, g.get("dit", "DIT_TINY")), config.VAEConfig(block_out_channels=tuple(g["vae_channels"]))
     tile = (dict(encode_tiled=True, decode_tiled=True, encode_tile_size=tuple(g["vae_tile"]), decode_tile_size=tuple(g["vae_tile"]),
                  encode_tile_overlap=tuple(g["vae_tile_overlap"]), decode_tile_overlap=tuple(g["vae_tile_overlap"]))
             if g.get("vae_tile") else {})
-    if rounded is None:
+    if dit_ops is not None:
+        ops_v, ops_d = TorchOps("cpu", act_dtype=BF16), dit_ops
+    elif rounded is None:
         ops_v = ops_d = TorchOps("cpu", act_dtype=BF16)
     else:
         ops_v, ops_d = BudgetOps(rounded), BudgetOps(rounded)
@@ -141,6 +187,8 @@ def main():
     ap.add_argument("--quick", action="store_true", help="only: everything rounded / candidates")
     ap.add_argument("--engine-only", action="store_true", help="only the rows that run the engines in their real storage regimes")
     ap.add_argument("--rows", default="", help="comma-separated substrings: only the rows whose name contains one of them")
+    ap.add_argument("--fp8", action="store_true",
+                    help="pipeline fixtures: the shipped regime with the operands of the NaDiT's big GEMMs rounded to e4m3 (Fp8DitOps)")
     args = ap.parse_args()
     from oracle import make_golden as mg
     weights, config = sub("weights"), sub("config")
@@ -153,6 +201,19 @@ def main():
         sd = weights.synth_vae_state_dict(config.VAE_V3, seed=g["seed_weights"])
         run = lambda rounded, **kw: run_vae17(rounded, g, sd, mg, **kw)
     allr = set(sites)
+    if args.fp8:
+        for name, act, wgt in (("shipped regime (bf16 operands)", None, None),
+                               ("weights e4m3 unscaled (a fp8 checkpoint as the reference up-casts it), bf16 activations", None, "raw"),
+                               ("weights e4m3 per-row scale, bf16 activations", None, "row"),
+                               ("activations e4m3 per-tensor scale, bf16 weights", "tensor", None),
+                               ("activations e4m3 per-token scale, bf16 weights", "row", None),
+                               ("activations e4m3 MX blocks of 32 (v_mfma_scale f8f6f4), bf16 weights", "mx", None),
+                               ("both operands e4m3 MX blocks of 32", "mx", "mx"),
+                               ("both operands e4m3 per-row / per-token scale", "row", "row")):
+            ops_d = Fp8DitOps(act, wgt)
+            e, p = run(None, dit_ops=ops_d)
+            print(f"{args.fixture:16s} fp8: {name:95s} rel-err {e:.3e}   PSNR(nominal) {p:6.2f} dB   ({ops_d.hits} GEMMs)", flush=True)
+        return
     rows = [(f"ENGINE store trunk={t} branch={b}" + (" (round 4 as shipped)" if (t, b) == ("h16", "h16") else ""), None, dict(trunk_store=t, branch_store=b))
             for t, b in (("fp32", "h16"), ("h16", "h16"), ("h16", "bf16"), ("fp32", "fp32"))]
     rows += [("ENGINE sample fp32, store trunk=h16 branch=h16", None, dict(trunk_store="h16", branch_store="h16", sample_dtype=torch.float32)),
