@@ -48,7 +48,7 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "conv_impl")) { g_conv_impl = value; return 0; }
     if (!strcmp(key, "gemm_epi")) { g_gemm_epi = value; return 0; }
     if (!strcmp(key, "gemm_w4")) { g_gemm_w4 = value; return 0; }
-    if (!strcmp(key, "gemm_w4r")) { g_gemm_w4r = value; return 0; }
+    if (!strcmp(key, "gemm_w4r")) { if ((unsigned)value > 1u) return fail("svr_set_option: gemm_w4r is 0 or 1"); g_gemm_w4r = value; return 0; }
     if (!strcmp(key, "conv_rows")) { g_conv_rows = value; return 0; }
     if (!strcmp(key, "conv_band")) { g_conv_band = value; return 0; }
     if (!strcmp(key, "conv_sub")) { g_conv_sub = value; return 0; }

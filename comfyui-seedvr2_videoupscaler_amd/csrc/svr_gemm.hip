@@ -1537,8 +1537,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4q_kernel(const svr_gemm_
 
 extern int g_pipe_abl;  // (defined below)
 int g_gemm_w4r = 1;    // svr_set_option("gemm_w4r"): 1 (default) a persistent-kernel GEMM whose args carry W_frag runs on gemm_w4r_kernel
-                       // (weights from the fragment-ordered copy straight into registers, activations into LDS by LDS-DMA) | 2 the same
-                       // with the activations staged through registers | 0 always gemm_w4q_kernel (both operands through LDS)
+                       // (weights from the fragment-ordered copy straight into registers, activations into LDS by LDS-DMA) | 0 always
+                       // gemm_w4q_kernel (both operands through LDS)
 int g_gemm_w4 = 1;     // svr_set_option("gemm_w4"): 1 (default) big plain GEMMs on gemm_w4q_kernel | 0 everything on gemm_kernel | 2 (measurement
                        // build only) gemm_w4p_kernel.  Same box, the forms the NaDiT issues (profiles/r3_gemm_w4_ablations.txt sections 9, 10):
                        // against gemm_kernel qkv -6.5 %, attn-out / mlp-out into the fp32 stream -10 % / -12 %, mlp-in SwiGLU -7 %
@@ -1638,7 +1638,7 @@ static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
 #endif
     if (a.W_frag && g_gemm_w4r) {
 #ifdef SVR_ABLATIONS
-        if (g_pipe_abl >= 300 && g_pipe_abl < 428) {      // K-loop ablations of gemm_w4r_kernel (results invalid)
+        if (g_pipe_abl >= 500 && g_pipe_abl < 628) {      // K-loop ablations of gemm_w4r_kernel (results invalid)
             static uint64_t done_abl[128] = {0};
             auto go = [&](auto kern, uint64_t& done) {
                 const int e3 = set_max_dynamic_lds((const void*)kern, W4P_LDS, done);
@@ -1646,51 +1646,22 @@ static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a);
                 return (int)hipGetLastError();
             };
-            switch (g_pipe_abl - 300) {
-                case 1: return go(gemm_w4r_kernel<1, false>, done_abl[1]);
-                case 2: return go(gemm_w4r_kernel<2, false>, done_abl[2]);
-                case 4: return go(gemm_w4r_kernel<4, false>, done_abl[4]);
-                case 8: return go(gemm_w4r_kernel<8, false>, done_abl[8]);
-                case 6: return go(gemm_w4r_kernel<6, false>, done_abl[6]);
-                case 15: return go(gemm_w4r_kernel<15, false>, done_abl[15]);
-                case 16: return go(gemm_w4r_kernel<16, false>, done_abl[16]);
-                case 32: return go(gemm_w4r_kernel<32, false>, done_abl[32]);
-                case 64: return go(gemm_w4r_kernel<64, false>, done_abl[64]);
-                case 96: return go(gemm_w4r_kernel<96, false>, done_abl[96]);
+            switch (g_pipe_abl - 500) {
+                case 1: return go(gemm_w4r_kernel<1>, done_abl[1]);
+                case 2: return go(gemm_w4r_kernel<2>, done_abl[2]);
+                case 4: return go(gemm_w4r_kernel<4>, done_abl[4]);
+                case 8: return go(gemm_w4r_kernel<8>, done_abl[8]);
+                case 6: return go(gemm_w4r_kernel<6>, done_abl[6]);
+                case 32: return go(gemm_w4r_kernel<32>, done_abl[32]);
+                case 64: return go(gemm_w4r_kernel<64>, done_abl[64]);
                 default: break;
             }
         }
 #endif
-        if (g_gemm_w4r != 2) {                            // activations by LDS-DMA (the default)
-#ifdef SVR_ABLATIONS
-            if (g_pipe_abl >= 500 && g_pipe_abl < 516) {
-                static uint64_t done_abl2[16] = {0};
-                auto go = [&](auto kern, uint64_t& done) {
-                    const int e3 = set_max_dynamic_lds((const void*)kern, W4P_LDS, done);
-                    if (e3 != 0) return e3;
-                    hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a);
-                    return (int)hipGetLastError();
-                };
-                switch (g_pipe_abl - 500) {
-                    case 1: return go(gemm_w4r_kernel<1, true>, done_abl2[1]);
-                    case 2: return go(gemm_w4r_kernel<2, true>, done_abl2[2]);
-                    case 4: return go(gemm_w4r_kernel<4, true>, done_abl2[4]);
-                    case 8: return go(gemm_w4r_kernel<8, true>, done_abl2[8]);
-                    case 6: return go(gemm_w4r_kernel<6, true>, done_abl2[6]);
-                    default: break;
-                }
-            }
-#endif
-            static uint64_t lds_attr_done_s = 0;
-            const int es = set_max_dynamic_lds((const void*)gemm_w4r_kernel<0, true>, W4P_LDS, lds_attr_done_s);
-            if (es != 0) return es;
-            hipLaunchKernelGGL((gemm_w4r_kernel<0, true>), dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a);
-            return (int)hipGetLastError();
-        }
-        static uint64_t lds_attr_done_r = 0;
-        const int er = set_max_dynamic_lds((const void*)gemm_w4r_kernel<0, false>, W4P_LDS, lds_attr_done_r);
-        if (er != 0) return er;
-        hipLaunchKernelGGL((gemm_w4r_kernel<0, false>), dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a);
+        static uint64_t lds_attr_done_s = 0;
+        const int es = set_max_dynamic_lds((const void*)gemm_w4r_kernel<0>, W4P_LDS, lds_attr_done_s);
+        if (es != 0) return es;
+        hipLaunchKernelGGL((gemm_w4r_kernel<0>), dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a);
         return (int)hipGetLastError();
     }
     static uint64_t lds_attr_done_q = 0;

@@ -35,10 +35,8 @@
 //   -> loads issued behind the awaited one: BX[J] 23; BY[J] 23 21 21 21 21 23 23 23; the pieces before the barrier: 12 (Y4..Y7 and the
 //   eight BX reloads were issued behind D7).  The prologue issues one whole period in that order, so the counts hold from the first
 //   K tile on; nothing else touches vmcnt inside the K loop (the previous tile's stores are drained behind its epilogue).
-// ADMA = false (svr_set_option("gemm_w4r", 2); the first version, kept for A/B): the activations go through 32 staging VGPRs and
-//   ds_write_b128 as in gemm_w4q_kernel -- pieces stored in slots 11 + 6 q of half 0 and reloaded (K tile f + 2) in 12 + 6 q, load order
-//   B0 (7) A0 (12) B1 (15) A1 (18) B2 (23) A2 (24) A3 (30) B3 (31) A4 (36) B4 (39) A5 (42) B5 (47) A6 (48) A7 (54) B6 (55) B7 (63) | Y0..Y7,
-//   counts BX[J] 23 22 22 21 22 22 21 23, BY[J] 23, A pieces 23; LDS as gemm_w4q_kernel's (the B halves of the stages unused).
+// (The first version of this kernel staged the activations through 32 VGPRs and ds_write_b128 like gemm_w4q_kernel -- svr_set_option
+// ("gemm_w4r", 2) in round 4; 1-3 % slower, and its bit-equality test failed once in round 5's full GPU run: removed.)
 
 // W [N, K] (row-major bf16; N % 128 == 0, K % 32 == 0) -> fragment order: 16-byte unit
 //   (((n / 128) * (K / 32) + k32) * 8 + (n % 128) / 16) * 64 + lane  =  W[(n & ~15) + (lane & 15)][k32 * 32 + (lane >> 4) * 8 .. + 7]
@@ -61,21 +59,20 @@ template <int OFF> SVR_DEVICE void w4r_bload(bf16x8& r, const w4p_u32x4& rsrc, u
 template <int N> SVR_DEVICE void w4r_wait_frag(bf16x8& r) {           // counted vmcnt naming the fragment whose data must be there
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N));
 }
-constexpr int w4r_bx_count(int J) { return J == 0 || J == 7 ? 23 : (J == 3 || J == 6 ? 21 : 22); }
 
-// DBG (builds with -DSVR_ABLATIONS only; results invalid): 1 no K-loop barrier | 2 no weight loads in the K loop | 4 no A loads / LDS stores
-// in the K loop | 8 no fragment reads in the K loop | 16 A loads but no LDS stores | 32 A loads always from the same (cache-hot) K tile |
-// 64 weight loads always from the same K tile   (svr_set_option("pipe_abl", 300 + bits); profiles/r4_gemm_w4r_ablations.txt)
+// DBG (builds with -DSVR_ABLATIONS only; results invalid): 1 no K-loop barrier | 2 no weight loads in the K loop | 4 no A loads (LDS-DMA pieces)
+// in the K loop | 8 no fragment reads in the K loop | 32 A loads always from the same (cache-hot) K tile |
+// 64 weight loads always from the same K tile   (svr_set_option("pipe_abl", 500 + bits); profiles/r4_gemm_w4r_ablations.txt)
 constexpr int w4s_by_count(int J) { return J >= 1 && J <= 4 ? 21 : 23; }
 SVR_DEVICE void w4s_dma(unsigned lds_wave_base, const w4p_u32x4& rsrc, uint32_t voff, uint32_t soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_wave_base), "v"(voff), "s"(rsrc), "s"(soff) : "memory");     // (m0 is reserved: hipcc neither allocates it nor, on gfx950, keeps a value of its own in it)
 }
 // (Other placements of the LDS operations -- AY reads in the first 16 slots of half 0; barrier in slot 1 of half 1 with the AX reads right
 // behind it and the pieces in slots 20 .. 48 -- measured within +-0.5 % of this one: profiles/r4_gemm_w4r_ablations.txt section 4.)
-template <int DBG = 0, bool ADMA = true>
+template <int DBG = 0>
 __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4r_kernel(const svr_gemm_args a) {
     constexpr int BAR_SLOT = 6;
-    constexpr int S1 = ADMA ? 32768 : W4P_S1;             // byte offset of stage 1
+    constexpr int S1 = 32768;                             // byte offset of stage 1
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -164,8 +161,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4r_kernel(const svr_gemm_
     point_b(n0);
 
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    unsigned wrA = lds0 + (unsigned)(wave * 1024 + lane * 16);
-    unsigned dmaS = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wave * 1024));     // (ADMA) this wave's slice of the CURRENT stage
+    unsigned dmaS = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wave * 1024));     // this wave's slice of the CURRENT stage
     const int l15 = lane & 15, kq = lane >> 4;
     const unsigned key = (unsigned)((l15 >> 1) & 7);
     const unsigned rA = lds0 + (unsigned)((wm * 128 + l15) * 128);
@@ -174,18 +170,12 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4r_kernel(const svr_gemm_
     for (int kh = 0; kh < 2; ++kh) rdA[kh] = rA + ((((unsigned)(4 * kh + kq)) ^ key) << 4);
     f32x4 acc[8][8];
     bf16x8 AX[8], AY[8], BX[8], BY[8];
-    w4p_u32x4 sa[8];
 
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define W4R_C(v) std::integral_constant<int, (v)>{}
-#define W4R_LDA(Q) w4p_bload(sa[Q], Arsrc, aoff0, Akoff + (Q) * arowblk)
 #define W4S_DMA(BASE, Q) w4s_dma((BASE) + (Q) * 4096u, Arsrc, aoff0, Akoff + (Q) * arowblk)
 #define W4R_LDBX(J) w4r_bload<((J) & 3) * 1024>(BX[J], Brsrc, boff, Bsoff + ((J) >> 2) * 4096u)
 #define W4R_LDBY(J) w4r_bload<((J) & 3) * 1024>(BY[J], Brsrc, boff, Bsoff + 8192u + ((J) >> 2) * 4096u)
-#define W4R_LANDED() asm volatile("s_waitcnt vmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sa[4]), "+v"(sa[5]), \
-                                  "+v"(sa[6]), "+v"(sa[7]), "+v"(BX[0]), "+v"(BX[1]), "+v"(BX[2]), "+v"(BX[3]), "+v"(BX[4]), "+v"(BX[5]), \
-                                  "+v"(BX[6]), "+v"(BX[7]), "+v"(BY[0]), "+v"(BY[1]), "+v"(BY[2]), "+v"(BY[3]), "+v"(BY[4]), "+v"(BY[5]), \
-                                  "+v"(BY[6]), "+v"(BY[7]))
 #define W4S_LANDED() asm volatile("s_waitcnt vmcnt(0)" : "+v"(BX[0]), "+v"(BX[1]), "+v"(BX[2]), "+v"(BX[3]), "+v"(BX[4]), "+v"(BX[5]), \
                                   "+v"(BX[6]), "+v"(BX[7]), "+v"(BY[0]), "+v"(BY[1]), "+v"(BY[2]), "+v"(BY[3]), "+v"(BY[4]), "+v"(BY[5]), \
                                   "+v"(BY[6]), "+v"(BY[7]))
@@ -195,33 +185,17 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4r_kernel(const svr_gemm_
 
     // ---- prologue (once per workgroup): A K tile 0 -> registers -> stage 0; then ONE PERIOD of the steady-state load order (weights
     // of K tile 0, A pieces of K tile 1), so that the counted waits of the first K tile find the sequence they count in
-    if constexpr (ADMA) {
-        // A K tile 0 -> stage 0; then one period of the steady-state order: weights of K tile 0, A K tile 1 -> stage 1
-        W4S_DMA(dmaS, 0); W4S_DMA(dmaS, 1); W4S_DMA(dmaS, 2); W4S_DMA(dmaS, 3); W4S_DMA(dmaS, 4); W4S_DMA(dmaS, 5); W4S_DMA(dmaS, 6); W4S_DMA(dmaS, 7);
-        advance_a();
-        W4_FENCE();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        W4_FENCE();
-        W4R_LDBX(0); W4R_LDBX(1); W4R_LDBX(2); W4R_LDBX(3); W4R_LDBX(4); W4R_LDBX(5); W4R_LDBX(6); W4R_LDBX(7);
-        W4R_LDBY(0); W4S_DMA(dmaS + S1, 0); W4S_DMA(dmaS + S1, 1); W4R_LDBY(1); W4S_DMA(dmaS + S1, 2); W4S_DMA(dmaS + S1, 3);
-        W4R_LDBY(2); W4S_DMA(dmaS + S1, 4); W4S_DMA(dmaS + S1, 5); W4R_LDBY(3); W4S_DMA(dmaS + S1, 6); W4S_DMA(dmaS + S1, 7);
-        W4R_LDBY(4); W4R_LDBY(5); W4R_LDBY(6); W4R_LDBY(7);
-        advance_a();
-    } else {
-    W4R_LDA(0); W4R_LDA(1); W4R_LDA(2); W4R_LDA(3); W4R_LDA(4); W4R_LDA(5); W4R_LDA(6); W4R_LDA(7);
+    // A K tile 0 -> stage 0; then one period of the steady-state order: weights of K tile 0, A K tile 1 -> stage 1
+    W4S_DMA(dmaS, 0); W4S_DMA(dmaS, 1); W4S_DMA(dmaS, 2); W4S_DMA(dmaS, 3); W4S_DMA(dmaS, 4); W4S_DMA(dmaS, 5); W4S_DMA(dmaS, 6); W4S_DMA(dmaS, 7);
     advance_a();
     W4_FENCE();
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sa[4]), "+v"(sa[5]), "+v"(sa[6]), "+v"(sa[7]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     W4_FENCE();
-    w4p_swrite<0 * 4096>(wrA, sa[0]); w4p_swrite<1 * 4096>(wrA, sa[1]); w4p_swrite<2 * 4096>(wrA, sa[2]); w4p_swrite<3 * 4096>(wrA, sa[3]);
-    w4p_swrite<4 * 4096>(wrA, sa[4]); w4p_swrite<5 * 4096>(wrA, sa[5]); w4p_swrite<6 * 4096>(wrA, sa[6]); w4p_swrite<7 * 4096>(wrA, sa[7]);
-    W4_FENCE();
-    W4R_LDBX(0); W4R_LDA(0); W4R_LDBX(1); W4R_LDA(1); W4R_LDBX(2); W4R_LDA(2); W4R_LDA(3); W4R_LDBX(3);
-    W4R_LDA(4); W4R_LDBX(4); W4R_LDA(5); W4R_LDBX(5); W4R_LDA(6); W4R_LDA(7); W4R_LDBX(6); W4R_LDBX(7);
-    W4R_LDBY(0); W4R_LDBY(1); W4R_LDBY(2); W4R_LDBY(3); W4R_LDBY(4); W4R_LDBY(5); W4R_LDBY(6); W4R_LDBY(7);
+    W4R_LDBX(0); W4R_LDBX(1); W4R_LDBX(2); W4R_LDBX(3); W4R_LDBX(4); W4R_LDBX(5); W4R_LDBX(6); W4R_LDBX(7);
+    W4R_LDBY(0); W4S_DMA(dmaS + S1, 0); W4S_DMA(dmaS + S1, 1); W4R_LDBY(1); W4S_DMA(dmaS + S1, 2); W4S_DMA(dmaS + S1, 3);
+    W4R_LDBY(2); W4S_DMA(dmaS + S1, 4); W4S_DMA(dmaS + S1, 5); W4R_LDBY(3); W4S_DMA(dmaS + S1, 6); W4S_DMA(dmaS + S1, 7);
+    W4R_LDBY(4); W4R_LDBY(5); W4R_LDBY(6); W4R_LDBY(7);
     advance_a();
-    wrA += W4P_S1;
-    }
     W4_FENCE();
     w4_wait_lgkm_n<0>();
     __builtin_amdgcn_s_barrier();
@@ -234,40 +208,35 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4r_kernel(const svr_gemm_
     // one slot = one MFMA + at most one LDS store, one LDS read, one A load and one weight load behind it
     auto slot0 = [&](auto sc) {                           // half 0: sets AX, BX
         constexpr int S = decltype(sc)::value, J = S >> 3, I = S & 7;
-        if constexpr (I == 0 && !(DBG & 2)) { w4r_wait_frag<(ADMA ? 23 : w4r_bx_count(J))>(BX[J]); W4_FENCE(); }
+        if constexpr (I == 0 && !(DBG & 2)) { w4r_wait_frag<23>(BX[J]); W4_FENCE(); }
         w4q_mfma(acc[I][J], BX[J], AX[I]);
         W4_FENCE();
         if constexpr (S == 1 && !(DBG & 64)) advance_b(); // the reloads of this K tile fetch the next one's weights
-        constexpr int WQ = (S >= 11 && S <= 53 && (S - 11) % 6 == 0) ? (S - 11) / 6 : -1;
         constexpr int RY = (S >= 10 && S <= 52 && (S - 10) % 6 == 0) ? (S - 10) / 6 : -1;
-        constexpr int LQ = (S >= 12 && S <= 54 && (S - 12) % 6 == 0) ? (S - 12) / 6 : -1;
-        if constexpr (!ADMA && WQ >= 0 && !(DBG & 4) && !(DBG & 16)) { w4p_wait_piece<23>(sa[WQ]); w4p_swrite<WQ * 4096>(wrA, sa[WQ]); }
         if constexpr (RY >= 0 && !(DBG & 8)) w4_rd<RY * 2048>(AY[RY], rdA[1]);
-        if constexpr (!ADMA && LQ >= 0 && !(DBG & 4)) W4R_LDA(LQ);
         if constexpr (I == 7 && !(DBG & 2)) W4R_LDBX(J);
         W4_FENCE();
     };
     auto slot1 = [&](auto sc) {                           // half 1: sets AY, BY
         constexpr int S = decltype(sc)::value, J = S >> 3, I = S & 7;
         if constexpr (S == BAR_SLOT) {                    // THE barrier of the K tile
-            if constexpr (ADMA && !(DBG & 4)) w4_wait_vmcnt<12>();    // this wave's pieces of the next K tile are in LDS
+            if constexpr (!(DBG & 4)) w4_wait_vmcnt<12>();    // this wave's pieces of the next K tile are in LDS
             w4_wait_lgkm_n<0>();
             if constexpr (!(DBG & 1)) __builtin_amdgcn_s_barrier();
             W4_FENCE();
             rdA[0] += st ? (unsigned)-S1 : (unsigned)S1;              // the AX reads below come from the other stage
             W4_FENCE();
         }
-        if constexpr (I == 0 && !(DBG & 2)) { w4r_wait_frag<(ADMA ? w4s_by_count(J) : 23)>(BY[J]); W4_FENCE(); }
+        if constexpr (I == 0 && !(DBG & 2)) { w4r_wait_frag<w4s_by_count(J)>(BY[J]); W4_FENCE(); }
         w4q_mfma(acc[I][J], BY[J], AY[I]);
         W4_FENCE();
-        constexpr int RX = ADMA ? ((S >= 10 && S <= 38 && (S - 10) % 4 == 0) ? (S - 10) / 4 : -1)
-                                : ((S >= 10 && S <= 52 && (S - 10) % 6 == 0) ? (S - 10) / 6 : -1);
-        constexpr int DQ = (ADMA && S >= 8 && S <= 36 && (S - 8) % 4 == 0) ? (S - 8) / 4 : -1;      // piece of K tile f + 2 -> the stage just freed
+        constexpr int RX = (S >= 10 && S <= 38 && (S - 10) % 4 == 0) ? (S - 10) / 4 : -1;
+        constexpr int DQ = (S >= 8 && S <= 36 && (S - 8) % 4 == 0) ? (S - 8) / 4 : -1;      // piece of K tile f + 2 -> the stage just freed
         if constexpr (RX >= 0 && !(DBG & 8)) w4_rd<RX * 2048>(AX[RX], rdA[0]);
         if constexpr (DQ >= 0 && !(DBG & 4)) W4S_DMA(dmaS, DQ);
         if constexpr (S == 54) {
             const unsigned d = st ? (unsigned)-S1 : (unsigned)S1;
-            rdA[1] += d; wrA -= d; dmaS += d;
+            rdA[1] += d; dmaS += d;
             st ^= 1;
         }
         if constexpr (S == 58 && !(DBG & 32)) advance_a();
@@ -292,13 +261,13 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4r_kernel(const svr_gemm_
             W4R_64(slot1);
         }
         W4_FENCE();
-        if constexpr (ADMA) W4S_LANDED(); else W4R_LANDED();
+        W4S_LANDED();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
         {
             int lane_e;                                   // (rebuilt here, by an asm hipcc cannot hoist: no register kept for it across the K loop)
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
             const int wave_e = wave, tid_e = wave * 64 + lane_e;
-            char* const park = ADMA ? smem + 65536 : smem + (st ? 0 : W4_STAGE);
+            char* const park = smem + 65536;
             if (a.epilogue == SVR_EPI_SWIGLU && !a.out_f32)
                 epilogue_swiglu_bf16_m16<W4_THREADS, W4P_EPI>(a, acc, park, m0, n0, tid_e, lane_e, wave_e);
             else
@@ -315,12 +284,10 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4r_kernel(const svr_gemm_
     }
 #undef W4_FENCE
 #undef W4R_C
-#undef W4R_LDA
 #undef W4S_DMA
 #undef W4S_LANDED
 #undef W4R_LDBX
 #undef W4R_LDBY
-#undef W4R_LANDED
 #undef W4R_READ_X_ALL
 #undef W4R_8
 #undef W4R_64

@@ -256,8 +256,7 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * "gemm_w4" 1 (default) plain GEMMs with N % 256 == 0 and >= 256 tiles on the persistent four-wave kernel (256 accumulators per
  * wave, the vendor library's tile shape and MFMA) | 0 on the eight-wave kernel like everything else,
  * "gemm_w4r" 1 (default) the persistent kernel streams the weights of a launch that carries W_frag from that copy into registers and
- * brings the activations into LDS by LDS-DMA | 2 the same with the activations staged through registers | 0 it stages both operands
- * through LDS whether W_frag is given or not,
+ * brings the activations into LDS by LDS-DMA | 0 it stages both operands through LDS whether W_frag is given or not,
  * "gemm_epi" epilogue of the GEMM kernel: 0 auto | 1 stores straight from the accumulators | 2 through LDS wherever possible,
  * "attn_impl" 0 auto (second-generation window kernel for head_dim 128 / windows <= 2048 rows) | 1 first kernel everywhere,
  * "attn_variant" build variant of the second-generation window kernel (0 default = 8 waves x 32 queries; 1 / 3 / 4: 4-wave and

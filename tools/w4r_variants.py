@@ -2,7 +2,6 @@
 """A/B of the persistent GEMM kernels on the NaDiT's four shapes, every variant checked bit for bit against gemm_w4q_kernel first:
     gemm_w4r = 0  both operands through LDS (gemm_w4q_kernel, round 3)
     gemm_w4r = 1  gemm_w4r_kernel: weights straight into registers, activations into LDS by LDS-DMA (default)
-    gemm_w4r = 2  gemm_w4r_kernel with the activations staged through registers + ds_write_b128
   plus, with the measurement build (SVR_BUILD_ABLATIONS=1), svr_set_option("pipe_abl", v) variants given as --abl v,v,...
   python tools/w4r_variants.py [--reps 5] [--abl 701,702]"""
 import argparse, importlib, json, math, os, sys
@@ -31,7 +30,7 @@ def main():
     ops = ops_mod.HipOps("cuda:0")
     g = torch.Generator(device="cuda").manual_seed(0)
     M = args.M
-    variants = [("w4q (gemm_w4r=0)", 0, 0), ("gemm_w4r=1", 1, 0), ("gemm_w4r=2", 2, 0)]
+    variants = [("w4q (gemm_w4r=0)", 0, 0), ("gemm_w4r=1", 1, 0)]
     variants += [(f"gemm_w4r=1 pipe_abl={v}", 1, int(v)) for v in filter(None, args.abl.split(","))]
     for name, N, K, epi, f32 in (("qkv 2560->7680", 7680, 2560, ops_mod.EPI_BIAS, False),
                                  ("attn-out 2560->2560 (+gate, fp32 stream in place)", 2560, 2560, ops_mod.EPI_RESID_GATE, True),
