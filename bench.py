@@ -245,6 +245,8 @@ def main():
                          "h16 / fp32 (48.2 instead of 50 dB end to end against the fp32 reference at production width)")
     ap.add_argument("--trunk", choices=["h16", "fp32", "bf16"], default=None,
                     help="A/B: storage of the VAE's residual trunk (VideoVAEEngine(trunk_store=...)); default: the engine's (h16; round 3: fp32)")
+    ap.add_argument("--stream", choices=["h16", "fp32", "bf16"], default=None,
+                    help="A/B: storage of the NaDiT's residual stream (NaDiTEngine(hid_store=...)); default: the engine's")
     ap.add_argument("--tile-streams", type=int, default=None,
                     help="A/B: HIP streams the VAE's spatial tiles are issued on (VideoVAEEngine(tile_streams=...); default: the "
                          "engine's, 1 = every launch on one stream)")
@@ -289,7 +291,8 @@ def main():
         else:
             frames, H, W = min(frames, 5), min(H, 32), min(W, 48)
     # random-init weights of the exact architecture, generated on the GPU (no checkpoints available offline)
-    dit = sub("dit").NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, device=device), ops, hid_fp32=not args.bf16_trunk)
+    dit = sub("dit").NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, device=device), ops,
+                                 hid_store="bf16" if args.bf16_trunk else args.stream)
     vae = sub("vae").VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, device=device), ops,
                                     merge_upsamplers=not args.two_step_upsampler, merge_causal_head=not args.three_tap_head,
                                     trunk_store="bf16" if args.bf16_trunk else args.trunk, branch_store=args.branch,
@@ -481,7 +484,7 @@ def main():
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "storage": f"bf16 activations (every MFMA operand); VAE residual trunk {vae.trunk_store}, conv1 outputs {vae.branch_store} "
-                       f"(h16 = IEEE half of x * 2^-6); DiT residual stream {'bf16' if args.bf16_trunk else 'fp32'}",
+                       f"(h16 = IEEE half of x * 2^-6); DiT residual stream {dit.hid_store}",
             "config": {"workload": f"{args.workload}: {desc}",
                        "frames_per_step_per_gpu": useful if not sharded else f"{frames} per clip, 8 batches of 17 shared by the ranks",
                        "pixels": [H, W], "latent": [Tl, hl, wl] if not sharded else [(CFG4["batch_size"] - 1) // 4 + 1, hl, wl],

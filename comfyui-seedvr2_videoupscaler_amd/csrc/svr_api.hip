@@ -122,12 +122,14 @@ int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps
     if (rows <= 0) return 0;
     if (dim <= 0 || dim % 8 || dim > 64 * 8 * 8) return fail("svr_rmsnorm_mod: dim must be a multiple of 8 and <= 4096");
     if (!x || !y) return fail("svr_rmsnorm_mod: null pointer");
-    if ((unsigned)x_f32 > (unsigned)SVR_STORE_FP32) return fail("svr_rmsnorm_mod: x_f32 must be SVR_STORE_BF16 or SVR_STORE_FP32");
+    if ((unsigned)x_f32 > (unsigned)SVR_STORE_H16) return fail("svr_rmsnorm_mod: x_f32 must be SVR_STORE_BF16 / _FP32 / _H16");
     const unsigned grid = (unsigned)(rows < 4 * 2048 ? blocks_for(rows, 4) : 2048);      // 8 blocks per CU, rows strided
     const int nc = (dim + 511) / 512;
-#define SVR_RMS_LAUNCH(NC) do { if (x_f32) hipLaunchKernelGGL((rmsnorm_mod_kernel<NC, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
+#define SVR_RMS_LAUNCH(NC) do { if (x_f32 == SVR_STORE_FP32) hipLaunchKernelGGL((rmsnorm_mod_kernel<NC, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
                                               x, (bf16_t*)y, rows, dim, eps, w, scale, shift); \
-                           else hipLaunchKernelGGL((rmsnorm_mod_kernel<NC, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
+                           else if (x_f32 == SVR_STORE_H16) hipLaunchKernelGGL((rmsnorm_mod_kernel<NC, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
+                                              x, (bf16_t*)y, rows, dim, eps, w, scale, shift); \
+                           else hipLaunchKernelGGL((rmsnorm_mod_kernel<NC, 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
                                               x, (bf16_t*)y, rows, dim, eps, w, scale, shift); } while (0)
     switch (nc) {
         case 1: SVR_RMS_LAUNCH(1); break; case 2: SVR_RMS_LAUNCH(2); break; case 3: SVR_RMS_LAUNCH(3); break;

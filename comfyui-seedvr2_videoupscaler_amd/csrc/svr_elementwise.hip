@@ -12,62 +12,74 @@ namespace svr {
 // ------------------------------------------------------------------------------------------------
 constexpr int RMS_MAXC = 8;   // 16-byte chunks per lane -> dim <= 4096
 
-// One wave per row, rows strided over the grid so that the per-channel affine (w * scale, shift) is loaded
-// ONCE per wave into registers and reused for all its rows (a per-element reload made the first version
-// load-issue bound at 1.1 TB/s); the next row's chunks are fetched while the current one is reduced.
-template <int NC, bool XF32>  // chunks per lane actually used: ceil(dim / 512); XF32: x is the fp32 residual stream
+// One wave per row, rows strided over the grid.  Round 5 form: the pass is LATENCY-bound, not bandwidth-bound -- with the per-channel
+// affine (w * scale, shift) and two unpacked rows in registers (~200 VGPRs) only two waves per SIMD were resident, each with one row
+// in flight, and the 2-byte inputs (half the bytes in flight per wave) ran SLOWER than fp32 (rocprof, round 5: 291 600 x 2560 from
+// h16 1.06 ms against 0.86 ms from fp32).  Now the affine lives in LDS (written once per workgroup), the rows that are in flight are
+// held PACKED as loaded (16 B per 8 elements of a 2-byte input), and a wave keeps D rows in flight -- 2 for the 2-byte kinds, 1 for
+// fp32, i.e. ~10 KiB per wave either way -- at ~110 registers: four waves per SIMD.
+template <int NC, int KIND>   // NC: 16-byte (2-byte kinds) / 32-byte (fp32) chunks per lane = ceil(dim / 512); KIND: SVR_STORE_* of x
 __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const void* __restrict__ x, bf16_t* __restrict__ y,
                                                           int64_t rows, int dim, float eps,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift) {
+    __shared__ float mul_s[RMS_MAXC * 512], add_s[RMS_MAXC * 512];
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int nchunk = dim >> 3;
-    float mul[NC][8], add[NC][8];
     const bool affine = w || scale || shift;
     if (affine) {
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = lane + 64 * i;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ch = c * 8 + e;
-                float m = 1.f, a = 0.f;
-                if (c < nchunk) {
-                    if (w) m *= w[ch];
-                    if (scale) m *= scale[ch];
-                    if (shift) a = shift[ch];
-                }
-                mul[i][e] = m; add[i][e] = a;
-            }
+        for (int ch = threadIdx.x; ch < dim; ch += 256) {
+            float m = 1.f;
+            if (w) m *= w[ch];
+            if (scale) m *= scale[ch];
+            mul_s[ch] = m;
+            add_s[ch] = shift ? shift[ch] : 0.f;
         }
+        __syncthreads();
     }
-    struct chunk8 { float f[8]; };
-    chunk8 v[NC], nx[NC];
-    auto fetch = [&](int64_t row, chunk8 (&dst)[NC]) {
+    constexpr int D = KIND == 1 ? 1 : 2;                 // rows in flight per wave
+    constexpr int RW = KIND == 1 ? 2 : 1;                // 16-byte registers per chunk as loaded
+    uint4 raw[D][NC * RW];
+    auto fetch = [&](int64_t row, uint4 (&dst)[NC * RW]) {
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = lane + 64 * i;
-            if (c < nchunk) load8<XF32>(x, row * dim + c * 8, dst[i].f);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dst[i].f[e] = 0.f;
+            if (c < nchunk) {
+                if constexpr (KIND == 1) {
+                    const uint4* p = (const uint4*)((const float*)x + row * dim + c * 8);
+                    dst[2 * i] = p[0]; dst[2 * i + 1] = p[1];
+                } else {
+                    dst[i] = *(const uint4*)((const bf16_t*)x + row * dim + c * 8);
+                }
             }
         }
     };
-    if (wave0 < rows) fetch(wave0, nx);
-    for (int64_t row = wave0; row < rows; row += nwaves) {
-#pragma unroll
-        for (int i = 0; i < NC; ++i) v[i] = nx[i];
-        if (row + nwaves < rows) fetch(row + nwaves, nx);
+    auto unpack = [&](const uint4 (&src)[NC * RW], int i, float* f) {
+        if constexpr (KIND == 1) {
+            const uint4 a = src[2 * i], b = src[2 * i + 1];
+            f[0] = __uint_as_float(a.x); f[1] = __uint_as_float(a.y); f[2] = __uint_as_float(a.z); f[3] = __uint_as_float(a.w);
+            f[4] = __uint_as_float(b.x); f[5] = __uint_as_float(b.y); f[6] = __uint_as_float(b.z); f[7] = __uint_as_float(b.w);
+        } else if constexpr (KIND == 2) {
+            unpack8h(src[i], f);
+        } else {
+            unpack8(src[i], f);
+        }
+    };
+    auto one_row = [&](int64_t row, uint4 (&slot)[NC * RW]) {      // consume the row held in `slot`, then refill the slot D rows ahead
+        float v[NC][8];
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
+            if (lane + 64 * i < nchunk) {
+                unpack(slot, i, v[i]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ss += v[i].f[e] * v[i].f[e];
+                for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+            }
         }
+        if (row + D * nwaves < rows) fetch(row + D * nwaves, slot);
         ss = wave_sum(ss);
         const float inv = rsqrtf(ss / (float)dim + eps);
         uint4* yp = (uint4*)(y + row * dim);
@@ -76,14 +88,28 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const void* __restrict
             const int c = lane + 64 * i;
             if (c < nchunk) {
                 float f[8];
+                if (affine) {
+                    const float4 m0 = *(const float4*)(mul_s + c * 8), m1 = *(const float4*)(mul_s + c * 8 + 4);
+                    const float4 a0 = *(const float4*)(add_s + c * 8), a1 = *(const float4*)(add_s + c * 8 + 4);
+                    const float m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+                    const float ad[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    // same operation order as the reference: ((x * inv) * w * scale) + shift  (modulation.py:110)
-                    float t = v[i].f[e] * inv;
-                    f[e] = affine ? t * mul[i][e] + add[i][e] : t;
+                    for (int e = 0; e < 8; ++e) f[e] = (v[i][e] * inv) * m[e] + ad[e];   // ((x * inv) * w * scale) + shift  (modulation.py:110)
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = v[i][e] * inv;
                 }
                 yp[c] = pack8(f);
             }
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (wave0 + d * nwaves < rows) fetch(wave0 + d * nwaves, raw[d]);
+    for (int64_t row = wave0; row < rows; row += D * nwaves) {
+        one_row(row, raw[0]);
+        if constexpr (D > 1) {
+            if (row + nwaves < rows) one_row(row + nwaves, raw[1]);
         }
     }
 }

@@ -667,6 +667,12 @@ SVR_DEVICE void epilogue_through_lds(const svr_gemm_args& a, const ACC& acc, cha
         }
     }
     if (PLAIN_ONLY || (!a.ps.enabled && !a.phase.enabled)) {
+        if constexpr (PLAIN_ONLY) {                      // the persistent kernel's h16 forms: the NaDiT's 2-byte residual stream (round 5)
+            if (a.out_f32 == SVR_STORE_H16) {
+                if (a.epilogue == SVR_EPI_RESID_GATE) { SVR_EPI_CASE(SVR_EPI_RESID_GATE, SVR_STORE_H16, SVR_STORE_H16); return; }
+                SVR_EPI_CASE(SVR_EPI_BIAS, SVR_STORE_H16, 0); return;
+            }
+        }
         const int of = a.out_f32 == SVR_STORE_FP32 ? 1 : 0, rf = (a.epilogue == SVR_EPI_RESID_GATE && a.resid && a.resid_f32 == SVR_STORE_FP32) ? 1 : 0;
         switch (a.epilogue * 4 + of * 2 + rf) {
             case SVR_EPI_BIAS * 4 + 0:       SVR_EPI_CASE(SVR_EPI_BIAS, false, false); return;
@@ -1721,7 +1727,12 @@ static bool gemm_epi_lds(const svr_gemm_args& a) {
 // what gemm_w4q_kernel serves: plain GEMMs with whole 256-column tiles, at least two K tiles, 16-byte aligned rows, the
 // row-contiguous epilogue's alignment, and enough tiles to fill the chip (one workgroup per CU)
 static bool gemm_w4_eligible(const svr_gemm_args& a) {
-    return g_gemm_w4 && !a.conv.enabled && !a.ps.enabled && !a.phase.enabled && a.out_f32 != SVR_STORE_H16 && a.resid_f32 != SVR_STORE_H16 &&
+    // h16 tensors: only the two forms of the NaDiT's 2-byte residual stream have an instance in the persistent kernel's epilogue --
+    // bias -> h16 (patch-in) and gate * (acc + bias) + h16 residual -> h16 (attn-out / mlp-out); anything else takes gemm_kernel
+    const bool rg = a.epilogue == SVR_EPI_RESID_GATE && a.resid != nullptr;
+    const bool h16_any = a.out_f32 == SVR_STORE_H16 || (rg && a.resid_f32 == SVR_STORE_H16);
+    const bool h16_ok = a.out_f32 == SVR_STORE_H16 && ((rg && a.resid_f32 == SVR_STORE_H16) || (a.epilogue == SVR_EPI_BIAS && !a.resid));
+    return g_gemm_w4 && !a.conv.enabled && !a.ps.enabled && !a.phase.enabled && (!h16_any || h16_ok) &&
            (a.N % 256) == 0 && a.K >= 2 * BK &&
            (a.lda % 8) == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0 && ((uintptr_t)a.W_frag % 16) == 0 && gemm_epi_lds_aligned(a) &&
            (int64_t)a.lda * 2 * 255 < ((int64_t)1 << 31) && (int64_t)a.K * 2 * 255 < ((int64_t)1 << 31) &&

@@ -24,6 +24,7 @@ fractional window positions linspace(-1, 1, n) become rows of a per-layer cos/si
 q/k-norm + RoPE kernel serves both families), ``out_norm False`` and a full last block.
 """
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -36,6 +37,7 @@ from .ops import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWI
 from .packing import pack_matrix, pack_swiglu, pack_vec
 
 BF16 = torch.bfloat16
+DEFAULT_HID_STORE = "h16"           # storage of the residual stream unless the caller (or SVR_DIT_STREAM) says otherwise: see NaDiTEngine
 
 
 @dataclass
@@ -62,11 +64,31 @@ def timestep_sinusoid(t: float, dim: int = 256) -> torch.Tensor:
 
 
 class NaDiTEngine:
-    def __init__(self, cfg: DiTConfig, state_dict: Dict[str, torch.Tensor], ops, hid_fp32: bool = True):
-        """``hid_fp32``: the residual stream ``hid`` is stored in fp32 (its only readers are RMSNorm and the gate+residual GEMM
-        epilogues; every MFMA operand stays bf16) -- 64 bf16 roundings of the stream per 32-layer pass disappear."""
+    def __init__(self, cfg: DiTConfig, state_dict: Dict[str, torch.Tensor], ops, hid_fp32: Optional[bool] = None,
+                 hid_store: Optional[str] = None, overflow_guard: bool = True):
+        """``hid_store`` ("fp32" | "h16" | "bf16"): how the residual stream ``hid`` is held.  Its only readers are RMSNorm and the
+        gate + residual GEMM epilogues -- every MFMA operand stays bf16 -- so it can be WIDE without touching the matrix pipe:
+        bf16 costs 64 roundings of the stream per 32-layer pass (49.1 dB end to end at production width, tools/error_budget.py: the
+        most expensive store of the whole chain), fp32 none (rounds 3-4), "h16" (round 5; an IEEE half of x * 2^-6, ops.H16: 11
+        significant bits in two bytes, range +-4.2e6) -0.07 dB against fp32 at half the bytes: the attn-out / mlp-out epilogues
+        read and write 2 instead of 4 B per element and RMSNorm reads 2.  Default on the bf16 backends: "h16" (measured on MI355X at
+        BASELINE config 3, same box: DiT step 1 322 -> 1 289 ms; production-width chain 50.9 dB either way, 36-layer 7B 4.7e-3
+        against 4.4e-3: profiles/r5_dit_stream_ab.txt).
+        ``hid_fp32`` (rounds 3-4 spelling): True -> "fp32", False -> "bf16".
+        ``overflow_guard``: h16 ends at +-4.2e6 where fp32 / bf16 go on; forward() looks at one sum of its result (one host sync per
+        call) and, when it is not finite under an h16 stream although the inputs were, repeats the call with an fp32 stream and warns."""
         self.cfg, self.ops = cfg, ops
-        self.hid_dtype = torch.float32 if hid_fp32 else None        # None: the ops' activation dtype
+        if hid_store is None and hid_fp32 is None:
+            hid_store = os.environ.get("SVR_DIT_STREAM") or DEFAULT_HID_STORE      # (the env var: A/B runs of the parity tests)
+        elif hid_store is None:
+            hid_store = "fp32" if hid_fp32 else "bf16"
+        if hid_store not in ("fp32", "h16", "bf16"):
+            raise ValueError(f"hid_store must be 'fp32', 'h16' or 'bf16', got {hid_store!r}")
+        if getattr(ops, "act_dtype", BF16) != BF16:      # (the exact-arithmetic CPU double keeps everything in its one dtype)
+            hid_store = "fp32" if ops.act_dtype == torch.float32 else hid_store
+        self.hid_store = hid_store
+        self.hid_dtype = {"fp32": torch.float32, "h16": torch.float16, "bf16": None}[hid_store]     # None: the ops' activation dtype
+        self.overflow_guard, self.overflow_reruns = bool(overflow_guard), 0
         dev = ops.device
         self.device = dev
         d, inner = cfg.vid_dim, cfg.heads * cfg.head_dim
@@ -245,6 +267,26 @@ class NaDiTEngine:
         """vid [T, H, W, 33] bf16 (x_t || condition), txt [Lt, txt_in_dim] bf16.
         Returns the model prediction [T, H, W, 16]; with ``x_t`` given returns the one-step Euler
         endpoint x_t - pred instead (fused into the un-patchify kernel)."""
+        out = self._forward(vid, txt, timestep, x_t)
+        if self.hid_store != "h16" or not self.overflow_guard or bool(torch.isfinite(out.sum(dtype=torch.float32))):
+            return out
+        import warnings
+        if not (bool(torch.isfinite(vid.float().sum())) and bool(torch.isfinite(txt.float().sum()))
+                and (x_t is None or bool(torch.isfinite(x_t.float().sum())))):
+            warnings.warn("NaDiTEngine: the input of this call is not finite; its output is returned as computed (not an h16 range "
+                          "problem, no fp32 re-run)", RuntimeWarning, stacklevel=2)
+            return out
+        warnings.warn("NaDiTEngine: non-finite output with an h16 residual stream (an activation beyond +-4.2e6?); repeating the call "
+                      "with an fp32 stream", RuntimeWarning, stacklevel=2)
+        saved = (self.hid_store, self.hid_dtype)
+        self.hid_store, self.hid_dtype = "fp32", torch.float32
+        self.overflow_reruns += 1
+        try:
+            return self._forward(vid, txt, timestep, x_t)
+        finally:
+            self.hid_store, self.hid_dtype = saved
+
+    def _forward(self, vid, txt, timestep, x_t):
         cfg, ops = self.cfg, self.ops
         d, heads, hd = cfg.vid_dim, cfg.heads, cfg.head_dim
         inner = heads * hd
@@ -256,7 +298,7 @@ class NaDiTEngine:
         eps = cfg.norm_eps
 
         hid = ops.empty(R, d, dtype=self.hid_dtype)
-        hf = hid.dtype == torch.float32
+        hf = hid.dtype in (torch.float32, torch.float16)     # a WIDE stream (fp32 or h16): the ops derive the kind from the dtype
         a0 = ops.empty(N, self.kpad_in)
         ops.patchify(vid.contiguous(), a0)
         ops.gemm(a0, self.vid_in.w, hid[:N], N=d, K=self.kpad_in, bias=self.vid_in.b, out_f32=hf)
@@ -344,7 +386,7 @@ class NaDiTEngine:
                 else:
                     ops.gemm(xn[rows], s_["mlp_in"].w, h1[rows], N=2 * hm, K=d, epilogue=EPI_SWIGLU, W_frag=s_["mlp_in"].frag)
                 o = hid[rows] if dst is None else dst
-                ops.gemm(h1[rows], s_["mlp_out"].w, o, N=d, K=hm, bias=s_["mlp_out"].b, out_f32=o.dtype == torch.float32,
+                ops.gemm(h1[rows], s_["mlp_out"].w, o, N=d, K=hm, bias=s_["mlp_out"].b, out_f32=o.dtype in (torch.float32, torch.float16),
                          epilogue=EPI_RESID_GATE, gate=gate, resid=hid[rows], W_frag=s_["mlp_out"].frag)
 
             if shared and not final:

@@ -324,8 +324,8 @@ class HipOps:
     def rmsnorm_mod(self, x, out, eps, w=None, scale=None, shift=None):
         xf = self._xf32(x); self._chk(out, BF16, "out")
         rows, dim = x.shape
-        if xf == STORE_H16 or tuple(out.shape) != (rows, dim):
-            raise ValueError("rmsnorm_mod: x must be bf16 or fp32 [rows, dim] and out bf16 of the same shape")
+        if tuple(out.shape) != (rows, dim):
+            raise ValueError("rmsnorm_mod: x must be bf16, fp32 or h16 [rows, dim] and out bf16 of the same shape")
         hip_lib.check(self.lib.svr_rmsnorm_mod(_ptr(x), _ptr(out), rows, dim, eps, self._opt(w, torch.float32, "w", dim),
                                                self._opt(scale, torch.float32, "scale", dim),
                                                self._opt(shift, torch.float32, "shift", dim), xf,

@@ -168,7 +168,8 @@ int svr_gemm_bf16(const svr_gemm_args* args, void* stream);
 
 /* ---- DiT elementwise / normalisation ------------------------------------------------------- */
 /* y = rms_norm(x) [* w] * scale + shift, per row.  normalization.py:88-109 + modulation.py:110.
- * x bf16 (fp32 if x_f32: the wide residual stream) [rows, dim], y bf16; w (affine weight) / scale / shift fp32 [dim] or NULL. */
+ * x [rows, dim] of storage kind x_f32 (SVR_STORE_BF16 | _FP32 | _H16: the NaDiT's residual stream is wide), y bf16; w (affine
+ * weight) / scale / shift fp32 [dim] or NULL. */
 int svr_rmsnorm_mod(const void* x, void* y, int64_t rows, int32_t dim, float eps,
                     const float* w, const float* scale, const float* shift, int32_t x_f32, void* stream);
 

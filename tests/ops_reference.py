@@ -124,7 +124,7 @@ class TorchOps:
 
     # ------------------------------------------------------------------ DiT side kernels
     def rmsnorm_mod(self, x, out, eps, w=None, scale=None, shift=None):
-        xf = x.float()
+        xf = _ld(x)
         y = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
         if w is not None:
             y = y * w

@@ -304,3 +304,69 @@ def test_vae_engine_storage_regimes_agree_with_their_cpu_emulation(hip):
         assert e_enc < 2e-2, name
     assert vae.VideoVAEEngine(cfg, sd, hip).trunk_store == "h16"           # the default regime
     assert errs["h16/h16"] < errs["bf16/bf16"] and errs["fp32/bf16"] < errs["bf16/bf16"]   # fewer roundings -> less noise
+
+
+# ------------------------------------------------------------------ the NaDiT's 2-byte residual stream (round 5)
+@pytest.mark.parametrize("rows,dim", [(1000, 2560), (58, 2560), (7, 3072)])
+def test_rmsnorm_mod_h16_input(hip, ref, rows, dim):
+    """RMSNorm + modulation reading the stream in h16 (the stored half is x * 2^-6; eps applies to the values the halves stand for)."""
+    xv = rnd(rows, dim, scale=2.0, dtype=F32)
+    x = (xv * H16_SCALE).to(H16)
+    w, sc, sh = (rnd(dim, dtype=F32, seed=s) for s in (1, 2, 3))
+    for kw in (dict(), dict(scale=sc, shift=sh), dict(w=w, scale=sc, shift=sh)):
+        out = torch.empty(rows, dim, device="cuda", dtype=BF16)
+        hip.rmsnorm_mod(x, out, 1e-5, **kw)
+        assert rel_err(out.float(), ref.rmsnorm_mod(x, torch.empty(rows, dim, device="cuda"), 1e-5, **kw)) < TOL_BF16
+        same = torch.empty_like(out)
+        hip.rmsnorm_mod(_ld(x), same, 1e-5, **kw)                 # == the fp32 kernel on the values the halves stand for
+        assert torch.equal(out, same)
+
+
+@pytest.mark.parametrize("M,N,K", [(70000, 2560, 2560), (16300, 4096, 192), (9000, 2560, 6912)])
+def test_gemm_persistent_h16_stream_epilogues(hip, ref, M, N, K):
+    """The persistent GEMM kernel's two h16 forms (the NaDiT's residual stream): bias -> h16 (patch-in) and gate * (acc + bias) + h16
+    residual -> h16 in place (attn-out / mlp-out), with and without the fragment-ordered weights; routed to the persistent kernel,
+    <= 1e-3 like any wide store, bit-identical between the two main loops and from launch to launch."""
+    packing = sub("packing")
+    A = rnd(M, K)
+    W = packing.pack_matrix(rnd(N, K, scale=1.0 / math.sqrt(K), seed=1), "cuda")
+    Wf = hip.pack_gemm_frag(W)
+    bias, gate = rnd(N, dtype=F32, seed=3), rnd(N, dtype=F32, seed=4)
+    hid0 = (rnd(M, N, seed=6, dtype=F32) * 3.0 * H16_SCALE).to(H16)
+    hip.record_kernel_class = True
+    try:
+        out = torch.full((M, N), float("nan"), device="cuda", dtype=H16)
+        hip.gemm(A, W, out, N=N, K=K, bias=bias, out_f32=True, W_frag=Wf)
+        assert hip.last_kernel_class == "gemm_persistent"
+        assert rel_err(_ld(out), ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias)) < TOL_F32
+        want = ref.gemm(A, W, torch.empty(M, N, device="cuda"), N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE, gate=gate, resid=hid0)
+        outs = []
+        for frag in (Wf, None, Wf):
+            hid = hid0.clone()
+            hip.gemm(A, W, hid, N=N, K=K, bias=bias, epilogue=EPI_RESID_GATE, gate=gate, resid=hid, out_f32=True, W_frag=frag)
+            assert hip.last_kernel_class == "gemm_persistent"
+            outs.append(hid)
+        assert rel_err(_ld(outs[0]), want) < TOL_F32
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    finally:
+        hip.record_kernel_class = False
+
+
+def test_dit_engine_h16_stream_matches_its_emulation_and_the_fp32_stream(hip):
+    """NaDiTEngine(hid_store="h16") on the HIP path against the same host code over the torch double of the C ABI in the same regime,
+    and against the fp32-stream engine (the two differ by the h16 roundings of the stream only: ~3e-4 per store)."""
+    config, weights, dit = sub("config"), sub("weights"), sub("dit")
+    cfg = config.DIT_TINY
+    sd = weights.synth_dit_state_dict(cfg, seed=5)
+    g = torch.Generator().manual_seed(1)
+    vid = torch.randn(3, 16, 24, 33, generator=g).to(BF16)
+    txt = weights.synth_text_embedding()
+    outs = {}
+    for store in ("h16", "fp32", "bf16"):
+        eng = dit.NaDiTEngine(cfg, sd, hip, hid_store=store)
+        assert eng.hid_store == store
+        outs[store] = eng.forward(vid.cuda(), txt.cuda(), 1000.0).float().cpu()
+    emu = dit.NaDiTEngine(cfg, sd, TorchOps("cpu", act_dtype=BF16), hid_store="h16").forward(vid, txt, 1000.0).float()
+    e_emu, e_32, e_16 = rel_err(outs["h16"], emu), rel_err(outs["h16"], outs["fp32"]), rel_err(outs["bf16"], outs["fp32"])
+    print(f"DiT(tiny) h16 stream: vs its CPU emulation {e_emu:.3e}, vs the fp32 stream {e_32:.3e} (bf16 stream vs fp32: {e_16:.3e})")
+    assert e_emu < 8e-3 and e_32 < e_16 and e_32 < 5e-3

@@ -107,3 +107,30 @@ def test_oracle_ref_recipe_compiles_the_reference_without_copying_source(tmp_pat
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SEEDVR2_REFERENCE_ROOT=out), capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and r.stdout.split() == ["NaDiT", "True"], r.stderr[-2000:]
+
+
+def test_dit_engine_h16_stream_overflow_guard():
+    """The NaDiT's residual stream in h16 (round 5) ends at +-4.2e6: an engine whose patch-in projection is scaled beyond that gets
+    inf in the stream -> NaN out; forward() notices, repeats the call with an fp32 stream (same answer as an fp32-stream engine),
+    warns once and keeps h16 for the next call.  A non-finite INPUT is not blamed on h16."""
+    config, weights, dit = sub("config"), sub("weights"), sub("dit")
+    cfg = config.DIT_TINY
+    sd = dict(weights.synth_dit_state_dict(cfg, seed=3))
+    sd["vid_in.proj.weight"] = sd["vid_in.proj.weight"] * 3.0e8
+    g = torch.Generator().manual_seed(2)
+    vid = torch.randn(1, 8, 12, 33, generator=g).to(BF16)
+    txt = weights.synth_text_embedding()
+    wide = dit.NaDiTEngine(cfg, sd, TorchOps("cpu", act_dtype=BF16), hid_store="fp32").forward(vid, txt, 1000.0)
+    assert torch.isfinite(wide.float()).all()
+    eng = dit.NaDiTEngine(cfg, sd, TorchOps("cpu", act_dtype=BF16))
+    assert eng.hid_store == "h16"                                     # the default on a bf16 backend
+    with pytest.warns(RuntimeWarning, match="h16 residual stream"):
+        got = eng.forward(vid, txt, 1000.0)
+    assert torch.equal(got, wide) and eng.overflow_reruns == 1 and eng.hid_store == "h16" and eng.hid_dtype == H16
+    bad = vid.clone()
+    bad[0, 0, 0, 0] = float("nan")
+    with pytest.warns(RuntimeWarning, match="input of this call is not finite"):
+        out = eng.forward(bad, txt, 1000.0)
+    assert eng.overflow_reruns == 1 and not torch.isfinite(out.float()).all()
+    # the exact-arithmetic CPU double keeps its one dtype whatever is asked for
+    assert dit.NaDiTEngine(cfg, sd, TorchOps("cpu", act_dtype=torch.float32), hid_store="h16").hid_store == "fp32"
