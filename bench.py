@@ -203,8 +203,19 @@ def cpu_baseline(flops_per_frame: float) -> dict:
     tflops = (f_vae + f_dit) / (t_vae + t_dit) / 1e12
     what = (f"the reference's own model classes ({rl.kind()}: {'oracle/_ref, byte-compiled by oracle/build_ref.py' if rl.kind() == 'compiled' else rl.REFERENCE_ROOT}), fp32, PyTorch-SDPA path"
             if use_ref else "oracle/*.py (in-repo port of the reference's PyTorch path), fp32")
+    # BASELINE config 1 IN FULL (the reference's 32-layer NaDiT-3B + VAE on one 256 x 256 image): tools/cpu_cfg1_full.py, run once per
+    # round on a GPU box's host and committed -- building 3.4e9 random fp32 parameters takes longer than this whole measurement
+    cfg1_full = None
+    for name in ("r5_cpu_cfg1_full.json",):
+        try:
+            one = json.load(open(os.path.join(ROOT, "profiles", name)))
+            cfg1_full = {"frames_per_s_cfg1": one["frames_per_s_cfg1"], "cpu_tflops": one["cpu_tflops"], "cores": one["cores"],
+                         "seconds": one["seconds"], "source": f"profiles/{name} (tools/cpu_cfg1_full.py on a GPU box's host; NOT timed in this run)"}
+            break
+        except (OSError, KeyError, ValueError):
+            continue
     return {"value": tflops * 1e12 / flops_per_frame, "unit": "frames/s", "cores": cores, "kind": "reference" if use_ref else "port",
-            "cpu_tflops": tflops, "timing": "1 warm-up + median of 3 per leg",
+            "cpu_tflops": tflops, "timing": "1 warm-up + median of 3 per leg", "cfg1_full": cfg1_full,
             "sample": f"{what}: full VAE enc+dec of a 5x96x96 clip ({t_vae:.2f}s) + 2-layer (regular + shifted windows) "
                       f"3B-width DiT on a 3x48x48 latent ({t_dit:.2f}s); extrapolated to the workload by algorithmic FLOPs"}
 

@@ -18,7 +18,7 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def _run(args, env_extra=None, timeout=900):
-    env = dict(os.environ, SVR_BENCH_ALLOW_CPU_DOUBLE="1", OMP_NUM_THREADS="8", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    env = dict(os.environ, SVR_BENCH_ALLOW_CPU_DOUBLE="1", OMP_NUM_THREADS="2", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     env.update(env_extra or {})
     return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)

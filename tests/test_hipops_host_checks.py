@@ -52,9 +52,12 @@ def recorded():
     torch.manual_seed(0)
     # NaDiT (reduced width; MM + shared blocks, regular + shifted windows), then the VAE engine: untiled and tiled, both directions
     cfg = config.DIT_TINY
-    eng = sub("dit").NaDiTEngine(cfg, weights.synth_dit_state_dict(cfg), ops)
+    eng = sub("dit").NaDiTEngine(cfg, weights.synth_dit_state_dict(cfg), ops, overflow_guard=False)    # (outputs are uninitialised memory here)
     vid = torch.randn(3, 16, 24, 33).to(torch.bfloat16)
     eng.forward(vid, weights.synth_text_embedding(), 1000.0, x_t=vid[..., :16].contiguous())
+    for store in ("fp32", "bf16"):                        # the other storage kinds of the residual stream (default: h16)
+        sub("dit").NaDiTEngine(cfg, weights.synth_dit_state_dict(cfg), ops, hid_store=store, overflow_guard=False).forward(
+            vid, weights.synth_text_embedding(), 1000.0)
     n_dit = len(lib.calls)
     vcfg = config.VAE_V3
     veng = sub("vae").VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg), ops, overflow_guard=False)    # (outputs are uninitialised memory here)
@@ -76,7 +79,7 @@ def recorded():
         l2 = v2.encode(x)
         v2.decode(torch.randn_like(l2.float()).to(l2.dtype))
     cfg7 = config.DIT_7B_TINY
-    eng7 = sub("dit").NaDiTEngine(cfg7, weights.synth_dit_state_dict(cfg7), ops)
+    eng7 = sub("dit").NaDiTEngine(cfg7, weights.synth_dit_state_dict(cfg7), ops, overflow_guard=False)
     eng7.forward(vid, weights.synth_text_embedding(), 1000.0, x_t=vid[..., :16].contiguous())
     return lib.calls, n_dit
 
@@ -119,7 +122,7 @@ def recorded_routed():
     veng.decode(torch.randn_like(lat.float()).to(lat.dtype), latents_per_slice=1, keep_frames=7)
     veng.decode(torch.randn_like(lat.float()).to(lat.dtype), tiled=True, tile_size=(32, 48), tile_overlap=(8, 8))
     cfg = config.DIT_TINY
-    eng = sub("dit").NaDiTEngine(cfg, weights.synth_dit_state_dict(cfg), ops)
+    eng = sub("dit").NaDiTEngine(cfg, weights.synth_dit_state_dict(cfg), ops, overflow_guard=False)
     vid = torch.randn(3, 16, 24, 33).to(torch.bfloat16)
     eng.forward(vid, weights.synth_text_embedding(), 1000.0, x_t=vid[..., :16].contiguous())
     return lib.calls
@@ -156,7 +159,7 @@ def test_recorded_calls_satisfy_the_librarys_own_host_rules(recorded):
     for name, a in calls:
         if name == "svr_rmsnorm_mod":
             rows, dim, x_f32 = a[2], a[3], a[8]
-            assert rows > 0 and dim % 8 == 0 and 0 < dim <= 4096 and x_f32 in (0, 1), a
+            assert rows > 0 and dim % 8 == 0 and 0 < dim <= 4096 and x_f32 in (0, 1, 2), a
         elif name == "svr_groupnorm_apply":
             T, HW, Cc, groups, x_f32 = a[5], a[6], a[7], a[8], a[11]
             assert T > 0 and HW > 0 and Cc % 8 == 0 and Cc <= 512 and groups > 0 and Cc % groups == 0 and x_f32 in (0, 1, 2), a
@@ -188,7 +191,12 @@ def test_hipops_rejects_bad_side_operands():
     with pytest.raises(ValueError, match="shift"):
         ops.rmsnorm_mod(x, out, 1e-6, shift=torch.zeros(32))                             # wrong length
     with pytest.raises(ValueError, match="rmsnorm_mod"):
-        ops.rmsnorm_mod(x.to(torch.float16), out, 1e-6)                                  # h16 is not a stream format
+        ops.rmsnorm_mod(x.to(torch.float16), out[:2], 1e-6)                              # (h16 is a stream format since round 5; shapes must agree)
+    with pytest.raises(ValueError, match="activation storage"):
+        ops.rmsnorm_mod(x.to(torch.float64), out, 1e-6)
+    with pytest.raises(ValueError, match="q / k norm weights"):
+        ops.qknorm_rope(torch.zeros(4, 3 * 2 * 128, dtype=bf), 2, torch.zeros(4, 3, dtype=torch.int16), 0, torch.zeros(8, 21), torch.zeros(8, 21),
+                        None, torch.zeros(128), 1e-6)
     g = torch.zeros(2, 4, 4, 128, dtype=bf)
     with pytest.raises(ValueError, match="gamma"):
         ops.groupnorm_apply(g, torch.zeros_like(g), torch.zeros(2, 32, 2, dtype=torch.float64), torch.zeros(64), torch.zeros(128), 32, 1e-6, True)
