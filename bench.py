@@ -144,6 +144,25 @@ def make_profiled_ops(device):
     return ProfiledOps(device)
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: the scheduler affinity mask capped by the cgroup CPU quota (a GPU box reports 256 logical
+    CPUs and hands the container a quota of 16: 128 torch threads on 16 cores run the reference ~3x SLOWER than 16 threads do)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(flops_per_frame: float) -> dict:
     """The reference's CPU path timed on this host's cores on a bounded sample of the same pipeline: 1 warm-up + median of 3
     per leg, converted to the metric's unit through the algorithmic FLOP ratio (labelled extrapolation).
@@ -154,6 +173,7 @@ def cpu_baseline(flops_per_frame: float) -> dict:
     as a reported baseline."""
     from oracle import dit_oracle, vae_oracle, reference_loader as rl
     config, weights, windows, flops = sub("config"), sub("weights"), sub("windows"), sub("flops")
+    torch.set_num_threads(min(torch.get_num_threads(), usable_cores()))     # (never more threads than cores the container may use)
     cores = torch.get_num_threads()
     vcfg = config.VAE_V3
     vsd = {k: v.float() for k, v in weights.synth_vae_state_dict(vcfg).items()}

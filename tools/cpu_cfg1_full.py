@@ -36,13 +36,22 @@ def main():
     from oracle import reference_loader as rl
     assert rl.available(), "needs the reference checkout or oracle/_ref"
     config, weights, flops = sub("config"), sub("weights"), sub("flops")
-    torch.set_num_threads(os.cpu_count())
+    # (torch's default thread count = what bench.py's cpu_baseline uses; on a box whose cgroup grants fewer cores than os.cpu_count()
+    # reports, forcing cpu_count() threads oversubscribes and the run never finishes)
+    def note(msg):
+        print(f"[cpu_cfg1_full +{time.perf_counter() - t00:6.1f}s] {msg}", file=sys.stderr, flush=True)
+    t00 = time.perf_counter()
+    import bench
+    torch.set_num_threads(min(torch.get_num_threads(), bench.usable_cores()))   # (the cgroup quota, not the 256 logical CPUs the box reports)
+    note(f"threads {torch.get_num_threads()}, usable cores {bench.usable_cores()}, os.cpu_count {os.cpu_count()}")
     g = torch.Generator().manual_seed(42)
     t_build = time.perf_counter()
     dcfg, vcfg = config.DIT_3B, config.VAE_V3
     dsd = {k: v.float() for k, v in weights.synth_dit_state_dict(dcfg).items()}
+    note("3B weights drawn")
     ref_dit = rl.build_reference_dit(dcfg.as_dict(), dsd)
     del dsd
+    note("reference NaDiT built")
     vsd = {k: v.float() for k, v in weights.synth_vae_state_dict(vcfg).items()}
     ref_vae = rl.build_reference_vae(vsd)
     t_build = time.perf_counter() - t_build
@@ -64,14 +73,17 @@ def main():
             ref_dit(vid=vid.reshape(-1, 33), txt=txt, vid_shape=torch.tensor([[1, 32, 32]]), txt_shape=torch.tensor([[txt.shape[0]]]),
                     timestep=torch.tensor([1000.0]))
 
-    t_enc, t_dit, t_dec = median3(enc), median3(dit), median3(dec)
+    note("models built")
+    t_enc = median3(enc); note(f"encode {t_enc:.2f}s")
+    t_dit = median3(dit); note(f"dit {t_dit:.2f}s")
+    t_dec = median3(dec); note(f"decode {t_dec:.2f}s")
     fv = flops.vae_flops_tiled(vcfg, 1, 256, 256, False)
     fd = flops.dit_flops(dcfg, (1, 16, 16))["total"]
     total = t_enc + t_dit + t_dec
     f_cfg3 = flops.dit_flops(dcfg, (9, 135, 240))["total"] + sum(flops.vae_flops_tiled(vcfg, 33, 2160, 3840, True).values())
     res = {"what": "BASELINE config 1 in full on the host CPU: the reference's own NaDiT-3B (32 layers, SDPA path, fp32) + video VAE v3 "
                    f"({rl.kind()}: {rl.REFERENCE_ROOT if rl.kind() == 'source' else 'oracle/_ref'}), one 256 x 256 image",
-           "cores": os.cpu_count(), "torch_threads": torch.get_num_threads(), "timing": "1 warm-up + median of 3 per leg",
+           "cores": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "timing": "1 warm-up + median of 3 per leg",
            "seconds": {"vae_encode": t_enc, "dit_32_layers": t_dit, "vae_decode": t_dec, "total": total, "model_build": t_build},
            "algorithmic_tflop": {"vae_encode": fv["encode"] / 1e12, "dit": fd / 1e12, "vae_decode": fv["decode"] / 1e12},
            "cpu_tflops": (fv["encode"] + fv["decode"] + fd) / total / 1e12,
