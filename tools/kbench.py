@@ -261,11 +261,7 @@ def main():
             t_seq, t_out, t_cu = (torch.from_numpy(v).to(dev) for v in (seq, outr, cu))
             fl = sum(4.0 * heads * 128 * float(l + Lt) ** 2 for l in lens)
             for impl, variant, tag in ((0, 0, "gen2 8 waves (default)"), (0, 1, "gen2 4 waves + setprio"), (0, 4, "gen2 4 waves"),
-                                       (0, 3, "gen2 8 waves + setprio"), (0, 5, "gen2 4 waves x 64 queries"),
-                                       (0, 6, "gen2 4 waves x 64 queries + hints"), (0, 7, "gen2 4 x 64, K Q^T one tile ahead"),
-                                       (0, 8, "gen2 4 x 64, K Q^T one tile ahead + hints"),
-                                       (0, 9, "gen2 8 waves, waves 0..3 favoured"), (0, 10, "gen2 8 waves, even waves favoured"),
-                                       (1, 0, "gen1 svr_attn")):
+                                       (0, 3, "gen2 8 waves + setprio"), (1, 0, "gen1 svr_attn")):
                 if variant and args.attn_default_only:
                     continue
                 ops.set_option("attn_impl", impl)

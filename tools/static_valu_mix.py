@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Static VALU issue-cycle mix of a kernel region, from the device assembly hipcc emits (no GPU needed).
 
-    python tools/static_valu_mix.py conv_halo2_kernelILi16ELi3ELi0 [--region epilogue|prologue|all] [-D SVR_EP_ADDR=1 ...] [--asm file.s]
+    python tools/static_valu_mix.py conv_halo2_kernelILi16ELi3ELi0 [--region epilogue|prologue|all] [-D SOME_EXPERIMENT=1 ...] [--asm file.s]
 
 Region ``epilogue`` = everything after the kernel's last MFMA, ``prologue`` = everything before its first (kernels without MFMAs: use
 ``all``).  Every VALU instruction is priced at its issue cost for a wave64 on a 16-lane SIMD: 4 cycles, 16 for the quarter-rate ones --

@@ -2,7 +2,7 @@
 //   usage: gn_ab [reps] [case ...] [key=value ...]     (key=value: svr_set_option before the runs)     cases (h16 trunk input -> bf16 output, 32 groups, as a VAE tile issues them):
 //     gn128  5 x 1024^2 x 128 (default)    gn256  5 x 512^2 x 256    gn512  5 x 256^2 x 512    gn128b  the same tensor as bf16 input
 // Each case runs with SiLU and without; prints microseconds, TB/s over the algorithmic bytes (2 B read + 2 B written per element) and a
-// 64-bit checksum of the output -- an experiment library (tools/ubench/build_variant.sh -DSVR_GN_PACKED=1 -> gn_ab_x) must print the same.
+// 64-bit checksum of the output -- an experiment library (tools/ubench/build_variant.sh -D... -> gn_ab_x) must print the same.
 // build: tools/ubench/build_ubench.sh   (measurement aid, not part of the product)
 #include <hip/hip_runtime.h>
 #include <cstdint>
