@@ -351,6 +351,13 @@ class VideoVAEEngine:
             ops.im2col_causal(x, cols, geom)
             ops.gemm(cols, cw.w, out, N=cw.cout, K=K, M=To * Ho * Wo, bias=cw.b, epilogue=epi, resid=resid,
                      lda=K, ldc=cw.cout, ldr=cw.cout, out_f32=f32)
+        elif tuple(cw.k) == (1, 1, 1) and tuple(cw.stride) == (1, 1, 1) and cw.pad_lo == 0 and not gn and K == Cin:
+            # a 1x1x1 conv (the ResnetBlock3D shortcuts, attn_video_vae.py:299-308) IS a plain GEMM over the NDHWC rows: no tap gather,
+            # and the forms with N % 256 == 0 reach the persistent kernel (round 5, same box: -23 ms per config-3 step against the
+            # implicit-GEMM route; these launches are HBM-bound either way)
+            M_ = To * Ho * Wo
+            ops.gemm(x.reshape(M_, Cin), cw.w, out.reshape(M_, cw.cout), N=cw.cout, K=K, M=M_, bias=cw.b, epilogue=epi,
+                     resid=None if resid is None else resid.reshape(M_, cw.cout), out_f32=f32)
         else:
             # implicit-GEMM conv; RGB input (encoder conv_in, Cin 3 -> 4) is served by the thin-input variant of the
             # LDS-halo kernel, which builds the im2col image of each patch in LDS

@@ -9,8 +9,8 @@ most 9 x 30 x 54 tokens, 5 x 1024 x 1152 px) cannot see a 32-bit index slip.
         slip confined to one window cannot hide in the average) and per row.  The qkv tensor of this run holds 2.24e9 elements.
         Reference path: src/models/dit_3b/nablocks/attention/mmattn.py:161-271, mmsr_block.py:108-126, na.py:320-424.
   (ii)  The decoder's full-resolution level on a 33 x 1024 x 1024 tile (8.9 GB per 128-channel tensor, 17.7 GB at 256): both kinds of
-        ResnetBlock3D (256 -> 128 with its 1x1x1 shortcut, 128 -> 128), conv_norm_out and conv_out run through the engine's own
-        layer code over HipOps; EVERY conv launch and GroupNorm pass it issued is then re-computed in fp32 (F.conv3d / the GroupNorm
+        ResnetBlock3D (256 -> 128 with its 1x1x1 shortcut -- a plain GEMM over 34.6 M rows --, 128 -> 128), conv_norm_out and conv_out
+        run through the engine's own layer code over HipOps; EVERY conv / GEMM launch and GroupNorm pass it issued is then re-computed in fp32 (F.conv3d / the GroupNorm
         formula) on crops of the launch's own input with halo -- the four corners of the first and of the last frame, the last rows
         and columns, crops behind byte offset 2^32 and element offset 2^32 -- and every set of fused GroupNorm statistics against an
         fp64 reduction of the full stored tensor.  Reference path: causal_inflation_lib.py:213-305, 354-409, attn_video_vae.py:255-362.
@@ -110,12 +110,14 @@ def _recording_ops(hip_cls, dev):
     class RecordingOps(hip_cls):
         def __init__(self, device):
             super().__init__(device)
-            self.convs, self.norms = [], []
+            self.convs, self.norms, self.gemms = [], [], []
 
         def gemm(self, A, W, out, **kw):
             r = super().gemm(A, W, out, **kw)
             if kw.get("conv") is not None:
                 self.convs.append(dict(A=A, W=W, out=out, kw=kw, stats=r[1] if isinstance(r, tuple) else None))
+            else:
+                self.gemms.append(dict(A=A, W=W, out=out, kw=kw))
             return r
 
         def groupnorm_apply(self, x, out, stats, gamma, beta, groups, eps, silu):
@@ -221,8 +223,19 @@ def test_decoder_full_resolution_level_on_a_33_frame_1024px_tile(hip):
                 assert torch.allclose(r["stats"][f], want, rtol=2e-6, atol=1e-3), (name, f)
     for name, e in sorted(worst.items()):
         print(f"{name}: worst crop rel-err {e:.3e}")
-    # (conv1 / conv2 of both blocks and conv_out as a causal-head + body launch pair, the 1x1x1 shortcut as one launch)
-    assert len(rec.convs) == 2 * 2 + 1 + 2 * 2 + 2 and len(kinds) >= 5
+    # (conv1 / conv2 of both blocks and conv_out as a causal-head + body launch pair; the 1x1x1 shortcut is a plain GEMM over the rows)
+    assert len(rec.convs) == 2 * 2 + 2 * 2 + 2 and len(kinds) >= 4 and len(rec.gemms) == 1
+    for r in rec.gemms:                                     # the shortcut: [34.6 M rows, 256] @ [256, 128]^T + bias -> h16, row blocks up to the last row
+        kw = r["kw"]
+        M_, N_, K_ = kw["M"], kw["N"], kw["K"]
+        A2, O2 = r["A"].reshape(M_, -1), r["out"].reshape(M_, -1)
+        assert M_ == T * S * S and M_ * K_ * 2 > 2 ** 32
+        for a0 in (0, 12345 * 7, M_ // 2 + 3, (2 ** 32) // (K_ * 2) - 100, (2 ** 32) // N_ + 1000, M_ - 5000):
+            a1 = min(a0 + 5000, M_)
+            want = A2[a0:a1, :K_].float() @ r["W"][:N_, :K_].float().t() + kw["bias"][:N_].float()
+            e = rel_err(_ld(O2[a0:a1, :N_]), want)
+            assert e < TOL_WIDE, ("shortcut GEMM", a0, e)
+        print(f"1x1x1 shortcut as a plain GEMM [{M_}, {K_}] x [{N_}, {K_}]^T -> {str(O2.dtype).split('.')[-1]}: row blocks up to the last row <= {TOL_WIDE}")
     for n_, r in enumerate(rec.norms):
         xs, out = r["x"], r["out"]
         Tn, Hn, Wn, Cn = xs.shape
