@@ -63,6 +63,7 @@ static const Case CASES[] = {
     {"sp256", 5, 512, 512, 256, 256, 3, 2, 2, 1, 1, 1, 2, 1, 1, false, 1},
     {"sp512", 5, 256, 256, 512, 512, 2, 2, 2, 1, 1, 1, 1, 1, 1, false, 2},
     {"cin", 5, 1024, 1024, 4, 128, 3, 3, 3, 1, 1, 1, 2, 1, 1, false, 0, true},      // encoder.conv_in: RGB padded to 4 channels, K padded to 128
+    {"cout", 9, 1024, 1024, 128, 3, 3, 3, 3, 1, 1, 1, 2, 1, 1, false},              // decoder.conv_out: 128 -> 3 at full resolution (conv_thinout16_kernel), bf16 out
 };
 
 static int apply_options(const std::string& set) {
@@ -116,7 +117,7 @@ int main(int argc, char** argv) {
         svr_gemm_args a;
         memset(&a, 0, sizeof(a));
         a.A = x; a.W = w; a.C = out; a.ldc = N; a.M = To * Ho * Wo; a.N = N; a.K = K; a.bias = bias;
-        a.epilogue = SVR_EPI_BIAS; a.out_f32 = SVR_STORE_H16;
+        a.epilogue = SVR_EPI_BIAS; a.out_f32 = N < 32 ? SVR_STORE_BF16 : SVR_STORE_H16;
         a.conv.enabled = 1;
         a.conv.T = c->T; a.conv.H = c->H; a.conv.W = c->W; a.conv.Cin = c->Cin; a.conv.To = To; a.conv.Ho = Ho; a.conv.Wo = Wo;
         a.conv.kt = c->kt; a.conv.kh = c->kh; a.conv.kw = c->kw; a.conv.st = c->st; a.conv.sh = c->sh; a.conv.sw = c->sw;
