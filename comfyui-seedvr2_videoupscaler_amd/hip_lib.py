@@ -19,7 +19,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                "-mllvm", "-pragma-unroll-threshold=1000000"]
 
 EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU, EPI_BIAS_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 # svr_gemm_kernel_class() codes (include/seedvr2_hip.h)
 KERNEL_CLASSES = {0: "none", 1: "gemm", 2: "gemm_persistent", 3: "conv_halo", 4: "conv_subpixel", 5: "conv_thin_in",
                   6: "conv_thinout", 7: "conv_generic"}

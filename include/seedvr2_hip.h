@@ -19,13 +19,17 @@
 extern "C" {
 #endif
 
-#define SVR_ABI_VERSION 7
+/* v8 (round 5): svr_rmsnorm_mod takes SVR_STORE_H16 inputs; svr_gemm_bf16's persistent kernel serves the two h16 forms of the NaDiT's
+ * residual stream (bias -> h16; gate * (acc + bias) + h16 residual -> h16); svr_qknorm_rope / svr_groupnorm_apply refuse NULL weights;
+ * svr_set_option keys "gemm_asym", "gn_grid_cap", attn_variant 5..10 and gemm_w4r = 2 are gone (measured, deleted).  No signature changed. */
+#define SVR_ABI_VERSION 8
 
 /* ---- GEMM / implicit-GEMM convolution epilogues ------------------------------------------ */
 /* Storage kinds of activation tensors that are NOT MFMA operands (svr_gemm_args.out_f32 / .resid_f32, the x_f32 arguments).
  * SVR_STORE_H16 (ABI v6): an IEEE half holding x * 2^-6 -- 11 significant bits for bf16's bytes, range +-4.2e6, absolute floor
- * 3.8e-6: the residual trunk of the VAE (ResnetBlock3D / attention outputs, attn_video_vae.py:311-362, 615-665) and a block's
- * conv1 output, read only by GroupNorm and residual adds.  Every MFMA operand is bf16. */
+ * 3.8e-6: the residual trunk of the VAE (ResnetBlock3D / attention outputs, attn_video_vae.py:311-362, 615-665), a block's conv1
+ * output and (v8) the NaDiT's residual stream (mmsr_block.py:108-126): tensors read only by GroupNorm / RMSNorm and residual adds.
+ * Every MFMA operand is bf16. */
 #define SVR_STORE_BF16 0
 #define SVR_STORE_FP32 1
 #define SVR_STORE_H16  2

@@ -30,8 +30,8 @@ def test_library_builds_loads_and_exports_header_symbols():
         assert hasattr(lib, name), f"{name} declared in seedvr2_hip.h but not exported"
     assert sorted(hip_lib.SYMBOLS) == declared, "ctypes table and header disagree"
     lib.svr_abi_version.restype = ctypes.c_int
-    assert lib.svr_abi_version() == hip_lib.ABI_VERSION == 7
-    assert hip_lib.lib().svr_abi_version() == 7
+    assert lib.svr_abi_version() == hip_lib.ABI_VERSION == 8
+    assert hip_lib.lib().svr_abi_version() == 8
     # the binary carries the content hash of the sources it was compiled from; the loader refuses any other
     assert hip_lib.built_id() == hip_lib.source_id() and not hip_lib.needs_build()
 
