@@ -88,6 +88,8 @@ int main(int argc, char** argv) {
     std::vector<std::string> sets;
     for (int i = 3; i < argc; ++i) sets.push_back(argv[i]);
     if (sets.empty()) sets.push_back("");
+    if (apply_options(sets[0])) return 1;            // (buffers that depend on the route -- the fused-statistics partials -- are sized under the FIRST set:
+                                                     //  option sets that change the route of a case belong in separate invocations)
     char info[256];
     svr_device_info(info, 256);
     printf("# %s | build %s\n", info, svr_build_id());
