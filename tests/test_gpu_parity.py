@@ -517,3 +517,27 @@ def test_two_gpu_rccl_sharded_pipeline_equals_single_gpu():
         assert p.exitcode == 0
     want = res[0][1]
     assert torch.equal(res[0][0], want) and torch.equal(res[1][0], want)
+
+
+# ------------------------------------------------------------------ colour correction on the device (§8f N3: all five modes)
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["adain", "wavelet", "lab", "hsv", "wavelet_adaptive"])
+def test_colour_modes_on_the_device_equal_their_cpu_run(method):
+    """The pipeline runs colour correction on the device the decoder left the frames on; tests/test_glue.py pins the same
+    functions to the reference's text on CPU (<= 2e-6).  Here: device result == CPU result.  The three histogram modes
+    are RANK based (sort + gather), so pixels tied within fp32 rounding of the device's blur / colour-space arithmetic
+    may exchange matched values: all but a handful agree to 2e-5, none is off by more than a histogram neighbour."""
+    cf = sub("colorfix")
+    g = torch.Generator().manual_seed(11)
+    content = (torch.rand(3, 3, 96, 160, generator=g) * 2 - 1) * 0.9
+    style = (torch.rand(3, 3, 96, 160, generator=g) * 2 - 1) * 0.6 + 0.1
+    content[:, :, :8, :8] = 0.3                          # grey block: hue 0 / saturation 0 branch
+    want = cf.METHODS[method](content.clone(), style.clone())
+    got = cf.METHODS[method](content.cuda(), style.cuda())
+    assert got.is_cuda and got.shape == want.shape and got.dtype == want.dtype
+    d = (got.cpu() - want).abs()
+    assert torch.isfinite(got).all()
+    if method in ("adain", "wavelet"):
+        assert float(d.max()) < 2e-5, float(d.max())
+    else:
+        assert float((d > 2e-5).float().mean()) < 5e-3 and float(d.max()) < 5e-3, (float((d > 2e-5).float().mean()), float(d.max()))
