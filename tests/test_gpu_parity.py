@@ -526,12 +526,13 @@ def test_colour_modes_on_the_device_equal_their_cpu_run(method):
     """The pipeline runs colour correction on the device the decoder left the frames on; tests/test_glue.py pins the same
     functions to the reference's text on CPU (<= 2e-6).  Here: device result == CPU result.  The three histogram modes
     are RANK based (sort + gather), so pixels tied within fp32 rounding of the device's blur / colour-space arithmetic
-    may exchange matched values: all but a handful agree to 2e-5, none is off by more than a histogram neighbour."""
+    may exchange matched values: all but a handful agree to 2e-5, none is off by more than a histogram neighbour.
+    No exactly-tied pixels here (the CPU test's grey block): torch.sort is not stable, so the order of ties -- and with it
+    which tied pixel receives which matched value -- is undefined between devices for the reference's own code as well."""
     cf = sub("colorfix")
     g = torch.Generator().manual_seed(11)
     content = (torch.rand(3, 3, 96, 160, generator=g) * 2 - 1) * 0.9
     style = (torch.rand(3, 3, 96, 160, generator=g) * 2 - 1) * 0.6 + 0.1
-    content[:, :, :8, :8] = 0.3                          # grey block: hue 0 / saturation 0 branch
     want = cf.METHODS[method](content.clone(), style.clone())
     got = cf.METHODS[method](content.cuda(), style.cuda())
     assert got.is_cuda and got.shape == want.shape and got.dtype == want.dtype
