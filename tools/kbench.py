@@ -84,7 +84,7 @@ def main():
             if Co <= 16:                                    # the 32-cout kernel these launches ran on until round 4
                 ops.set_option("conv_thinout16", 0)
                 sec = timeit(lambda: ops.gemm(x, w, y, N=Co, K=27 * Ci, bias=b, conv=geom, ldc=Co, W_frag=wf), args.reps)
-                ops.set_option("conv_thinout16", 1)
+                ops.set_option("conv_thinout16", 2)
                 report(name + " [conv_thinout16=0: the 32-cout kernel]", sec, flops=2.0 * T * H * W * Co * 27 * Ci)
             del x, w, y
     if "thin" in only:
