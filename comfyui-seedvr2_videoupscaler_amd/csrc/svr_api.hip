@@ -53,7 +53,7 @@ int svr_set_option(const char* key, int32_t value) {
     if (!strcmp(key, "conv_band")) { g_conv_band = value; return 0; }
     if (!strcmp(key, "conv_sub")) { g_conv_sub = value; return 0; }
     if (!strcmp(key, "conv_lds")) { g_conv_lds_dbg = value; return 0; }
-    if (!strcmp(key, "conv_thinout16")) { g_conv_thinout16 = value; return 0; }
+    if (!strcmp(key, "conv_thinout4")) { g_conv_thinout4 = value; return 0; }
     if (!strcmp(key, "attn_impl")) { g_attn_impl = value; return 0; }
     if (!strcmp(key, "attn_variant")) { g_attn_variant = value; return 0; }
     return fail("svr_set_option: unknown key");

@@ -187,304 +187,60 @@ __global__ __launch_bounds__(CT_NT) void conv_thinout_kernel(const svr_gemm_args
 
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Round 4: the N <= 16 form (decoder conv_out, 128 -> 3 at full resolution: 0.9 % of the BASELINE config 3 step).  The kernel above
+// The N <= 4 form (decoder conv_out, 128 -> 3 at full resolution: 0.8 % of the BASELINE config 3 step in round 4).  The kernel above
 // is LDS-bound -- eight waves of ONE patch row each read 72 KiB of fragments per step, every wave its own copy of the step's nine
 // weight units: 576 KiB per step and CU = 4608 cycles at 128 B/clk for 2304 cycles of (mostly padding) MFMA work -- and behind
 // that it is bound by its staging: 3.6 staged bytes per input byte (halo x three temporal taps) at almost no arithmetic.  Here:
-//   * v_mfma_f32_16x16x32_bf16 with the couts as the 16-row operand: half the padding of the 32-cout tile, and one fragment
-//     read covers the whole 32-channel slice of 16 voxels or 16 couts (64-byte LDS rows);
+//   * v_mfma_f32_16x16x32_bf16 with the couts as the 16-row operand, and only FOUR cout rows per (channel slice, temporal tap, tap)
+//     unit in LDS (256 B): lanes 4..15 of the operand read the rows of lanes 0..3 again -- their accumulator rows are never stored,
+//     and a row of D depends on its own row of the operand only -- so ALL weights of the conv (Cin x kt x 9 x 4 x 2 B = 27 KiB for
+//     128 x 3) are staged ONCE per workgroup and stay resident;
 //   * four waves, FOUR patch rows each (16 x 32 patch): a wave's weight fragments serve 8 MFMAs each, its six halo rows are
 //     shared by the three vertical taps;
 //   * FRAME STREAMING: a workgroup keeps its patch and walks the INPUT frames of its chunk of the clip; a staged halo
 //     (input frame f, 32-channel slice) is multiplied with the weights of ALL temporal taps and accumulated into the up to
 //     three output frames it belongs to (to = f - dt + pt; three accumulator sets of 8 f32x4 in a static ring) -- the thin
 //     output is what makes three live output frames affordable, and the staging drops from 3.6 to 1.2 bytes per input byte;
+//   * a THREE-deep halo ring (18 x 34 pixels x 64 B per step): steps k + 1 and k + 2 are in flight under the MFMAs of step k
+//     (`vmcnt(10)`: every wave stages whole pieces, the tail of the tenth reads the zero page, so the count is a constant), one
+//     barrier per step.  Round 4's double buffer -- one step, 17 MB on the chip, in flight when a step starts and nothing when it
+//     ends -- was half of what the HBM latency needs;
 //   * per column shift dx: 12 halo + 3 weight fragment reads (15 = the most lgkmcnt can count) issued under the MFMAs of the
-//     previous shift, the other temporal taps' 6 weight fragments under the first 24 MFMAs of their shift; the step's 18 x 34
-//     halo and kt x 9 sixteen-cout weight units are staged by LDS-DMA into a double buffer one step ahead, one `vmcnt(0)` +
-//     barrier per step as above.
-// Same swizzles as the LDS-halo kernels (64-byte rows, chunk c at position c ^ ((row_or_hx >> 2) & 3)).
-// ------------------------------------------------------------------------------------------------------------------------
-constexpr int C2_TY = 16, C2_TX = 32, C2_HX = C2_TX + 2, C2_HY = C2_TY + 2;
-constexpr int C2_NT = 256;
-constexpr int C2_AROWS = C2_HX * C2_HY;                  // 612 halo pixels, 64 B each
-constexpr int C2_ACHUNKS = C2_AROWS * 4;                 // 2448 16-byte chunks
-constexpr int C2_APIECES = (C2_ACHUNKS + C2_NT - 1) / C2_NT;   // 10 (the last one partial)
-constexpr int C2_ABUF = C2_AROWS * 64;                   // 39 168 B
-constexpr int C2_WTAP = 9 * 16 * 64;                     // one temporal tap's nine 16-cout units: 9 216 B
-constexpr int C2_WPIECES = (3 * 9 * 16 * 4 + C2_NT - 1) / C2_NT;   // 7 for kt = 3 (fewer rows are staged for kt < 3)
-constexpr int C2_STEP = C2_ABUF + 3 * C2_WTAP;           // 66 816 B
-constexpr int C2_LDS = 2 * C2_STEP;                      // 133 632 B
-static_assert(C2_APIECES == 10 && C2_WPIECES == 7 && (C2_ABUF % 16) == 0 && C2_LDS <= 160 * 1024, "piece schedule / LDS budget");
-
-__global__ __launch_bounds__(C2_NT, 1) void conv_thinout16_kernel(const svr_gemm_args a, const int frames_per_chunk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const svr_conv_geom& g = a.conv;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // patch rows 4 wave .. 4 wave + 3
-
-    const int tiles_x = (g.W + C2_TX - 1) / C2_TX;
-    const int tiles_y = (g.H + C2_TY - 1) / C2_TY;
-    int tl;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, j = bid >> 3, q = nwg >> 3, r = nwg & 7;
-        tl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int tx = tl % tiles_x;
-    const int rr = tl / tiles_x;
-    const int ty = rr % tiles_y;
-    const int chunk = rr / tiles_y;
-    const int y0 = ty * C2_TY, x0 = tx * C2_TX;
-    const int t0 = chunk * frames_per_chunk, t1 = min(g.To, t0 + frames_per_chunk);   // output frames of this workgroup
-
-    const int kt = g.kt;
-    const int cpk = g.Cin / 32;                           // 32-channel slices per input frame
-    const int n_in = (t1 - t0) + kt - 1;                  // input frames walked: i = 0 .. n_in - 1 is frame f = t0 - pt + i
-    const int nsteps = n_in * cpk;
-    const int64_t frame_bytes = (int64_t)g.H * g.W * g.Cin * 2;
-
-    // ---- staging roles: chunk id = piece * 256 + tid -> (row = id >> 2, position = id & 3); source chunk = position ^ key(row)
-    const int srow = tid >> 2, spos = tid & 3;
-    uint32_t poff[C2_APIECES];                            // halo piece -> pixel index (or ~0: outside the image / past the halo)
-    uint32_t akeys = 0;                                   // halo piece -> source chunk (2 bits each)
-#pragma unroll
-    for (int q = 0; q < C2_APIECES; ++q) {
-        const int row = q * 64 + srow;
-        const int hy = row / C2_HX, hx = row - hy * C2_HX;
-        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-        const bool ok = (row < C2_AROWS) & ((unsigned)y < (unsigned)g.H) & ((unsigned)x < (unsigned)g.W);
-        poff[q] = ok ? (uint32_t)(y * g.W + x) : 0xffffffffu;
-        akeys |= (uint32_t)(spos ^ ((hx >> 2) & 3)) << (2 * q);
-    }
-    int64_t woff[C2_WPIECES];                             // weight piece -> element offset of the source chunk for channel slice 0
-    const int wrows = kt * 144;                           // (dt, tap, cout) rows actually staged
-#pragma unroll
-    for (int q = 0; q < C2_WPIECES; ++q) {
-        const int row = q * 64 + srow;                    // = (dt * 9 + tap) * 16 + cout
-        const int n = row & 15, dtap = row >> 4;          // W is [n][K = (dt, dy, dx, c)]: (dt * 9 + tap) * Cin + c
-        const int ck = spos ^ ((row >> 2) & 3);
-        woff[q] = row < wrows ? (int64_t)n * a.K + (int64_t)dtap * g.Cin + ck * 8 : -1;
-    }
-    char* const wave_dst = smem + wave * 1024;
-
-    auto stage_step = [&](int k, int buf) {               // step k = (input frame i = k / cpk, channel slice k % cpk)
-        const int i = k / cpk;
-        const int c0 = (k - i * cpk) * 32;
-        int f = t0 - g.pt + i;
-        const char* basep = (const char*)a.A;
-        if (f < 0) {
-            if (g.halo != nullptr) { basep = (const char*)g.halo; f += g.halo_frames; }
-            else f = 0;
-        }
-        const char* fptr = basep + (int64_t)f * frame_bytes + c0 * 2;
-        char* dst = wave_dst + buf * C2_STEP;
-#pragma unroll
-        for (int q = 0; q < C2_APIECES; ++q) {
-            const int ck = (akeys >> (2 * q)) & 3;
-            const char* src = poff[q] == 0xffffffffu ? (const char*)g.zeros : fptr + ((int64_t)poff[q] * g.Cin + ck * 8) * 2;
-            if (q * C2_NT + tid < C2_ACHUNKS) glds16(src, dst + q * 4096);
-        }
-        const bf16_t* wsl = (const bf16_t*)a.W + c0;
-#pragma unroll
-        for (int q = 0; q < C2_WPIECES; ++q)
-            if (woff[q] >= 0) glds16(wsl + woff[q], dst + C2_ABUF + q * 4096);
-    };
-
-    // ---- fragment addressing (lane constants).  v_mfma_f32_16x16x32_bf16: lane (l15, kq) holds row / column l15, k = 8 kq .. 8 kq + 7.
-    // halo fragment (row hy, column shift dx, half h): pixel hx = dx + 16 h + l15; weights (dt, tap): row (dt * 9 + tap) * 16 + l15
-    const int l15 = lane & 15, kq = lane >> 4;
-    int rd_a[3][2], rd_b;
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int hx = dx + 16 * h + l15;
-            rd_a[dx][h] = (wave * 4 * C2_HX + hx) * 64 + ((kq ^ ((hx >> 2) & 3)) << 4);
-        }
-    rd_b = C2_ABUF + l15 * 64 + ((kq ^ ((l15 >> 2) & 3)) << 4);
-
-    f32x4 acc[3][4][2];                                   // [ring slot of the output frame][patch row][half]
-#pragma unroll
-    for (int sl = 0; sl < 3; ++sl)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) acc[sl][r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    bf16x8 hA[6][2], hB[6][2], w0A[3], w0B[3], w1[3], w2[3];
-    unsigned ra[3][2], rb;
-#define C2_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
-    // the 12 halo fragments of column shift DX + the three vertical taps' weights of temporal tap 0
-#define C2_ISSUE_H(DX, H, W_) \
-    C2_RD(H[0][0], ra[DX][0], 0 * C2_HX * 64); C2_RD(H[0][1], ra[DX][1], 0 * C2_HX * 64); \
-    C2_RD(H[1][0], ra[DX][0], 1 * C2_HX * 64); C2_RD(H[1][1], ra[DX][1], 1 * C2_HX * 64); \
-    C2_RD(H[2][0], ra[DX][0], 2 * C2_HX * 64); C2_RD(H[2][1], ra[DX][1], 2 * C2_HX * 64); \
-    C2_RD(W_[0], rb, (0 * 3 + DX) * 1024); C2_RD(W_[1], rb, (1 * 3 + DX) * 1024); C2_RD(W_[2], rb, (2 * 3 + DX) * 1024); \
-    C2_RD(H[3][0], ra[DX][0], 3 * C2_HX * 64); C2_RD(H[3][1], ra[DX][1], 3 * C2_HX * 64); \
-    C2_RD(H[4][0], ra[DX][0], 4 * C2_HX * 64); C2_RD(H[4][1], ra[DX][1], 4 * C2_HX * 64); \
-    C2_RD(H[5][0], ra[DX][0], 5 * C2_HX * 64); C2_RD(H[5][1], ra[DX][1], 5 * C2_HX * 64)
-    // the weights of temporal taps 1 and 2 for column shift DX
-#define C2_ISSUE_W12(DX) \
-    C2_RD(w1[0], rb, C2_WTAP + (0 * 3 + DX) * 1024); C2_RD(w1[1], rb, C2_WTAP + (1 * 3 + DX) * 1024); C2_RD(w1[2], rb, C2_WTAP + (2 * 3 + DX) * 1024); \
-    C2_RD(w2[0], rb, 2 * C2_WTAP + (0 * 3 + DX) * 1024); C2_RD(w2[1], rb, 2 * C2_WTAP + (1 * 3 + DX) * 1024); C2_RD(w2[2], rb, 2 * C2_WTAP + (2 * 3 + DX) * 1024)
-#define C2_LANDED_H(H, W_) \
-    asm volatile("s_waitcnt lgkmcnt(0)" \
-                 : "+v"(H[0][0]), "+v"(H[0][1]), "+v"(H[1][0]), "+v"(H[1][1]), "+v"(H[2][0]), "+v"(H[2][1]), "+v"(H[3][0]), "+v"(H[3][1]), \
-                   "+v"(H[4][0]), "+v"(H[4][1]), "+v"(H[5][0]), "+v"(H[5][1]), "+v"(W_[0]), "+v"(W_[1]), "+v"(W_[2])); \
-    __builtin_amdgcn_sched_barrier(0)
-#define C2_LANDED_W12() \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w2[0]), "+v"(w2[1]), "+v"(w2[2])); \
-    __builtin_amdgcn_sched_barrier(0)
-    // 24 MFMAs: output row r, vertical tap dy reads halo row r + dy; into ring slot SL
-    auto mm = [&](auto slc, bf16x8 (&h)[6][2], bf16x8 (&w)[3]) {
-        constexpr int SL = decltype(slc)::value;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
-                    acc[SL][r][hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[dy], h[r + dy][hh], acc[SL][r][hh], 0, 0, 0);
-    };
-    // one step (input frame i with i % 3 == Q, one channel slice) out of buffer `buf`; ok0 / ok1 / ok2: does temporal tap dt land in
-    // an output frame of this chunk (wave-uniform).  Output frame of tap dt: t0 + i - dt -> ring slot (Q - dt) mod 3.
-    auto step_body = [&](auto qc, int buf, bool ok0, bool ok1, bool ok2) {
-        constexpr int Q = decltype(qc)::value;
-        using S0 = std::integral_constant<int, Q % 3>;
-        using S1 = std::integral_constant<int, (Q + 2) % 3>;
-        using S2 = std::integral_constant<int, (Q + 1) % 3>;
-        const unsigned bufoff = lds0 + (unsigned)(buf * C2_STEP);
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) ra[dx][h] = bufoff + (unsigned)rd_a[dx][h];
-        rb = bufoff + (unsigned)rd_b;
-        __builtin_amdgcn_sched_barrier(0);
-        const bool any12 = ok1 | ok2;
-        C2_ISSUE_H(0, hA, w0A);
-        C2_LANDED_H(hA, w0A);                             // (the first shift of a step is not overlapped: the buffer has just landed)
-        // shift 0 out of set A
-        if (any12) { C2_ISSUE_W12(0); }
-        if (ok0) mm(S0{}, hA, w0A);
-        __builtin_amdgcn_sched_barrier(0);
-        C2_LANDED_W12();
-        C2_ISSUE_H(1, hB, w0B);
-        if (ok1) mm(S1{}, hA, w1);
-        if (ok2) mm(S2{}, hA, w2);
-        __builtin_amdgcn_sched_barrier(0);
-        C2_LANDED_H(hB, w0B);
-        // shift 1 out of set B
-        if (any12) { C2_ISSUE_W12(1); }
-        if (ok0) mm(S0{}, hB, w0B);
-        __builtin_amdgcn_sched_barrier(0);
-        C2_LANDED_W12();
-        C2_ISSUE_H(2, hA, w0A);
-        if (ok1) mm(S1{}, hB, w1);
-        if (ok2) mm(S2{}, hB, w2);
-        __builtin_amdgcn_sched_barrier(0);
-        C2_LANDED_H(hA, w0A);
-        // shift 2 out of set A
-        if (any12) { C2_ISSUE_W12(2); }
-        if (ok0) mm(S0{}, hA, w0A);
-        __builtin_amdgcn_sched_barrier(0);
-        C2_LANDED_W12();
-        if (ok1) mm(S1{}, hA, w1);
-        if (ok2) mm(S2{}, hA, w2);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // output frame `to` is complete: bias etc. through the shared 4-column epilogue, then its ring slot is cleared
-    auto flush = [&](auto slc, int to) {
-        constexpr int SL = decltype(slc)::value;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int y = y0 + wave * 4 + r, x = x0 + 16 * h + l15;
-                const int n = 4 * kq;
-                if (y < g.H && x < g.W && n < a.N) {
-                    const int m = (to * g.H + y) * g.W + x;
-                    epilogue_store(a, acc[SL][r][h], acc[SL][r][h], m, n);
-                }
-                acc[SL][r][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-    };
-
-    if (nsteps <= 0) return;
-    stage_step(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int k = 0;
-    for (int i = 0; i < n_in; ++i) {
-        const int q3 = i % 3;
-        // temporal tap dt of input frame i feeds output frame t0 + i - dt: inside [t0, t1) and dt < kt ?
-        const bool ok0 = (t0 + i < t1);
-        const bool ok1 = kt > 1 && i >= 1 && (t0 + i - 1 < t1);
-        const bool ok2 = kt > 2 && i >= 2 && (t0 + i - 2 < t1);
-        for (int c = 0; c < cpk; ++c, ++k) {
-            if (k + 1 < nsteps) stage_step(k + 1, (k + 1) & 1);
-            if (q3 == 0) step_body(std::integral_constant<int, 0>{}, k & 1, ok0, ok1, ok2);
-            else if (q3 == 1) step_body(std::integral_constant<int, 1>{}, k & 1, ok0, ok1, ok2);
-            else step_body(std::integral_constant<int, 2>{}, k & 1, ok0, ok1, ok2);
-            // next step landed (this wave's share: vmcnt(0)) + everyone done with this buffer
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // the output frame whose LAST temporal tap (dt = kt - 1) this input frame carried is complete
-        const int to = t0 + i - (kt - 1);
-        if (to >= t0 && to < t1) {
-            const int sl = (q3 + 3 - ((kt - 1) % 3)) % 3;
-            if (sl == 0) flush(std::integral_constant<int, 0>{}, to);
-            else if (sl == 1) flush(std::integral_constant<int, 1>{}, to);
-            else flush(std::integral_constant<int, 2>{}, to);
-        }
-    }
-#undef C2_LANDED_W12
-#undef C2_LANDED_H
-#undef C2_ISSUE_W12
-#undef C2_ISSUE_H
-#undef C2_RD
-}
-
-
-// ------------------------------------------------------------------------------------------------------------------------
-// Round 5: the N <= 4 form of the kernel above (the only production user: decoder conv_out, 128 -> 3).  The frame-streaming kernel
-// moves 1.2 staged bytes per input byte and still ran at 3.6 TB/s of input: its double buffer has ONE step (66 KiB per CU, 17 MB
-// on the chip) in flight when a step starts and nothing when it ends -- `vmcnt(0)` + barrier per step -- i.e. half of what the HBM
-// latency needs on average, and 27 KiB of every step are the 16-cout weight units of which 13 rows are padding.  Here
-//   * only FOUR cout rows per (slice, temporal tap, tap) unit exist in LDS (256 B); lanes 4..15 of the 16-row MFMA operand read the
-//     rows of lanes 0..3 again -- their accumulator rows are never stored, and a row of D depends on its own row of the operand
-//     only -- so ALL weights of the conv (Cin x kt x 9 x 4 x 2 B = 27 KiB for 128 x 3) are staged ONCE and stay resident;
-//   * the freed LDS holds a THREE-deep halo ring: steps k + 1 and k + 2 are in flight under the MFMAs of step k
-//     (`vmcnt(10)`: every wave stages whole pieces, the tail of the tenth reads the zero page, so the count is a constant),
-//     one barrier per step as before;
+//     previous shift, the other temporal taps' 6 weight fragments under the first 24 MFMAs of their shift;
+//   * the step body exists twice: without branches when all three temporal taps are live (all input frames but the first and
+//     last kt - 1 of a chunk) -- behind a wave-uniform branch hipcc copies the 32 accumulators of the not-taken side, 9 x 32
+//     v_accvgpr_mov per step with one wave per SIMD -- and with them for the head and tail frames;
 //   * a completed output frame leaves through LDS: the MFMA layout puts one voxel's N <= 4 couts in one lane, i.e. N scalar stores of
-//     2 or 4 bytes per voxel at a stride of N elements -- 600 of the 1 680 us of the 9 x 1024^2 launch were those partial writes
-//     (ablation: profiles/r5_conv_thinout4_ab.txt).  Each wave parks its four patch rows (32 voxels x N couts, contiguous in the
-//     [T, H, W, N] output) in a private 2 KiB of LDS and writes them back one element per lane: full lines.  Taken for the plain
-//     bias epilogue into a dense output (conv_out); anything else goes through epilogue_store() as above.
-// Everything else (patch, frame walk, accumulator ring, fragment schedule, swizzle of the halo image) is the kernel above.
+//     2 or 4 bytes per voxel at a stride of N elements -- 600 of the 1 680 us of the 9 x 1024^2 launch were those partial writes.
+//     Each wave parks its four patch rows (32 voxels x N couts, contiguous in the [T, H, W, N] output) in a private 2 KiB of LDS
+//     and writes them back one element per lane: full lines.  Taken for the plain bias epilogue into a dense output (conv_out);
+//     anything else goes through epilogue_store().
+// Round 5 measurements (profiles/r5_conv_thinout4_ab.txt): 1 885 -> 1 131 us on 9 x 1024^2 x 128 -> 3, bit-identical to round 4's
+// kernel (N <= 16 couts per unit, weights re-staged with every halo, double buffer, scalar stores), which it replaces.
+// Same swizzle of the halo image as the LDS-halo kernels (64-byte rows, chunk c at position c ^ ((hx >> 2) & 3)).
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int C4_ABUF = C2_APIECES * C2_NT * 16;         // 40 960 B: ten whole pieces
-constexpr int C4_WOFF = 3 * C4_ABUF;                     // 122 880
+constexpr int C4_TY = 16, C4_TX = 32, C4_HX = C4_TX + 2, C4_HY = C4_TY + 2;
+constexpr int C4_NT = 256;
+constexpr int C4_AROWS = C4_HX * C4_HY;                  // 612 halo pixels, 64 B each
+constexpr int C4_ACHUNKS = C4_AROWS * 4;                 // 2448 16-byte chunks
+constexpr int C4_APIECES = (C4_ACHUNKS + C4_NT - 1) / C4_NT;   // 10 (the tail of the last one reads the zero page)
+constexpr int C4_ABUF = C4_APIECES * C4_NT * 16;         // 40 960 B: ten whole pieces
+constexpr int C4_WOFF = 3 * C4_ABUF;                     // 122 880: the resident weights follow the ring
 constexpr int C4_FLUSH = 4 * 4 * 128 * 4;                // 8 KiB: per wave four patch rows x (32 voxels x <= 4 couts) dwords
-static_assert(C4_ABUF >= C2_ABUF, "whole pieces cover the halo image");
+static_assert(C4_APIECES == 10 && C4_ABUF >= C4_AROWS * 64, "piece schedule: vmcnt(10) names one step's staging");
 
-// DBG (builds with -DSVR_ABLATIONS only; results invalid): 1 no halo staging after the first two steps, 2 no MFMAs, 4 no fragment reads,
-// 8 no global stores
+// DBG (builds with -DSVR_ABLATIONS only; results invalid): 1 no halo staging after the first two steps, 4 no fragment reads, 8 no global
+// stores (2: no MFMAs -- not launched: the accumulators then travel through VGPRs around the empty asm and the time says nothing)
 template <int DBG = 0>
-__global__ __launch_bounds__(C2_NT, 1) void conv_thinout4_kernel(const svr_gemm_args a, const int frames_per_chunk, const int flush_off) {
+__global__ __launch_bounds__(C4_NT, 1) void conv_thinout4_kernel(const svr_gemm_args a, const int frames_per_chunk, const int flush_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const svr_conv_geom& g = a.conv;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // patch rows 4 wave .. 4 wave + 3
 
-    const int tiles_x = (g.W + C2_TX - 1) / C2_TX;
-    const int tiles_y = (g.H + C2_TY - 1) / C2_TY;
+    const int tiles_x = (g.W + C4_TX - 1) / C4_TX;
+    const int tiles_y = (g.H + C4_TY - 1) / C4_TY;
     int tl;
     {
         const int nwg = gridDim.x, bid = blockIdx.x;
@@ -495,7 +251,7 @@ __global__ __launch_bounds__(C2_NT, 1) void conv_thinout4_kernel(const svr_gemm_
     const int rr = tl / tiles_x;
     const int ty = rr % tiles_y;
     const int chunk = rr / tiles_y;
-    const int y0 = ty * C2_TY, x0 = tx * C2_TX;
+    const int y0 = ty * C4_TY, x0 = tx * C4_TX;
     const int t0 = chunk * frames_per_chunk, t1 = min(g.To, t0 + frames_per_chunk);   // output frames of this workgroup
 
     const int kt = g.kt;
@@ -505,16 +261,17 @@ __global__ __launch_bounds__(C2_NT, 1) void conv_thinout4_kernel(const svr_gemm_
     const int64_t frame_bytes = (int64_t)g.H * g.W * g.Cin * 2;
     if (nsteps <= 0) return;
 
-    // ---- halo staging roles (as above, but every thread stages all ten pieces: rows past the image read the zero page)
+    // ---- halo staging roles: chunk id = piece * 256 + tid -> (row = id >> 2, position = id & 3); source chunk = position ^ key(row).
+    // Every thread stages all ten pieces: rows past the halo image or outside the frame read the zero page
     const int srow = tid >> 2, spos = tid & 3;
-    uint32_t poff[C2_APIECES];
+    uint32_t poff[C4_APIECES];
     uint32_t akeys = 0;
 #pragma unroll
-    for (int q = 0; q < C2_APIECES; ++q) {
+    for (int q = 0; q < C4_APIECES; ++q) {
         const int row = q * 64 + srow;
-        const int hy = row / C2_HX, hx = row - hy * C2_HX;
+        const int hy = row / C4_HX, hx = row - hy * C4_HX;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-        const bool ok = (row < C2_AROWS) & ((unsigned)y < (unsigned)g.H) & ((unsigned)x < (unsigned)g.W);
+        const bool ok = (row < C4_AROWS) & ((unsigned)y < (unsigned)g.H) & ((unsigned)x < (unsigned)g.W);
         poff[q] = ok ? (uint32_t)(y * g.W + x) : 0xffffffffu;
         akeys |= (uint32_t)(spos ^ ((hx >> 2) & 3)) << (2 * q);
     }
@@ -532,7 +289,7 @@ __global__ __launch_bounds__(C2_NT, 1) void conv_thinout4_kernel(const svr_gemm_
         const char* fptr = basep + (int64_t)f * frame_bytes + c0 * 2;
         char* dst = wave_dst + buf * C4_ABUF;
 #pragma unroll
-        for (int q = 0; q < C2_APIECES; ++q) {
+        for (int q = 0; q < C4_APIECES; ++q) {
             const int ck = (akeys >> (2 * q)) & 3;
             const char* src = poff[q] == 0xffffffffu ? (const char*)g.zeros : fptr + ((int64_t)poff[q] * g.Cin + ck * 8) * 2;
             glds16(src, dst + q * 4096);
@@ -543,9 +300,9 @@ __global__ __launch_bounds__(C2_NT, 1) void conv_thinout4_kernel(const svr_gemm_
     // piece * 256 + tid -> (u = id >> 4, n = (id >> 2) & 3, chunk = id & 3).  W is [n][K = (dt, dy, dx, c)] and padded to >= 4 rows.
     {
         const int units = cpk * kt * 9;
-        const int wpieces = (units * 16 + C2_NT - 1) / C2_NT;
+        const int wpieces = (units * 16 + C4_NT - 1) / C4_NT;
         for (int p = 0; p < wpieces; ++p) {
-            const int id = p * C2_NT + tid;
+            const int id = p * C4_NT + tid;
             const int u = id >> 4, n = (id >> 2) & 3, ck = id & 3;
             const int sl = u / (kt * 9), dtap = u - sl * (kt * 9);
             const bf16_t* src = u < units ? (const bf16_t*)a.W + (int64_t)n * a.K + (int64_t)dtap * g.Cin + sl * 32 + ck * 8
@@ -563,7 +320,7 @@ __global__ __launch_bounds__(C2_NT, 1) void conv_thinout4_kernel(const svr_gemm_
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int hx = dx + 16 * h + l15;
-            rd_a[dx][h] = (wave * 4 * C2_HX + hx) * 64 + ((kq ^ ((hx >> 2) & 3)) << 4);
+            rd_a[dx][h] = (wave * 4 * C4_HX + hx) * 64 + ((kq ^ ((hx >> 2) & 3)) << 4);
         }
     const int rd_b = C4_WOFF + (l15 & 3) * 64 + kq * 16;
     const int wslice = kt * 9 * 256;                      // bytes of one channel slice's units
@@ -582,13 +339,13 @@ __global__ __launch_bounds__(C2_NT, 1) void conv_thinout4_kernel(const svr_gemm_
 #define C4_RD(DST, ADDR, OFF) do { if constexpr ((DBG & 4) == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory"); \
                                 else asm volatile("" : "=v"(DST) : "v"(ADDR)); } while (0)
 #define C4_ISSUE_H(DX, H, W_) \
-    C4_RD(H[0][0], ra[DX][0], 0 * C2_HX * 64); C4_RD(H[0][1], ra[DX][1], 0 * C2_HX * 64); \
-    C4_RD(H[1][0], ra[DX][0], 1 * C2_HX * 64); C4_RD(H[1][1], ra[DX][1], 1 * C2_HX * 64); \
-    C4_RD(H[2][0], ra[DX][0], 2 * C2_HX * 64); C4_RD(H[2][1], ra[DX][1], 2 * C2_HX * 64); \
+    C4_RD(H[0][0], ra[DX][0], 0 * C4_HX * 64); C4_RD(H[0][1], ra[DX][1], 0 * C4_HX * 64); \
+    C4_RD(H[1][0], ra[DX][0], 1 * C4_HX * 64); C4_RD(H[1][1], ra[DX][1], 1 * C4_HX * 64); \
+    C4_RD(H[2][0], ra[DX][0], 2 * C4_HX * 64); C4_RD(H[2][1], ra[DX][1], 2 * C4_HX * 64); \
     C4_RD(W_[0], rb, (0 * 3 + DX) * 256); C4_RD(W_[1], rb, (1 * 3 + DX) * 256); C4_RD(W_[2], rb, (2 * 3 + DX) * 256); \
-    C4_RD(H[3][0], ra[DX][0], 3 * C2_HX * 64); C4_RD(H[3][1], ra[DX][1], 3 * C2_HX * 64); \
-    C4_RD(H[4][0], ra[DX][0], 4 * C2_HX * 64); C4_RD(H[4][1], ra[DX][1], 4 * C2_HX * 64); \
-    C4_RD(H[5][0], ra[DX][0], 5 * C2_HX * 64); C4_RD(H[5][1], ra[DX][1], 5 * C2_HX * 64)
+    C4_RD(H[3][0], ra[DX][0], 3 * C4_HX * 64); C4_RD(H[3][1], ra[DX][1], 3 * C4_HX * 64); \
+    C4_RD(H[4][0], ra[DX][0], 4 * C4_HX * 64); C4_RD(H[4][1], ra[DX][1], 4 * C4_HX * 64); \
+    C4_RD(H[5][0], ra[DX][0], 5 * C4_HX * 64); C4_RD(H[5][1], ra[DX][1], 5 * C4_HX * 64)
 #define C4_ISSUE_W12(DX) \
     C4_RD(w1[0], rb, (9 + 0 * 3 + DX) * 256); C4_RD(w1[1], rb, (9 + 1 * 3 + DX) * 256); C4_RD(w1[2], rb, (9 + 2 * 3 + DX) * 256); \
     C4_RD(w2[0], rb, (18 + 0 * 3 + DX) * 256); C4_RD(w2[1], rb, (18 + 1 * 3 + DX) * 256); C4_RD(w2[2], rb, (18 + 2 * 3 + DX) * 256)
@@ -613,7 +370,8 @@ __global__ __launch_bounds__(C2_NT, 1) void conv_thinout4_kernel(const svr_gemm_
                     else { f32x4& av = acc[SL][r][hh]; const bf16x8 wv = w[dy], hv = h[r + dy][hh]; asm volatile("" : "+v"(av) : "v"(wv), "v"(hv)); }
                 }
     };
-    // one step (input frame i with i % 3 == Q, channel slice c) out of ring buffer `buf`; ok0 / ok1 / ok2 as above
+    // one step (input frame i with i % 3 == Q, channel slice c) out of ring buffer `buf`; ok0 / ok1 / ok2: does temporal tap dt land in
+    // an output frame of this chunk (wave-uniform).  Output frame of tap dt: t0 + i - dt -> ring slot (Q - dt) mod 3.
     // ALL: every temporal tap lands in an output frame of this chunk (all input frames but the first and last kt - 1): no branches
     // around the MFMAs, so the accumulators stay in place (behind a branch hipcc copies all 32 of them on the not-taken side)
     auto step_body = [&](auto qc, auto allc, int buf, int c, bool ok0_, bool ok1_, bool ok2_) {
@@ -667,7 +425,7 @@ __global__ __launch_bounds__(C2_NT, 1) void conv_thinout4_kernel(const svr_gemm_
         for (int ch = 0; ch < 4; ++ch) if (ch < a.N) bias4[ch] = a.bias[ch];
     }
     const unsigned fl_base = lds0 + (unsigned)(flush_off + wave * 2048);
-    const int row_px = min(C2_TX, g.W - x0);              // voxels of a patch row inside the image
+    const int row_px = min(C4_TX, g.W - x0);              // voxels of a patch row inside the image
     auto flush = [&](auto slc, int to) {
         constexpr int SL = decltype(slc)::value;
         if (dense) {
@@ -773,40 +531,29 @@ __global__ __launch_bounds__(C2_NT, 1) void conv_thinout4_kernel(const svr_gemm_
 #undef C4_RD
 }
 
-int g_conv_thinout16 = 2;  // svr_set_option("conv_thinout16"): 2 (default) N <= 4 on the resident-weight kernel, 1 N <= 16 on the frame-streaming kernel | 0 the 32-cout kernel
+int g_conv_thinout4 = 1;  // svr_set_option("conv_thinout4"): 1 (default) N <= 4 on conv_thinout4_kernel | 0 on the 32-cout kernel above
 
 static int launch_conv_thinout(const svr_gemm_args& a, hipStream_t s) {
     const svr_conv_geom& g = a.conv;
     const int w4_bytes = ((g.Cin / 32) * g.kt * 9 * 256 + 4095) / 4096 * 4096;      // resident 4-cout weight units, whole staging pieces
-    if (g_conv_thinout16 >= 2 && a.N <= 4 && (g.Cin % 32) == 0 && C4_WOFF + w4_bytes + C4_FLUSH <= 160 * 1024) {
-        const int patches = ((g.H + C2_TY - 1) / C2_TY) * ((g.W + C2_TX - 1) / C2_TX);
+    if (g_conv_thinout4 && a.N <= 4 && (g.Cin % 32) == 0 && C4_WOFF + w4_bytes + C4_FLUSH <= 160 * 1024) {
+        // a workgroup walks the frames of its chunk of the clip; the clip is cut into chunks only when the patches alone would leave
+        // the chip under-filled (every chunk re-stages kt - 1 input frames)
+        const int patches = ((g.H + C4_TY - 1) / C4_TY) * ((g.W + C4_TX - 1) / C4_TX);
         const int want_chunks = std::max(1, std::min(g.To, (4 * device_cu_count() + patches - 1) / patches));
         const int fpc = (g.To + want_chunks - 1) / want_chunks;
         const int chunks = (g.To + fpc - 1) / fpc;
 #ifdef SVR_ABLATIONS
 #define SVR_T4_ABL(D) case D: { static uint64_t done = 0; const int e = set_max_dynamic_lds((const void*)conv_thinout4_kernel<D>, 160 * 1024, done); \
-        if (e != 0) return e; hipLaunchKernelGGL(conv_thinout4_kernel<D>, dim3(patches * chunks), dim3(C2_NT), C4_WOFF + w4_bytes + C4_FLUSH, s, a, fpc, C4_WOFF + w4_bytes); \
+        if (e != 0) return e; hipLaunchKernelGGL(conv_thinout4_kernel<D>, dim3(patches * chunks), dim3(C4_NT), C4_WOFF + w4_bytes + C4_FLUSH, s, a, fpc, C4_WOFF + w4_bytes); \
         return (int)hipGetLastError(); }
-        switch (g_pipe_abl) { SVR_T4_ABL(1) SVR_T4_ABL(2) SVR_T4_ABL(4) SVR_T4_ABL(6) SVR_T4_ABL(7) SVR_T4_ABL(8) default: break; }
+        switch (g_pipe_abl) { SVR_T4_ABL(1) SVR_T4_ABL(4) SVR_T4_ABL(8) default: break; }
 #undef SVR_T4_ABL
 #endif
         static uint64_t lds_attr_done4 = 0;
         const int e4 = set_max_dynamic_lds((const void*)conv_thinout4_kernel<0>, 160 * 1024, lds_attr_done4);
         if (e4 != 0) return e4;
-        hipLaunchKernelGGL(conv_thinout4_kernel<0>, dim3(patches * chunks), dim3(C2_NT), C4_WOFF + w4_bytes + C4_FLUSH, s, a, fpc, C4_WOFF + w4_bytes);
-        return (int)hipGetLastError();
-    }
-    if (g_conv_thinout16 && a.N <= 16 && (g.Cin % 32) == 0) {
-        // a workgroup walks the frames of its chunk of the clip; the clip is cut into chunks only when the patches alone would leave
-        // the chip under-filled (every chunk re-stages kt - 1 input frames)
-        const int patches = ((g.H + C2_TY - 1) / C2_TY) * ((g.W + C2_TX - 1) / C2_TX);
-        const int want_chunks = std::max(1, std::min(g.To, (4 * device_cu_count() + patches - 1) / patches));
-        const int fpc = (g.To + want_chunks - 1) / want_chunks;
-        const int chunks = (g.To + fpc - 1) / fpc;
-        static uint64_t lds_attr_done16 = 0;
-        const int e16 = set_max_dynamic_lds((const void*)conv_thinout16_kernel, 160 * 1024, lds_attr_done16);
-        if (e16 != 0) return e16;
-        hipLaunchKernelGGL(conv_thinout16_kernel, dim3(patches * chunks), dim3(C2_NT), C2_LDS, s, a, fpc);
+        hipLaunchKernelGGL(conv_thinout4_kernel<0>, dim3(patches * chunks), dim3(C4_NT), C4_WOFF + w4_bytes + C4_FLUSH, s, a, fpc, C4_WOFF + w4_bytes);
         return (int)hipGetLastError();
     }
     const int tiles = g.To * ((g.H + CT_TY - 1) / CT_TY) * ((g.W + CT_TX - 1) / CT_TX);

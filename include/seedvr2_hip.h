@@ -21,7 +21,8 @@ extern "C" {
 
 /* v8 (round 5): svr_rmsnorm_mod takes SVR_STORE_H16 inputs; svr_gemm_bf16's persistent kernel serves the two h16 forms of the NaDiT's
  * residual stream (bias -> h16; gate * (acc + bias) + h16 residual -> h16); svr_qknorm_rope / svr_groupnorm_apply refuse NULL weights;
- * svr_set_option keys "gemm_asym", "gn_grid_cap", attn_variant 5..10 and gemm_w4r = 2 are gone (measured, deleted).  No signature changed. */
+ * svr_set_option keys "gemm_asym", "gn_grid_cap", attn_variant 5..10 and gemm_w4r = 2 are gone (measured, deleted); "conv_thinout16" became "conv_thinout4" (1 default: N <= 4 thin-output
+ * convs on conv_thinout4_kernel, 0: on the 32-cout kernel).  No signature changed. */
 #define SVR_ABI_VERSION 8
 
 /* ---- GEMM / implicit-GEMM convolution epilogues ------------------------------------------ */
@@ -160,7 +161,7 @@ int32_t svr_gemm_gn_blocks(const svr_gemm_args* args);
 #define SVR_KERNEL_CONV_HALO       3   /* conv_halo2_kernel: stride-1 3x3 spatial taps, LDS halo (the dominant kernel) */
 #define SVR_KERNEL_CONV_SUBPIXEL   4   /* conv_sub_kernel: (kt, 2, 2)-tap phases of the sub-pixel upsamplers           */
 #define SVR_KERNEL_CONV_THIN_IN    5   /* conv_halo2_kernel<8, thin>: Cin = 4 (encoder.conv_in)                        */
-#define SVR_KERNEL_CONV_THIN_OUT   6   /* conv_thinout_kernel: Cout <= 32 (conv_out)                                   */
+#define SVR_KERNEL_CONV_THIN_OUT   6   /* conv_thinout4_kernel (Cout <= 4) / conv_thinout_kernel (Cout <= 32): conv_out */
 #define SVR_KERNEL_CONV_GENERIC    7   /* gemm_kernel in conv mode: strided / 1x1x1 / everything else                  */
 int32_t svr_gemm_kernel_class(const svr_gemm_args* args);
 const char* svr_gemm_kernel_name(int32_t kernel_class);
@@ -258,6 +259,8 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * "conv_band" tile rows per band of the conv kernel's frame-inner tile order (default 1; 0: frame outermost),
  * "conv_sub" 1 (default) (kt, 2, 2)-tap convs with W_frag run on the sub-pixel conv kernel | 0 on the generic kernel,
  * "conv_lds" dynamic LDS bytes to request for the halo kernel (> 80 KiB forces one workgroup per CU),
+ * "conv_thinout4" 1 (default) stride-1 3x3 convs with Cout <= 4 (decoder conv_out) on the resident-weight frame-streaming kernel | 0 on
+ * the 32-cout thin-output kernel,
  * "gemm_w4" 1 (default) plain GEMMs with N % 256 == 0 and >= 256 tiles on the persistent four-wave kernel (256 accumulators per
  * wave, the vendor library's tile shape and MFMA) | 0 on the eight-wave kernel like everything else,
  * "gemm_w4r" 1 (default) the persistent kernel streams the weights of a launch that carries W_frag from that copy into registers and

@@ -1098,10 +1098,11 @@ def test_vae_attention_at_config2_shape_512_channels_65536_tokens(hip):
 @pytest.mark.parametrize("T,H,W,Cin,N,hf,kt", [(3, 40, 70, 128, 3, 0, 3), (2, 17, 33, 128, 3, 2, 3), (1, 16, 32, 256, 16, 0, 3), (2, 5, 9, 128, 3, 0, 1),
                                                (1, 33, 65, 128, 3, 0, 2)])
 @pytest.mark.parametrize("out_f32", [False, True], ids=["bf16_store", "fp32_store"])
-def test_conv_thin_output_16_cout_kernel(hip, ref, T, H, W, Cin, N, hf, kt, out_f32):
-    """conv_thinout16_kernel (round 4: N <= 16 couts on v_mfma_f32_16x16x32_bf16, four patch rows per wave -- decoder conv_out) against
-    the torch conv and against the 32-cout kernel it replaces on these launches: ragged patches, carried temporal halo, the two-tap
-    causal-head launch (kt = 2), a 16-cout output, 1e-3 with an fp32 store."""
+def test_conv_thin_output_4_cout_kernel(hip, ref, T, H, W, Cin, N, hf, kt, out_f32):
+    """conv_thinout4_kernel (N <= 4 couts on v_mfma_f32_16x16x32_bf16, four patch rows per wave, resident weights, frames written back
+    through LDS -- decoder conv_out) against the torch conv and against the 32-cout kernel it replaces on these launches: ragged patches
+    (odd row starts for the 2-byte stores), carried temporal halo, the two-tap causal-head launch (kt = 2), 1e-3 with an fp32 store; the
+    16-cout case takes the 32-cout kernel either way."""
     packing, opsmod = sub("packing"), sub("ops")
     x = rnd(T, H, W, Cin)
     halo = rnd(hf, H, W, Cin, seed=9) if hf else None
@@ -1114,17 +1115,16 @@ def test_conv_thin_output_16_cout_kernel(hip, ref, T, H, W, Cin, N, hf, kt, out_
     kw = dict(N=N, K=Wp.shape[1], bias=bias, conv=geom, ldc=N)
     want = ref.gemm(x, Wp, torch.empty(To, H, W, N, device="cuda"), **kw)
     outs = []
-    for new in (2, 1, 0):
-        hip.set_option("conv_thinout16", new)
+    for new in (1, 0):
+        hip.set_option("conv_thinout4", new)
         try:
             out = torch.full((To, H, W, N), float("nan"), device="cuda", dtype=torch.float32 if out_f32 else BF16)
             hip.gemm(x, Wp, out, out_f32=out_f32, **kw)
             again = torch.full_like(out, float("nan"))
             hip.gemm(x, Wp, again, out_f32=out_f32, **kw)
         finally:
-            hip.set_option("conv_thinout16", 2)
+            hip.set_option("conv_thinout4", 1)
         assert not torch.isnan(out.float()).any() and torch.equal(out, again)          # every voxel written, reproducible
         assert rel_err(out.float(), want) < (1e-3 if out_f32 else TOL_BF16), new
         outs.append(out.float())
-    assert torch.equal(outs[0], outs[1])        # resident weights + three-deep ring: the same MFMAs in the same order
-    assert rel_err(outs[0], outs[2]) < (2e-4 if out_f32 else 4e-3)
+    assert rel_err(outs[0], outs[1]) < (2e-4 if out_f32 else 4e-3)

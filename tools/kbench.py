@@ -82,10 +82,10 @@ def main():
             sec = timeit(lambda: ops.gemm(x, w, y, N=Co, K=27 * Ci, bias=b, conv=geom, ldc=Co, W_frag=wf), args.reps)
             report(name, sec, flops=2.0 * T * H * W * Co * 27 * Ci)
             if Co <= 16:                                    # the 32-cout kernel these launches ran on until round 4
-                ops.set_option("conv_thinout16", 0)
+                ops.set_option("conv_thinout4", 0)
                 sec = timeit(lambda: ops.gemm(x, w, y, N=Co, K=27 * Ci, bias=b, conv=geom, ldc=Co, W_frag=wf), args.reps)
-                ops.set_option("conv_thinout16", 2)
-                report(name + " [conv_thinout16=0: the 32-cout kernel]", sec, flops=2.0 * T * H * W * Co * 27 * Ci)
+                ops.set_option("conv_thinout4", 1)
+                report(name + " [conv_thinout4=0: the 32-cout kernel]", sec, flops=2.0 * T * H * W * Co * 27 * Ci)
             del x, w, y
     if "thin" in only:
         # encoder.conv_in: RGB padded to 4 channels -> 128, the im2col image of a patch built in LDS; output on the h16 trunk with

@@ -63,7 +63,7 @@ static const Case CASES[] = {
     {"sp256", 5, 512, 512, 256, 256, 3, 2, 2, 1, 1, 1, 2, 1, 1, false, 1},
     {"sp512", 5, 256, 256, 512, 512, 2, 2, 2, 1, 1, 1, 1, 1, 1, false, 2},
     {"cin", 5, 1024, 1024, 4, 128, 3, 3, 3, 1, 1, 1, 2, 1, 1, false, 0, true},      // encoder.conv_in: RGB padded to 4 channels, K padded to 128
-    {"cout", 9, 1024, 1024, 128, 3, 3, 3, 3, 1, 1, 1, 2, 1, 1, false},              // decoder.conv_out: 128 -> 3 at full resolution (conv_thinout16_kernel), bf16 out
+    {"cout", 9, 1024, 1024, 128, 3, 3, 3, 3, 1, 1, 1, 2, 1, 1, false},              // decoder.conv_out: 128 -> 3 at full resolution (conv_thinout4_kernel), bf16 out
 };
 
 static int apply_options(const std::string& set) {
