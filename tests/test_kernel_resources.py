@@ -110,6 +110,11 @@ def test_hand_scheduled_kernels_do_not_spill_and_keep_their_occupancy(device_asm
     assert len(w4r) == 1, sorted(w4r)
     for name, m in w4r.items():
         assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0 and 256 < m["vgpr_count"] <= 512, (name, m)
+    # decoder conv_out (round 5): counted vmcnt(10) over a three-deep LDS-DMA ring, 96 accumulators, one four-wave workgroup per CU
+    t4 = {k: v for k, v in meta.items() if "conv_thinout4_kernel" in k}
+    assert len(t4) == 1 and not any("conv_thinout16" in k for k in meta), sorted(t4)
+    for name, m in t4.items():
+        assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0 and m["vgpr_count"] <= 512 and m["max_flat_workgroup_size"] == 256, (name, m)
 
 
 def test_window_attention_builds_keep_their_occupancy(device_asm):
@@ -140,3 +145,4 @@ def test_measurement_build_compiles(tmp_path_factory, request):
     assert rc == 0, err[-3000:]
     assert "conv_halo2_kernelILi16ELi3ELi256E" in asm and "gemm_w4p_kernelILb1ELi8E" in asm      # timeline / ablation variants
     assert "gemm_w4r_kernelILi4EE" in asm and "gemm_w4r_kernelILi64EE" in asm                     # K-loop ablations of gemm_w4r_kernel
+    assert "conv_thinout4_kernelILi1EE" in asm and "conv_thinout4_kernelILi8EE" in asm            # staging / store ablations of conv_out
