@@ -35,6 +35,10 @@ import subprocess
 import sys
 import time
 
+# dmabuf IPC is the only mode the host driver supports: without it RCCL's first cross-process handle exchange fails with
+# hipIpcGetMemHandle "invalid argument".  Set before the HIP runtime initialises (first CUDA call), for launchers that drop it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
