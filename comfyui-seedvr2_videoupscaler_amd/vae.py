@@ -17,6 +17,7 @@ Design (MI355X-first):
     attention change results, so this is semantics, not an optimisation); blending accumulates fp32.
 """
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -118,10 +119,15 @@ def _cos_ramp(n: int) -> Optional[torch.Tensor]:
 
 class VideoVAEEngine:
     def __init__(self, cfg: VAEConfig, state_dict: Dict[str, torch.Tensor], ops,
-                 act_budget_bytes: int = 12 << 30, merge_upsamplers: bool = True, merge_causal_head: bool = True,
+                 act_budget_bytes: int = 24 << 30, merge_upsamplers: bool = True, merge_causal_head: bool = True,
                  trunk_fp32: Optional[bool] = None, branch_fp32: Optional[bool] = None, tile_streams: int = 1,
                  trunk_store: Optional[str] = None, branch_store: Optional[str] = None, overflow_guard: bool = True):
-        """``tile_streams`` (default 1): spatial tiles of a tiled encode / decode are independent until the blend
+        """``act_budget_bytes`` (default 24 GiB; env SVR_VAE_ACT_BUDGET_GIB for A/B runs): bound on the widest activation of one
+        temporal slice, from which encode_clip / decode_clip derive the slice length (results do not depend on it, bit for bit).
+        24 GiB = the 9 latents (33 frames) of a 1024-px decoder tile in ONE slice: no carried-frame copies between slices, no second
+        set of launches; same box, BASELINE config 3: decode 5 146 / 5 172 ms at 12 GiB (two slices) -> 5 129 / 5 153 ms
+        (profiles/r5_vae_slice_budget_ab.txt); 48 GiB changes nothing further.  Peak memory of the config-3 step stays far below 288 GB.
+        ``tile_streams`` (default 1): spatial tiles of a tiled encode / decode are independent until the blend
         (attn_video_vae.py:1302-1630), so they CAN be issued round-robin onto several HIP streams, the HBM-bound passes of one tile
         (GroupNorm apply, statistics, layout copies) in the shadow of another tile's MFMA-bound convolutions; the blends are issued
         on the caller's stream in tile order, so the result is bit-identical to one stream (_run_tiles; tested).  MEASURED on
@@ -167,6 +173,8 @@ class VideoVAEEngine:
         self.overflow_reruns = 0            # calls the guard had to repeat with fp32 stores
         self.device = ops.device
         self.act_budget_bytes = act_budget_bytes
+        if os.environ.get("SVR_VAE_ACT_BUDGET_GIB"):       # A/B runs: temporal slice size of encode_clip / decode_clip
+            self.act_budget_bytes = int(float(os.environ["SVR_VAE_ACT_BUDGET_GIB"]) * (1 << 30))
         self.tile_streams = int(tile_streams)
         self.sample_dtype = None            # tools/error_budget.py only (CPU double): dtype of the decoder's own output tile; the HIP
                                             # blend kernels take bf16 tiles, so the product leaves it at None (measured: +0.1 dB for fp32)
