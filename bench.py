@@ -132,12 +132,36 @@ def make_profiled_ops(device):
             e.record()
             # which kernel served the launch is the LIBRARY's answer (svr_gemm_kernel_class, the routing function the launch
             # itself uses: csrc/svr_gemm.hip gemm_route) -- "conv_halo" is conv_halo2_kernel alone
-            self.events.append((self.last_kernel_class, flops, s, e))
+            if conv is not None:
+                shape = (f"conv k{tuple(conv.k)} s{tuple(conv.stride)} out {conv.To}x{conv.Ho}x{conv.Wo} {conv.Cin}->{kw['N']}"
+                         + (" quad" if getattr(kw.get("phase"), "quad", None) is not None else ""))
+            else:
+                shape = f"gemm M{kw.get('M') or A.shape[0]} N{kw['N']} K{kw['K']}" + (" +resid" if kw.get("resid") is not None else "")
+            self.events.append((self.last_kernel_class, flops, s, e, shape))
             return r
+
+        def by_shape(self, steps):
+            """Per (kernel class, shape): launches per step, average duration, TFLOP/s, seconds per step -- the table the by-shape
+            rocprof grouping cannot give (it has no FLOPs)."""
+            agg = {}
+            for kind, flops, s, e, shape in self.events:
+                a = agg.setdefault((kind, shape), [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += flops
+                a[2] += s.elapsed_time(e) * 1e-3
+            rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
+            tot = sum(v[2] for _, v in rows)
+            lines = [f"# per-shape table of the GEMM / conv launches of one step (HIP events on the launch stream, {steps} timed steps; "
+                     f"{sum(v[0] for _, v in rows) // steps} launches, {tot / steps * 1e3:.1f} ms per step)",
+                     f"# {'kernel class':16s} {'shape':62s} {'n/step':>7s} {'avg us':>9s} {'TFLOP/s':>8s} {'ms/step':>8s} {'share':>6s}"]
+            for (kind, shape), (n, f, sec) in rows:
+                lines.append(f"{kind:18s} {shape:62s} {n // steps:7d} {sec / n * 1e6:9.1f} {f / max(sec, 1e-12) / 1e12:8.1f} "
+                             f"{sec / steps * 1e3:8.2f} {100 * sec / max(tot, 1e-12):5.1f}%")
+            return "\n".join(lines) + "\n"
 
         def summary(self):
             agg = {}
-            for kind, flops, s, e in self.events:
+            for kind, flops, s, e, _shape in self.events:
                 a = agg.setdefault(kind, [0, 0.0, 0.0])
                 a[0] += 1
                 a[1] += flops
@@ -287,6 +311,9 @@ def main():
                          "engine's, 1 = every launch on one stream)")
     ap.add_argument("--branch", choices=["h16", "fp32", "bf16"], default=None,
                     help="A/B: storage of conv1's output inside a VAE block (VideoVAEEngine(branch_store=...)); default: the engine's (h16; round 3: bf16)")
+    ap.add_argument("--by-shape", default=None, metavar="FILE",
+                    help="also write the per-(kernel class, shape) table of the timed steps' GEMM / conv launches (launches, avg us, "
+                         "TFLOP/s, ms per step) to FILE")
     ap.add_argument("--cpu-double", action="store_true",
                     help="TESTS ONLY (needs SVR_BENCH_ALLOW_CPU_DOUBLE=1): CPU ranks over gloo with the torch double of the C ABI and "
                          "reduced-width models -- exercises this script's launcher / gather / guard / JSON plumbing, measures nothing")
@@ -474,6 +501,9 @@ def main():
             frames_per_step = world * useful
             padded_per_step = world * frames
         kern = ops.summary()
+        if args.by_shape and not double:
+            with open(args.by_shape, "w") as fh:
+                fh.write(ops.by_shape(args.steps))
         # dominant kernel: the LDS-halo implicit-GEMM conv (63 % of the step, profiles/r3_cfg3_kernel_stats.csv) -- its launches
         # ALONE (the thin-output / thin-input / sub-pixel / generic conv kernels are separate classes of `per_kernel`)
         dom = kern.get("conv_halo") or kern.get("conv_generic") or kern.get("gemm_persistent") or kern["gemm"]

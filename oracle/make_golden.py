@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--only", default="", help="'r2': only the round-2 fixtures; 'r2-dit' / 'r2-vae17' / 'r2-vae1024': one of them; "
                                                "'r3-dit32' / 'r3-dit7b' / 'r3-refbf16': the round-3 fixtures")
     args = ap.parse_args()
+    if args.only.startswith("r6"):
+        return main_r6(args.only)
     if args.only.startswith("r4"):
         return main_r4(args.only)
     if args.only.startswith("r3"):
@@ -412,6 +414,72 @@ def main_r4(which):
         print("dit7b_36l_cfg1 reference fp32 forward %.0fs" % (time.time() - t0), tuple(out.shape), float(out.std()))
         torch.save({"out": out, "latent": (1, 32, 32), "seed_input": 50, "seed_weights": weights.SEED_WEIGHTS},
                    os.path.join(GOLD, "dit7b_36l_cfg1.pt"))
+
+
+# Round 6: BASELINE's own configurations end to end against the reference.
+# config 1 IN FULL: one image -> 256 x 256 (latent 1 x 32 x 32 -> 256 video + 58 text tokens), the reference's 32-layer SeedVR2-3B
+# NaDiT + full-width VAE, untiled, no temporal batching; same model seeds as PIPE_PROD so that the GPU tests share one 3B engine.
+PIPE_CFG1 = dict(frames=1, hw=(128, 128), resolution=256, batch_size=1, temporal_overlap=0, uniform_batch_size=False,
+                 seed_images=6, seed_dit=1234, seed_vae=1235, vae_channels=(128, 256, 512, 512), dit="DIT_3B")
+# config 2's GEOMETRY, untiled (attn_video_vae.py:1254-1300 slicing, :615-665 per-frame attention, causal_inflation_lib.py:354-409
+# per-frame GroupNorm): one 2048 x 2048 frame = GroupNorm groups over 4.2e6 pixels and 65 536-token mid-block attention, plus a
+# 5-frame 1024 x 1024 clip (two temporal slices through the causal memory, 16 384-token attention).  The 5 x 2048 x 2048 clip the
+# review named first needs ~10.7 GB per full-resolution fp32 activation of the reference on the 62 GB build box: not run.
+VAE_BIG = {"vae_untiled_2048": dict(frames=(1, 2048, 2048), latent=(1, 256, 256), seed_x=51, seed_z=52, cell=32),
+           "vae_untiled_1024x5": dict(frames=(5, 1024, 1024), latent=(2, 128, 128), seed_x=53, seed_z=54, cell=32)}
+
+
+def big_crops(H, W, size=96):
+    """(y, x) of 96 x 96 crops of a decoded frame: the four corners, the centre, three interior points."""
+    return [(0, 0), (0, W - size), (H - size, 0), (H - size, W - size), (H // 2 - size // 2, W // 2 - size // 2),
+            (H // 4, W // 3), (H // 3 * 2, W // 5), (H // 5, W // 3 * 2)]
+
+
+def main_r6(which):
+    import math
+    from oracle import reference_loader as rl
+    assert rl.available(), "needs /root/reference"
+    config = importlib.import_module(PKG + ".config")
+    weights = importlib.import_module(PKG + ".weights")
+    if which in ("r6", "r6-cfg1"):
+        from oracle import pipeline_oracle as po
+        pc = PIPE_CFG1
+        images = torch.rand(pc["frames"], pc["hw"][0], pc["hw"][1], 3, generator=torch.Generator().manual_seed(pc["seed_images"]))
+        text = weights.synth_text_embedding()
+        comps = reference_pipeline_components(rl, config, weights, text, case=pc)
+        t0 = time.time()
+        out = po.upscale(images, text.float(), comps, pc["batch_size"], pc["temporal_overlap"], pc["uniform_batch_size"])
+        print("pipeline_cfg1 fp32 %.1fs" % (time.time() - t0), tuple(out.shape), float(out.mean()), float(out.std()))
+        del comps
+        comps = reference_pipeline_components(rl, config, weights, text, dtype=torch.bfloat16, case=pc)
+        out_bf = po.upscale(images, text, comps, pc["batch_size"], pc["temporal_overlap"], pc["uniform_batch_size"],
+                            compute_dtype=torch.bfloat16)
+        mse = float((out_bf.double() - out.double()).pow(2).mean())
+        print("pipeline_cfg1 reference-bf16 twin: %.2f dB vs its fp32 self" % (10 * math.log10(1.0 / mse)))
+        del comps
+        torch.save({"out": out.clone(), "out_refbf16": out_bf.to(torch.bfloat16).clone(), **{k: v for k, v in pc.items()}},
+                   os.path.join(GOLD, "pipeline_cfg1.pt"))
+    for name, c in VAE_BIG.items():
+        if which not in ("r6", "r6-vaebig", "r6-" + name):
+            continue
+        vcfg = config.VAE_V3
+        sd = weights.synth_vae_state_dict(vcfg)
+        ref = rl.build_reference_vae({k: v.float() for k, v in sd.items()})
+        x = blocky_frames(*c["frames"], seed=c["seed_x"], cell=c["cell"])
+        z = latent_input(*c["latent"], seed=c["seed_z"])
+        t0 = time.time()
+        with torch.no_grad():
+            enc = ref.encode(x.float()).latent
+        print(name, "encode %.0fs" % (time.time() - t0), tuple(enc.shape), flush=True)
+        t0 = time.time()
+        with torch.no_grad():
+            dec = ref.decode(z.float()).sample
+        print(name, "decode %.0fs" % (time.time() - t0), tuple(dec.shape), flush=True)
+        crops = big_crops(dec.shape[-2], dec.shape[-1])
+        torch.save({"enc": enc.clone(), "dec_crops": torch.stack([dec[0, :, :, y:y + 96, xx:xx + 96] for (y, xx) in crops]),
+                    "crops": crops, "dec_mean": float(dec.mean()), "dec_std": float(dec.std()), **c,
+                    "seed_weights": weights.SEED_WEIGHTS + 1}, os.path.join(GOLD, name + ".pt"))
+        del ref, enc, dec
 
 
 if __name__ == "__main__":

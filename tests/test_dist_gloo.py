@@ -107,7 +107,9 @@ def _pipeline_worker(rank, world, port, q, noise=0.0, case=None, gather="all"):
     frames, kw = case or (23, dict(resolution=32, batch_size=7, uniform_batch_size=True, temporal_overlap=2, color_correction="wavelet"))
     images = torch.rand(frames, 16, 24, 3, generator=torch.Generator().manual_seed(5))
     out = d.upscale_sharded(images, _IdentityRunner(), torch.zeros(58, 8), input_noise_scale=noise, gather=gather, **kw)
-    q.put((rank, None if out is None else out.float()))
+    # (by value: a tensor in an mp.Queue travels as a shared-memory handle the parent must fetch while this process is still alive --
+    # under load the worker could exit first and the parent's q.get() died with FileNotFoundError)
+    q.put((rank, None if out is None else out.float().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -134,7 +136,7 @@ def test_sharded_pipeline_equals_single_rank_with_overlap_blend(world, noise):
         p.join(timeout=60)
         assert p.exitcode == 0
     for _, out in res:
-        assert out.shape == want.shape and torch.equal(out, want)
+        assert out.shape == want.shape and torch.equal(torch.from_numpy(out), want)
 
 
 CFG4_PLAN = (128, dict(resolution=32, batch_size=17, uniform_batch_size=True, temporal_overlap=1, color_correction="lab"))
@@ -167,4 +169,4 @@ def test_world8_cfg4_plan_equals_single_rank(gather):
         if gather == "root" and r != 0:
             assert out is None
         else:
-            assert out.shape == want.shape and torch.equal(out, want), r
+            assert out.shape == want.shape and torch.equal(torch.from_numpy(out), want), r

@@ -462,7 +462,7 @@ def _nccl_worker(rank, world, port, q):
     kw = dict(resolution=48, batch_size=5, uniform_batch_size=True, temporal_overlap=2, color_correction="lab")
     out = d.upscale_sharded(images, r, weights.synth_text_embedding().cuda(rank), **kw)
     want = pipeline.upscale(images, r, weights.synth_text_embedding().cuda(rank), **kw) if rank == 0 else None
-    q.put((rank, out.float().cpu(), None if want is None else want.float().cpu()))
+    q.put((rank, out.float().cpu().numpy(), None if want is None else want.float().cpu().numpy()))      # (by value: see tests/test_dist_gloo.py)
     _dist.barrier()
     _dist.destroy_process_group()
 
@@ -515,8 +515,9 @@ def test_two_gpu_rccl_sharded_pipeline_equals_single_gpu():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    import numpy as np
     want = res[0][1]
-    assert torch.equal(res[0][0], want) and torch.equal(res[1][0], want)
+    assert np.array_equal(res[0][0], want) and np.array_equal(res[1][0], want)
 
 
 # ------------------------------------------------------------------ colour correction on the device (§8f N3: all five modes)

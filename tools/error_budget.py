@@ -121,7 +121,8 @@ def quant_e4m3(x: torch.Tensor, mode: str) -> torch.Tensor:
 
 
 class Fp8DitOps(TorchOps):
-    """The product's storage regime (bf16 stores, fp32 stream) with the operands of the NaDiT's four big GEMMs per block (qkv,
+    """The product's storage regime (bf16 stores; the NaDiT's residual stream as NaDiTEngine defaults it -- h16 since round 5, or
+    what SVR_DIT_STREAM says: run_pipeline prints neither, so quote the default with the numbers) with the operands of the NaDiT's four big GEMMs per block (qkv,
     attn-out, mlp-in, mlp-out: every GEMM with K >= 2048 that sees the video tokens) rounded to e4m3 the way an fp8 MFMA path would
     have to: ``act`` / ``wgt`` in (None, "tensor", "row", "mx", "raw").  Arithmetic stays fp32 (the MFMA accumulates in fp32)."""
 
@@ -155,7 +156,7 @@ def run_vae17(rounded, g, sd, mg, **eng_kw):
     return rel_err(y, g["dec_tiled"][0]), psnr_nominal(y, g["dec_tiled"][0], 2.0)
 
 
-def run_pipeline(rounded, g, mg, dit_ops=None, **eng_kw):
+def run_pipeline(rounded, g, mg, dit_ops=None, vae_ops=None, **eng_kw):
     config, weights, dit, vae, runner, pipeline = (sub(n) for n in ("config", "weights", "dit", "vae", "runner", "pipeline"))
     dcfg, vcfg = getattr(config, g.get("dit", "DIT_TINY")), config.VAEConfig(block_out_channels=tuple(g["vae_channels"]))
     tile = (dict(encode_tiled=True, decode_tiled=True, encode_tile_size=tuple(g["vae_tile"]), decode_tile_size=tuple(g["vae_tile"]),
@@ -168,6 +169,8 @@ def run_pipeline(rounded, g, mg, dit_ops=None, **eng_kw):
     else:
         ops_v, ops_d = BudgetOps(rounded), BudgetOps(rounded)
         ops_d._dit = True
+    if vae_ops is not None:
+        ops_v = vae_ops
     r = runner.VideoDiffusionInfer(runner.default_config(dcfg, vcfg), **tile)
     dit_kw = {k: eng_kw.pop(k) for k in ("hid_fp32",) if k in eng_kw}
     r.dit = dit.NaDiTEngine(dcfg, weights.synth_dit_state_dict(dcfg, seed=g["seed_dit"]), ops_d, **dit_kw)
