@@ -191,6 +191,62 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def cpu_baseline_cfg1() -> dict:
+    """BASELINE config 1 IN FULL on this host's cores, in this run: the reference's own 32-layer NaDiT-3B (PyTorch-SDPA path, fp32) and
+    VideoAutoencoderKLWrapper -- from the checkout or oracle/_ref -- on the IDENTICAL workload the GPU leg of `--workload cfg1` times
+    (VAE encode of one 256 x 256 frame -> one-step DiT over the 1 x 32 x 32 latent + 58 text tokens -> VAE decode): 1 warm-up + median of
+    3 of the whole chain.  Not a sample and not an extrapolation: both legs of the line ran the same shapes.  Test infrastructure used
+    only as a reported baseline (generation_phases.py:171,542,807 make the same three runner calls per batch)."""
+    from oracle import reference_loader as rl
+    if not rl.available():
+        return {"value": None, "unit": "frames/s", "kind": "unavailable", "sample": "neither the reference checkout nor oracle/_ref is present"}
+    config, weights, flops = sub("config"), sub("weights"), sub("flops")
+    torch.set_num_threads(min(torch.get_num_threads(), usable_cores()))
+    cores = torch.get_num_threads()
+    dcfg, vcfg = config.DIT_3B, config.VAE_V3
+    t_build = time.perf_counter()
+    dsd = weights.synth_dit_state_dict(dcfg)
+    for k in list(dsd):                                  # (in place: 3.4e9 parameters are 13.6 GB in fp32)
+        dsd[k] = dsd[k].float()
+    ref_dit = rl.build_reference_dit(dcfg.as_dict(), dsd)
+    del dsd
+    ref_vae = rl.build_reference_vae({k: v.float() for k, v in weights.synth_vae_state_dict(vcfg).items()})
+    t_build = time.perf_counter() - t_build
+    g = torch.Generator().manual_seed(42)
+    x = torch.rand(1, 3, 1, 256, 256, generator=g) * 2 - 1
+    noise = torch.randn(1, 32, 32, 16, generator=g)
+    txt = weights.synth_text_embedding().float()
+    legs = {"vae_encode": [], "dit_32_layers": [], "vae_decode": []}
+
+    def chain(record):
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            lat = ref_vae.encode(x).latent                                            # [1, 16, 1, 32, 32]
+            t1 = time.perf_counter()
+            z = (lat[0].permute(1, 2, 3, 0) - vcfg.shifting_factor) * vcfg.scaling_factor        # infer.py:188
+            vid = torch.cat([noise, z, torch.ones_like(z[..., :1])], dim=-1)          # infer.py:54-78 task "sr"
+            v = ref_dit(vid=vid.reshape(-1, 33), txt=txt, vid_shape=torch.tensor([[1, 32, 32]]),
+                        txt_shape=torch.tensor([[txt.shape[0]]]), timestep=torch.tensor([1000.0])).vid_sample
+            x0 = noise - v.reshape(1, 32, 32, 16)                                     # one-step Euler endpoint (euler.py:60-63)
+            t2 = time.perf_counter()
+            zz = (x0 / vcfg.scaling_factor + vcfg.shifting_factor).permute(3, 0, 1, 2)[None]     # infer.py:236
+            ref_vae.decode(zz)
+            t3 = time.perf_counter()
+        if record:
+            legs["vae_encode"].append(t1 - t0); legs["dit_32_layers"].append(t2 - t1); legs["vae_decode"].append(t3 - t2)
+        return t3 - t0
+
+    chain(False)
+    total = statistics.median([chain(True) for _ in range(3)])
+    fv = flops.vae_flops_tiled(vcfg, 1, 256, 256, False)
+    f_all = fv["encode"] + fv["decode"] + flops.dit_flops(dcfg, (1, 16, 16))["total"]
+    return {"value": 1.0 / total, "unit": "frames/s", "cores": cores, "kind": "reference", "same_workload": True,
+            "cpu_tflops": f_all / total / 1e12, "timing": "1 warm-up + median of 3 whole chains",
+            "seconds": {"total": total, **{k: statistics.median(v) for k, v in legs.items()}, "model_build": t_build},
+            "sample": f"NOT a sample: the identical cfg1 workload (one 256x256 frame through VAE encode -> 32-layer NaDiT-3B -> VAE decode), "
+                      f"the reference's own model classes ({rl.kind()}), fp32, PyTorch-SDPA path, {cores} threads"}
+
+
 def cpu_baseline(flops_per_frame: float) -> dict:
     """The reference's CPU path timed on this host's cores on a bounded sample of the same pipeline: 1 warm-up + median of 3
     per leg, converted to the metric's unit through the algorithmic FLOP ratio (labelled extrapolation).
@@ -254,11 +310,17 @@ def cpu_baseline(flops_per_frame: float) -> dict:
     # BASELINE config 1 IN FULL (the reference's 32-layer NaDiT-3B + VAE on one 256 x 256 image): tools/cpu_cfg1_full.py, run once per
     # round on a GPU box's host and committed -- building 3.4e9 random fp32 parameters takes longer than this whole measurement
     cfg1_full = None
-    for name in ("r5_cpu_cfg1_full.json",):
+    for name in ("r6_bench_cfg1.json", "r5_cpu_cfg1_full.json"):
         try:
             one = json.load(open(os.path.join(ROOT, "profiles", name)))
-            cfg1_full = {"frames_per_s_cfg1": one["frames_per_s_cfg1"], "cpu_tflops": one["cpu_tflops"], "cores": one["cores"],
-                         "seconds": one["seconds"], "source": f"profiles/{name} (tools/cpu_cfg1_full.py on a GPU box's host; NOT timed in this run)"}
+            if "cpu_baseline" in one:                    # a committed `bench.py --workload cfg1` line: GPU and CPU legs of the SAME workload
+                cb = one["cpu_baseline"]
+                cfg1_full = {"frames_per_s_cfg1": cb["value"], "cpu_tflops": cb["cpu_tflops"], "cores": cb["cores"], "seconds": cb["seconds"],
+                             "gpu_frames_per_s_cfg1": one["value"],
+                             "source": f"profiles/{name} (bench.py --workload cfg1: both legs on one box in one run; NOT timed in this run)"}
+            else:
+                cfg1_full = {"frames_per_s_cfg1": one["frames_per_s_cfg1"], "cpu_tflops": one["cpu_tflops"], "cores": one["cores"],
+                             "seconds": one["seconds"], "source": f"profiles/{name} (tools/cpu_cfg1_full.py on a GPU box's host; NOT timed in this run)"}
             break
         except (OSError, KeyError, ValueError):
             continue
@@ -421,6 +483,14 @@ def main():
             first_print = fingerprint(out)
         del out
     sync()
+    # the matrix-pipe rate this device sustains under its power limit, measured HERE (svr_mfma_calibrate: a bare MFMA loop on random
+    # operands, ~0.25 s) right before and right after the timed region -- on every rank at the same time, so that node-level power /
+    # thermal coupling between the GPUs of one node shows up as a lower calibrated peak than the 1-GPU run's
+    if world > 1:
+        torch.distributed.barrier()
+    cal = [None, None]
+    if not double:
+        cal[0] = ops.mfma_calibrate()
     if world > 1:
         torch.distributed.barrier()
     ops.recording = True
@@ -434,6 +504,8 @@ def main():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     ops.recording = False
+    if not double:
+        cal[1] = ops.mfma_calibrate()
     # ---- output guards (after the timed region): a kernel that exits early, or a launch that was dropped, must not post a record.
     # (1) every value of the last step's output is finite; (2) its statistics sit in the band the REFERENCE's decoder produces
     # with these synthetic weights (tests/golden/vae_tile1024.pt records mean / std / min / max of the reference's fp32 decode
@@ -469,6 +541,7 @@ def main():
         sys.exit(3)
     del last_out
     n_ranks = 1
+    own_dt = dt
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -481,6 +554,15 @@ def main():
             for i, k in enumerate(("encode", "dit", "decode", "gather")):
                 phase[k] += ev[i].elapsed_time(ev[i + 1])
         phase = {k: v / args.steps for k, v in phase.items()}
+    # per-rank view of the same run (a multi-rank line that only carries the max-over-ranks wall time cannot show a straggler or a
+    # node that clocks all its GPUs down): every rank's phase times, own wall time and calibrated MFMA rate, gathered after the timing
+    own = [own_dt / args.steps * 1e3, phase["encode"], phase["dit"], phase["decode"], phase["gather"], cal[0] or 0.0, cal[1] or 0.0]
+    per_rank = [own]
+    if world > 1:
+        mine = torch.tensor(own, device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = [[float(v) for v in t.tolist()] for t in allr]
 
     if rank == 0:
         if sharded:        # 8 temporal batches of 17 frames (latent 5 x 270 x 480), tiled VAE
@@ -535,6 +617,14 @@ def main():
                 "timing_note": ("HIP events on the launch stream; with tile_streams > 1 another tile's kernels share the chip while "
                                 "a launch runs, so durations include that overlap (--tile-streams 1 isolates the kernel)")
                                if getattr(vae, "tile_streams", 1) > 1 else "HIP events on the launch stream",
+                # in-run calibration (svr_mfma_calibrate right before / after the timed region on this device): the bare-MFMA rate
+                # the power limit allows on random operands; `frac_of_power_limited` separates "this box clocks lower" from "the
+                # kernel got worse" inside the record itself (the nominal `frac` above cannot)
+                "power_limited_peak": None if cal[0] is None else {
+                    "tflops_before": cal[0], "tflops_after": cal[1], "tflops": min(cal), "unit": "TFLOP/s",
+                    "what": "bare v_mfma_f32_32x32x16_bf16 loop on random bf16 operands, 4 x 512 threads per CU, ~0.25 s, median of 3 "
+                            "(svr_mfma_calibrate), on this device in this run"},
+                "frac_of_power_limited": None if cal[0] is None else c_flops / max(c_sec, 1e-12) / 1e12 / min(cal),
                 "launches": c_n, "avg_launch_us": c_sec / max(c_n, 1) * 1e6,
                 "algorithmic_flops_per_launch": c_flops / max(c_n, 1),
                 "share_of_step_time": c_sec / max(dt, 1e-12),
@@ -565,29 +655,48 @@ def main():
             "vae_tile_streams": getattr(vae, "tile_streams", 1),
             "output_guard": guard,
         }
-        # DESIGN.md section 6's falsifiable prediction for THIS launch: compute is perfectly parallel over ranks, communication =
-        # direct xGMI transfers at ~64 GB/s per direction and link.  The compute term is THIS run's own measurement wherever the run
-        # has one (weak scaling: rank 0's encode + DiT + decode events), so what the line predicts is the communication.
+        # DESIGN.md section 6's prediction for THIS launch, made falsifiable: the compute term is A PRIORI -- the committed 1-GPU line of
+        # the same workload (profiles/), never this run's own timings -- plus the communication model (direct xGMI transfers at
+        # ~64 GB/s per direction and link).  What this run measured is reported next to it, with the difference.
         if world > 1 or sharded:
             frame_bytes = H * W * 3 * (4 if sharded else 2)      # (the pipeline's frames are fp32, the runner's decode output bf16)
+            one_gpu_s, src = None, None
+            for name in ((f"r6_bench_{args.workload}_1gpu.json", f"r5_bench_{args.workload}_1gpu.json", f"r4_bench_{args.workload}_1gpu.json")
+                         if sharded else (f"r6_bench_{args.workload}.json", f"r5_bench_{args.workload}.json")):
+                try:
+                    one = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    one_gpu_s, src = float(one["ms_per_step"]) / 1e3, f"profiles/{name}"
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
             if sharded:
-                n_b, per_batch_s, src = len(plans), 41.2 / 8, "41.2 s / 8 on one GPU, profiles/r4_bench_cfg4_1gpu.json"
-                for name in ("r5_bench_cfg4_1gpu.json", "r4_bench_cfg4_1gpu.json"):      # the newest committed 1-GPU line of this workload
-                    try:
-                        one = json.load(open(os.path.join(ROOT, "profiles", name)))
-                        per_batch_s, src = float(one["ms_per_step"]) / 1e3 / 8, f"{one['ms_per_step'] / 1e3:.1f} s / 8 on one GPU, profiles/{name}"
-                        break
-                    except (OSError, KeyError, ValueError):
-                        continue
+                n_b = len(plans)
+                per_batch_s = (one_gpu_s if one_gpu_s is not None else 41.2) / 8
                 comm = (frames * frame_bytes / max(world, 1)) / 64e9 + 0.001 * (n_b - 1)
-                res["predicted_s"] = {"per_step": math.ceil(n_b / world) * per_batch_s + (comm if world > 1 else 0.0),
-                                      "model": f"ceil({n_b} batches / {world} ranks) x {per_batch_s:.2f} s per batch ({src}) "
-                                               "+ gather of the clip over xGMI"}
+                pred = math.ceil(n_b / world) * per_batch_s + (comm if world > 1 else 0.0)
+                model = (f"ceil({n_b} batches / {world} ranks) x {per_batch_s:.2f} s per batch (the committed 1-GPU line {src}: "
+                         f"a priori) + gather of the clip over xGMI")
             else:
-                compute_s = (phase["encode"] + phase["dit"] + phase["decode"]) / 1e3
-                res["predicted_s"] = {"per_step": compute_s + useful * frame_bytes / 64e9 + 0.003,
-                                      "model": "this run's own encode + DiT + decode (rank 0, HIP events) + all-gather: each link carries "
-                                               "one rank's frames once at 64 GB/s"}
+                comm = useful * frame_bytes / 64e9 + 0.003
+                pred = None if one_gpu_s is None else one_gpu_s + (comm if world > 1 else 0.0)
+                model = (f"the committed 1-GPU step of this workload ({src}: a priori, not this run's timings) + all-gather: each link "
+                         "carries one rank's frames once at 64 GB/s")
+            res["predicted_s"] = {"per_step": pred, "model": model, "comm_s_model": comm if world > 1 else 0.0,
+                                  "measured_per_step": dt / args.steps,
+                                  "measured_minus_predicted_s": None if pred is None else dt / args.steps - pred,
+                                  "own_run_compute_s_rank0": None if sharded else (phase["encode"] + phase["dit"] + phase["decode"]) / 1e3}
+        if world > 1:
+            cols = ("step_ms", "encode_ms", "dit_ms", "decode_ms", "gather_ms", "mfma_calibrated_tflops_before", "mfma_calibrated_tflops_after")
+            stats = {}
+            for j, cname in enumerate(cols):
+                col = [r[j] for r in per_rank]
+                stats[cname] = {"min": min(col), "median": statistics.median(col), "max": max(col),
+                                "argmax_rank": col.index(max(col)), "argmin_rank": col.index(min(col))}
+            res["ranks"] = {"n": len(per_rank), "stats": stats,
+                            "note": "per-rank wall time per step, phase times (HIP events on each rank's launch stream) and the bare-MFMA rate "
+                                    "each device sustained right before / after the timed region, all ranks calibrating at the same time: a "
+                                    "straggler shows as argmax_rank of step_ms, node-level power coupling as calibrated rates below the 1-GPU "
+                                    "line's roofline.power_limited_peak"}
         if not sharded:
             dit_tf = f_dit["total"] / max(phase["dit"], 1e-9) / 1e9
             res.update({"dit_ms_per_step": phase["dit"], "vae_encode_ms": phase["encode"], "vae_decode_ms": phase["decode"],
@@ -598,7 +707,8 @@ def main():
             res.update(test_mode=True, data="synthetic; TEST MODE (--cpu-double): torch double of the C ABI on CPU ranks over gloo, "
                                             "reduced-width models -- plumbing only, the numbers mean nothing")
         if not args.no_cpu_baseline and world == 1 and not double:      # (the CPU leg is a 1-GPU line item: the other ranks would idle at the barrier)
-            res["cpu_baseline"] = cpu_baseline(f_step / frames_per_step * (world if not sharded else 1))
+            res["cpu_baseline"] = (cpu_baseline_cfg1() if args.workload == "cfg1" else
+                                   cpu_baseline(f_step / frames_per_step * (world if not sharded else 1)))
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()

@@ -14,6 +14,7 @@
 #include "svr_attn_win.hip"
 #include "svr_attn.hip"
 #include "svr_elementwise.hip"
+#include "svr_calibrate.hip"
 
 using namespace svr;
 
@@ -41,6 +42,18 @@ int svr_abi_version(void) { return SVR_ABI_VERSION; }
 static const char g_build_id[] = "SVR_BUILD_ID=" SVR_BUILD_ID;
 const char* svr_build_id(void) { return g_build_id + 13; }
 
+
+int64_t svr_mfma_calibrate_workspace_bytes(void) { return (int64_t)device_cu_count() * 4 * 512 * (int64_t)sizeof(float); }
+
+int svr_mfma_calibrate(void* workspace, int32_t iters, double* flops, void* stream) {
+    StreamDeviceGuard on_stream_device(stream);
+    if (!workspace || iters <= 0) return fail("svr_mfma_calibrate: workspace of svr_mfma_calibrate_workspace_bytes() and iters > 0");
+    const unsigned grid = (unsigned)device_cu_count() * 4;
+    hipLaunchKernelGGL(mfma_calibrate_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, (float*)workspace, iters);
+    // 8 waves per workgroup, 16 MFMAs of 2 * 32 * 32 * 16 FLOP per wave and iteration
+    if (flops) *flops = (double)grid * 8.0 * 16.0 * (2.0 * 32 * 32 * 16) * (double)iters;
+    return check(hipGetLastError(), "svr_mfma_calibrate");
+}
 
 int svr_set_option(const char* key, int32_t value) {
     if (!key) return fail("svr_set_option: null key");

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(C4_NT, 1) void conv_thinout4_kernel(const svr_gemm_
     };
 
     // ---- the resident weights: unit u = (slice * kt + dt) * 9 + tap holds cout rows 0..3 x 32 channels (4 x 64 B); LDS slot id =
-    // piece * 256 + tid -> (u = id >> 4, n = (id >> 2) & 3, chunk = id & 3).  W is [n][K = (dt, dy, dx, c)] and padded to >= 4 rows.
+    // piece * 256 + tid -> (u = id >> 4, n = (id >> 2) & 3, chunk = id & 3).  W is [n][K = (dt, dy, dx, c)], N <= 4 rows.
     {
         const int units = cpk * kt * 9;
         const int wpieces = (units * 16 + C4_NT - 1) / C4_NT;
@@ -305,8 +305,9 @@ __global__ __launch_bounds__(C4_NT, 1) void conv_thinout4_kernel(const svr_gemm_
             const int id = p * C4_NT + tid;
             const int u = id >> 4, n = (id >> 2) & 3, ck = id & 3;
             const int sl = u / (kt * 9), dtap = u - sl * (kt * 9);
-            const bf16_t* src = u < units ? (const bf16_t*)a.W + (int64_t)n * a.K + (int64_t)dtap * g.Cin + sl * 32 + ck * 8
-                                          : (const bf16_t*)g.zeros;
+            // (rows n >= N of the 4-row unit come from the zero page: W needs no row padding here, a [3, K] weight is read as is)
+            const bf16_t* src = u < units && n < a.N ? (const bf16_t*)a.W + (int64_t)n * a.K + (int64_t)dtap * g.Cin + sl * 32 + ck * 8
+                                                     : (const bf16_t*)g.zeros;
             glds16(src, wave_dst + C4_WOFF + p * 4096);
         }
     }

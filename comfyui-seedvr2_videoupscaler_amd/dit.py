@@ -267,7 +267,8 @@ class NaDiTEngine:
         """vid [T, H, W, 33] bf16 (x_t || condition), txt [Lt, txt_in_dim] bf16.
         Returns the model prediction [T, H, W, 16]; with ``x_t`` given returns the one-step Euler
         endpoint x_t - pred instead (fused into the un-patchify kernel)."""
-        out = self._forward(vid, txt, timestep, x_t)
+        out = self._forward(vid, txt, timestep, x_t, self.hid_dtype)
+        # the guard is an h16 affair: an fp32 / bf16 stream returns without looking (no reduction, no host sync)
         if self.hid_store != "h16" or not self.overflow_guard or bool(torch.isfinite(out.sum(dtype=torch.float32))):
             return out
         import warnings
@@ -278,15 +279,12 @@ class NaDiTEngine:
             return out
         warnings.warn("NaDiTEngine: non-finite output with an h16 residual stream (an activation beyond +-4.2e6?); repeating the call "
                       "with an fp32 stream", RuntimeWarning, stacklevel=2)
-        saved = (self.hid_store, self.hid_dtype)
-        self.hid_store, self.hid_dtype = "fp32", torch.float32
         self.overflow_reruns += 1
-        try:
-            return self._forward(vid, txt, timestep, x_t)
-        finally:
-            self.hid_store, self.hid_dtype = saved
+        # (the store kind travels as an argument: the engine's own state is not touched, so a concurrent or re-entrant call on the
+        # same engine keeps its h16 stream)
+        return self._forward(vid, txt, timestep, x_t, torch.float32)
 
-    def _forward(self, vid, txt, timestep, x_t):
+    def _forward(self, vid, txt, timestep, x_t, hid_dtype):
         cfg, ops = self.cfg, self.ops
         d, heads, hd = cfg.vid_dim, cfg.heads, cfg.head_dim
         inner = heads * hd
@@ -297,7 +295,7 @@ class NaDiTEngine:
         R = N + Lt
         eps = cfg.norm_eps
 
-        hid = ops.empty(R, d, dtype=self.hid_dtype)
+        hid = ops.empty(R, d, dtype=hid_dtype)
         hf = hid.dtype in (torch.float32, torch.float16)     # a WIDE stream (fp32 or h16): the ops derive the kind from the dtype
         a0 = ops.empty(N, self.kpad_in)
         ops.patchify(vid.contiguous(), a0)

@@ -19,7 +19,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                "-mllvm", "-pragma-unroll-threshold=1000000"]
 
 EPI_BIAS, EPI_BIAS_SILU, EPI_RESID_GATE, EPI_SWIGLU, EPI_BIAS_GELU = 0, 1, 2, 3, 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 # svr_gemm_kernel_class() codes (include/seedvr2_hip.h)
 KERNEL_CLASSES = {0: "none", 1: "gemm", 2: "gemm_persistent", 3: "conv_halo", 4: "conv_subpixel", 5: "conv_thin_in",
                   6: "conv_thinout", 7: "conv_generic"}
@@ -89,6 +89,8 @@ SYMBOLS = {
     "svr_blend_finalize": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _f, _vp]),
     "svr_affine_slice": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _f, _f, _vp]),
     "svr_set_option": (C.c_int, [C.c_char_p, _i32]),
+    "svr_mfma_calibrate_workspace_bytes": (C.c_int64, []),
+    "svr_mfma_calibrate": (C.c_int, [_vp, _i32, C.POINTER(C.c_double), _vp]),
     "svr_last_error": (C.c_char_p, []),
     "svr_abi_version": (C.c_int, []),
     "svr_build_id": (C.c_char_p, []),

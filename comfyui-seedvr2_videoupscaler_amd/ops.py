@@ -208,6 +208,28 @@ class HipOps:
             raise ValueError(f"{name} must hold {numel} elements, got {tuple(t.shape)}")
         return C.c_void_p(t.data_ptr())
 
+    def mfma_calibrate(self, seconds: float = 0.25, reps: int = 3) -> float:
+        """Measurement aid (svr_mfma_calibrate; never on the data path): TFLOP/s of a bare MFMA loop on this device right now =
+        the matrix-pipe rate its power limit allows.  A short launch sizes the iteration count for ``seconds``, then the median of
+        ``reps`` launches timed with events on the current stream is returned."""
+        with torch.cuda.device(self.device):
+            ws = torch.empty(int(self.lib.svr_mfma_calibrate_workspace_bytes()), dtype=torch.uint8, device=self.device)
+            flops = C.c_double(0.0)
+
+            def run(iters):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                hip_lib.check(self.lib.svr_mfma_calibrate(C.c_void_p(ws.data_ptr()), int(iters), C.byref(flops), self._stream()),
+                              "svr_mfma_calibrate")
+                e.record()
+                e.synchronize()
+                return flops.value / (s.elapsed_time(e) * 1e-3) / 1e12
+
+            run(2000)                                            # (first launch: code-object load)
+            rate = run(20000)
+            iters = max(2000, int(20000 * seconds / (flops.value / (rate * 1e12))))
+            return sorted(run(iters) for _ in range(reps))[reps // 2]
+
     def set_option(self, key: str, value: int):
         """Tuning / measurement knob of the library (see svr_set_option in include/seedvr2_hip.h)."""
         hip_lib.check(self.lib.svr_set_option(key.encode(), int(value)), "svr_set_option")

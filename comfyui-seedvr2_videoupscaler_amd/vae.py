@@ -119,11 +119,13 @@ def _cos_ramp(n: int) -> Optional[torch.Tensor]:
 
 class VideoVAEEngine:
     def __init__(self, cfg: VAEConfig, state_dict: Dict[str, torch.Tensor], ops,
-                 act_budget_bytes: int = 24 << 30, merge_upsamplers: bool = True, merge_causal_head: bool = True,
+                 act_budget_bytes: Optional[int] = None, merge_upsamplers: bool = True, merge_causal_head: bool = True,
                  trunk_fp32: Optional[bool] = None, branch_fp32: Optional[bool] = None, tile_streams: int = 1,
                  trunk_store: Optional[str] = None, branch_store: Optional[str] = None, overflow_guard: bool = True):
-        """``act_budget_bytes`` (default 24 GiB; env SVR_VAE_ACT_BUDGET_GIB for A/B runs): bound on the widest activation of one
-        temporal slice, from which encode_clip / decode_clip derive the slice length (results do not depend on it, bit for bit).
+        """``act_budget_bytes``: bound on the widest activation of one temporal slice, from which encode_clip / decode_clip derive the
+        slice length (results do not depend on it, bit for bit).  An explicit argument wins; ``None`` (default) takes env
+        SVR_VAE_ACT_BUDGET_GIB (A/B runs; validated) or else 24 GiB, clamped to 1/8 of the device's free memory divided by
+        ``tile_streams`` (the peak of a slice is several times its widest activation; a smaller HBM partition must not OOM).
         24 GiB = the 9 latents (33 frames) of a 1024-px decoder tile in ONE slice: no carried-frame copies between slices, no second
         set of launches; same box, BASELINE config 3: decode 5 146 / 5 172 ms at 12 GiB (two slices) -> 5 129 / 5 153 ms
         (profiles/r5_vae_slice_budget_ab.txt); 48 GiB changes nothing further.  Peak memory of the config-3 step stays far below 288 GB.
@@ -172,10 +174,8 @@ class VideoVAEEngine:
         self.overflow_guard = bool(overflow_guard)
         self.overflow_reruns = 0            # calls the guard had to repeat with fp32 stores
         self.device = ops.device
-        self.act_budget_bytes = act_budget_bytes
-        if os.environ.get("SVR_VAE_ACT_BUDGET_GIB"):       # A/B runs: temporal slice size of encode_clip / decode_clip
-            self.act_budget_bytes = int(float(os.environ["SVR_VAE_ACT_BUDGET_GIB"]) * (1 << 30))
         self.tile_streams = int(tile_streams)
+        self.act_budget_bytes = self._resolve_act_budget(act_budget_bytes, ops.device, self.tile_streams)
         self.sample_dtype = None            # tools/error_budget.py only (CPU double): dtype of the decoder's own output tile; the HIP
                                             # blend kernels take bf16 tiles, so the product leaves it at None (measured: +0.1 dB for fp32)
         self._streams = []
@@ -717,6 +717,29 @@ class VideoVAEEngine:
         x = torch.zeros(T, H, W, 4, dtype=self.ops.act_dtype, device=self.device)
         x[..., :Cc] = x_cthw.to(device=self.device, dtype=self.ops.act_dtype).permute(1, 2, 3, 0)   # layout only
         return x
+
+    @staticmethod
+    def _resolve_act_budget(explicit: Optional[int], device, tile_streams: int) -> int:
+        """explicit argument > env SVR_VAE_ACT_BUDGET_GIB > 24 GiB clamped to free device memory / 8 / tile_streams."""
+        if explicit is not None:
+            if int(explicit) <= 0:
+                raise ValueError(f"act_budget_bytes must be positive, got {explicit}")
+            return int(explicit)
+        env = os.environ.get("SVR_VAE_ACT_BUDGET_GIB")
+        if env:
+            try:
+                gib = float(env)
+            except ValueError:
+                raise ValueError(f"SVR_VAE_ACT_BUDGET_GIB must be a number of GiB, got {env!r}") from None
+            if not (gib > 0 and math.isfinite(gib)):
+                raise ValueError(f"SVR_VAE_ACT_BUDGET_GIB must be positive and finite, got {env!r}")
+            return int(gib * (1 << 30))
+        budget = 24 << 30
+        dev = torch.device(device)
+        if dev.type == "cuda" and torch.cuda.is_available():
+            free, _total = torch.cuda.mem_get_info(dev)
+            budget = min(budget, max(1 << 30, int(free) // 8 // max(1, int(tile_streams))))
+        return budget
 
     def _guarded(self, call, inp: torch.Tensor):
         """Run ``call()``; if its result is not finite although its input ``inp`` was, and an h16 store is in use, once more with

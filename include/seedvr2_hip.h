@@ -22,8 +22,10 @@ extern "C" {
 /* v8 (round 5): svr_rmsnorm_mod takes SVR_STORE_H16 inputs; svr_gemm_bf16's persistent kernel serves the two h16 forms of the NaDiT's
  * residual stream (bias -> h16; gate * (acc + bias) + h16 residual -> h16); svr_qknorm_rope / svr_groupnorm_apply refuse NULL weights;
  * svr_set_option keys "gemm_asym", "gn_grid_cap", attn_variant 5..10 and gemm_w4r = 2 are gone (measured, deleted); "conv_thinout16" became "conv_thinout4" (1 default: N <= 4 thin-output
- * convs on conv_thinout4_kernel, 0: on the 32-cout kernel).  No signature changed. */
-#define SVR_ABI_VERSION 8
+ * convs on conv_thinout4_kernel, 0: on the 32-cout kernel).  No signature changed.
+ * v9 (round 6): + svr_mfma_calibrate() / svr_mfma_calibrate_workspace_bytes() (measurement aid, not on the data path); a thin-output
+ * conv with N <= 4 couts accepts an exact [N, K] weight (the 4-row units take rows >= N from the zero page).  No signature changed. */
+#define SVR_ABI_VERSION 9
 
 /* ---- GEMM / implicit-GEMM convolution epilogues ------------------------------------------ */
 /* Storage kinds of activation tensors that are NOT MFMA operands (svr_gemm_args.out_f32 / .resid_f32, the x_f32 arguments).
@@ -271,6 +273,13 @@ int svr_affine_slice(const void* in, void* out, int64_t rows, int32_t c_in, int3
  * s_setprio builds -- see svr_attn_win.hip),
  * "pipe_abl" measurement-only ablations in -DSVR_ABLATIONS builds (non-zero values give garbage). */
 int svr_set_option(const char* key, int32_t value);
+/* Calibration aid, NOT on the data path (ABI v9; the reference has no counterpart -- its timing report is src/utils/debug.py): launches
+ * a bare v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands, four 512-thread workgroups per CU, `iters` x 16 MFMAs per wave, no
+ * memory traffic, on `stream`; `*flops` (if not NULL) receives the FLOPs the launch executes.  The caller times it with events on the
+ * same stream: FLOPs / time is the matrix-pipe rate this device sustains under its power limit at that moment (bench.py reports it
+ * as roofline.power_limited_peak next to the nominal 2.5 PFLOP/s).  `workspace`: svr_mfma_calibrate_workspace_bytes() of device memory. */
+int64_t svr_mfma_calibrate_workspace_bytes(void);
+int svr_mfma_calibrate(void* workspace, int32_t iters, double* flops, void* stream);
 const char* svr_last_error(void);
 int svr_abi_version(void);
 /* hex SHA-256 of the sources (every .hip and .h file under csrc/ and this header; sorted by name) AND the compile configuration (hipcc flags

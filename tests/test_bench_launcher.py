@@ -42,7 +42,11 @@ def test_two_ranks_weak_scaling_line():
     # two ranks, each its own 4-frame share (5 padded frames, 4 kept), frames / max-over-ranks time
     assert abs(res["value"] - 2 * 4 * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"])) < 1e-6 * res["value"]
     p = res["predicted_s"]
-    assert p["per_step"] > 0 and "this run's own" in p["model"]
+    assert p["per_step"] > 0 and "a priori" in p["model"] and p["measured_per_step"] > 0 and "measured_minus_predicted_s" in p
+    r = res["ranks"]                                       # per-rank min / median / max of the step and its phases
+    assert r["n"] == 2 and set(r["stats"]) >= {"step_ms", "encode_ms", "dit_ms", "decode_ms", "gather_ms"}
+    assert r["stats"]["step_ms"]["min"] <= r["stats"]["step_ms"]["median"] <= r["stats"]["step_ms"]["max"]
+    assert r["stats"]["step_ms"]["argmax_rank"] in (0, 1)
     assert "cpu_baseline" not in res                       # a 1-GPU line item
 
 

@@ -104,6 +104,32 @@ def test_dit_3b_full_depth_multiwindow_vs_reference_golden(hip):
     assert e < 1.0e-2 and p > 55
 
 
+def test_pipeline_cfg1_in_full_vs_reference_golden(hip):
+    """BASELINE config 1 IN FULL, end to end against the reference (round 6): one 128 x 128 image -> 256 x 256 through the whole
+    chain -- input transform, UNTILED VAE encode (latent 1 x 32 x 32), the 32-layer SeedVR2-3B NaDiT over 256 video + 58 text tokens,
+    one Euler step, VAE decode, LAB colour fix -- golden = the reference's own model classes and glue in fp32, plus the reference's
+    own bf16 run (oracle/make_golden.py --only r6-cfg1).  infer.py:117,203,315; generation_phases.py:171,542,807,1060."""
+    from oracle import make_golden as mg
+    config, weights, vae, runner, pipeline = (sub(n) for n in ("config", "weights", "vae", "runner", "pipeline"))
+    g = _golden("pipeline_cfg1.pt")
+    dcfg, vcfg = getattr(config, g["dit"]), config.VAEConfig(block_out_channels=tuple(g["vae_channels"]))
+    assert dcfg is config.DIT_3B and vcfg.block_out_channels == config.VAE_V3.block_out_channels
+    r = runner.VideoDiffusionInfer(runner.default_config(dcfg, vcfg))
+    r.dit = _dit3b_engine(hip, g["seed_dit"])
+    r.vae = vae.VideoVAEEngine(vcfg, weights.synth_vae_state_dict(vcfg, seed=g["seed_vae"]), hip)
+    images = torch.rand(g["frames"], g["hw"][0], g["hw"][1], 3, generator=torch.Generator().manual_seed(g["seed_images"]))
+    out = pipeline.upscale(images.cuda(), r, weights.synth_text_embedding().cuda(), resolution=g["resolution"],
+                           batch_size=g["batch_size"], uniform_batch_size=g["uniform_batch_size"],
+                           temporal_overlap=g["temporal_overlap"], color_correction="lab",
+                           noise_provider=mg.pipeline_noise).float().cpu()
+    assert out.shape == g["out"].shape == (1, 256, 256, 3)
+    p, e = _psnr_unit(out, g["out"]), rel_err(out, g["out"])
+    p_ref = _psnr_unit(g["out_refbf16"].float(), g["out"])
+    print(f"BASELINE config 1 in full (256x256 image, 3B x 32 layers + full VAE) vs the reference chain: PSNR {p:.1f} dB at the nominal "
+          f"peak, rel-err {e:.3e}; the reference chain in bf16 on the same input: {p_ref:.1f} dB")
+    assert p >= 50.0 and p >= p_ref
+
+
 def test_pipeline_production_width_and_depth_vs_reference_golden(hip):
     """The WHOLE chain at production width and depth (round 4): the reference's own four phases
     (generation_phases.py:171,542,807,1060, restated by oracle/pipeline_oracle.py and pinned to the phase text by
@@ -289,6 +315,50 @@ def test_vae_real_tile_size_strip_vs_reference_golden(hip):
           f"{pn:.1f} dB (nominal peak 2.0)")
     assert e < 2.5e-2 and p > 50 and pn >= 50.0        # (round 2, bf16 trunk: 50.3 dB)
     assert abs(float(y.mean()) - g["dec_mean"]) < 5e-3 and abs(float(y.std()) - g["dec_std"]) < 5e-3
+
+
+@pytest.mark.parametrize("name", ["vae_untiled_2048", "vae_untiled_1024x5"])
+def test_vae_untiled_cfg2_geometry_vs_reference_golden(hip, name):
+    """BASELINE config 2's GEOMETRY against the reference itself (round 6; before, this size was checked per op against this repo's own
+    torch restatement only): the UNTILED VAE on one 2048 x 2048 frame -- per-frame GroupNorm groups over 4.2e6 pixels
+    (causal_inflation_lib.py:354-409), 65 536-token mid-block attention (attn_video_vae.py:615-665) -- and on a 5-frame 1024 x 1024
+    clip (two temporal slices through the reference's causal memory, attn_video_vae.py:1254-1300; 16 384-token attention).  Goldens
+    from the imported reference in fp32 (oracle/make_golden.py --only r6-vaebig; 28 / 25 CPU-minutes); encode compared whole, decode
+    on eight 96 x 96 crops (corners, centre, interior) plus the mean / std of the whole output."""
+    from oracle import make_golden as mg
+    config, weights, vae = sub("config"), sub("weights"), sub("vae")
+    g = _golden(name + ".pt")
+    cfg = config.VAE_V3
+    eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg, seed=g["seed_weights"]), hip)
+    x = mg.blocky_frames(*g["frames"], seed=g["seed_x"], cell=g["cell"])[0].cuda()
+    lat = eng.encode(x).float().cpu()
+    lat = lat[None] if lat.dim() == 3 else lat
+    want = g["enc"][0].permute(1, 2, 3, 0) * cfg.scaling_factor
+    e, p = rel_err(lat, want), psnr(lat, want)
+    print(f"{name}: untiled VAE encode {tuple(g['frames'])}: rel-err {e:.3e}, PSNR {p:.1f} dB")
+    assert lat.shape == want.shape and e < 2.5e-2 and p > 50
+    del x
+    z = (mg.latent_input(*g["latent"], seed=g["seed_z"])[0].permute(1, 2, 3, 0).float() * cfg.scaling_factor).to(BF16).cuda()
+    y = eng.decode(z).float().cpu()
+    y = y.unsqueeze(1) if y.dim() == 3 else y                                        # [3, T, H, W]
+    assert y.shape == (3,) + tuple(g["frames"])
+    got = torch.stack([y[:, :, yy:yy + 96, xx:xx + 96] for (yy, xx) in g["crops"]])
+    e, p, pn = rel_err(got, g["dec_crops"]), psnr(got, g["dec_crops"]), psnr_nominal(got, g["dec_crops"])
+    print(f"{name}: untiled VAE decode (8 crops): rel-err {e:.3e}, PSNR {p:.1f} dB (own range), {pn:.1f} dB (nominal peak 2.0)")
+    assert e < 2.5e-2 and p > 50 and pn >= 50.0
+    assert abs(float(y.mean()) - g["dec_mean"]) < 5e-3 and abs(float(y.std()) - g["dec_std"]) < 5e-3
+
+
+@pytest.mark.parametrize("level", ["tail", "overflow"])
+def test_heavy_tail_checkpoint_statistics_on_the_hip_path(hip, level):
+    """Round 6: the h16 regime and its overflow guards on weights with outlier channels (x300 in the NaDiT's residual stream),
+    GroupNorm gains / modulation scales over three decades, O(1) biases, a 10x conv and e4m3-valued matrices, against the reference's
+    fp32 run (yardstick: the reference's own bf16 run).  "tail": guards silent, engine error <= reference-bf16 error.  "overflow": the
+    stream / trunk leaves h16's range -> the guard re-runs the call with fp32 stores ON THE HIP PATH, warns, and the result still
+    matches.  Bodies shared with the CPU-double test (tests/heavy_tail_cases.py)."""
+    import heavy_tail_cases as ht
+    ht.dit_case(hip, level)
+    ht.vae_case(hip, level)
 
 
 def test_vae_temporal_slicing_invariance(hip):

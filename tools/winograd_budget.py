@@ -128,20 +128,35 @@ class WinoOps(TorchOps):
         return (out, None) if gn_groups > 0 else out
 
 
+def run_vae17(g, mg, ops):
+    """decode of tests/golden/vae_tiled17.pt (17 frames 96 x 160, tiled 64 / 32: every decoder conv, seconds of CPU)."""
+    config, weights, vae = eb.sub("config"), eb.sub("weights"), eb.sub("vae")
+    cfg = config.VAE_V3
+    eng = vae.VideoVAEEngine(cfg, weights.synth_vae_state_dict(cfg, seed=g["seed_weights"]), ops)
+    kw = dict(tiled=True, tile_size=tuple(g["tile_size"]), tile_overlap=tuple(g["tile_overlap"]))
+    z = (mg.latent_input(*g["latent"], seed=g["seed_z"])[0].permute(1, 2, 3, 0).float() * cfg.scaling_factor).to(BF16)
+    y = eng.decode(z, **kw).float()
+    return eb.rel_err(y, g["dec_tiled"][0]), eb.psnr_nominal(y, g["dec_tiled"][0], 2.0)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--fixture", default="pipeline_prod")
+    ap.add_argument("--fixture", default="pipeline_prod", help="pipeline_prod | pipeline_small | vae_tiled17 (decode only, fast)")
     ap.add_argument("--rows", default="direct,spatial,temporal")
     ap.add_argument("--kinds", default="bf16,fp16,fp32")
     args = ap.parse_args()
     from oracle import make_golden as mg
     g = torch.load(os.path.join(GOLDEN, args.fixture + ".pt"), weights_only=True)
-    e, p = eb.run_pipeline(None, g, mg)
-    print(f"{args.fixture:14s} shipped regime (TorchOps, bf16 operands)                      rel-err {e:.3e}  PSNR(nominal) {p:6.2f} dB", flush=True)
+    if args.fixture.startswith("pipeline"):
+        run = lambda ops: eb.run_pipeline(None, g, mg, vae_ops=ops)
+    else:
+        run = lambda ops: run_vae17(g, mg, ops if ops is not None else TorchOps("cpu", act_dtype=BF16))
+    e, p = run(None)
+    print(f"{args.fixture:14s} shipped regime (TorchOps, bf16 operands)                               rel-err {e:.3e}  PSNR(nominal) {p:6.2f} dB", flush=True)
     for mode in args.rows.split(","):
         for kind in args.kinds.split(","):
             ops = WinoOps(mode, kind)
-            e, p = eb.run_pipeline(None, g, mg, vae_ops=ops)
+            e, p = run(ops)
             print(f"{args.fixture:14s} {mode:8s} operands {kind:5s} ({ops.hits:4d} convs, multiply-adds x{ops.macs_done / max(ops.macs_direct, 1):.3f})"
                   f"   rel-err {e:.3e}  PSNR(nominal) {p:6.2f} dB", flush=True)
 
