@@ -221,7 +221,8 @@ def cpu_baseline_cfg1() -> dict:
     def chain(record):
         with torch.no_grad():
             t0 = time.perf_counter()
-            lat = ref_vae.encode(x).latent                                            # [1, 16, 1, 32, 32]
+            lat = ref_vae.encode(x).latent
+            lat = lat.unsqueeze(2) if lat.dim() == 4 else lat                        # (a one-frame clip comes back as an image) [1, 16, 1, 32, 32]
             t1 = time.perf_counter()
             z = (lat[0].permute(1, 2, 3, 0) - vcfg.shifting_factor) * vcfg.scaling_factor        # infer.py:188
             vid = torch.cat([noise, z, torch.ones_like(z[..., :1])], dim=-1)          # infer.py:54-78 task "sr"

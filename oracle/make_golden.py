@@ -227,7 +227,8 @@ def reference_pipeline_components(rl, config, weights, txt, dtype=torch.float32,
 
     def vae_encode(x_cthw):                            # infer.py:117-199
         with torch.no_grad():
-            lat = vae.encode(x_cthw[None].to(dtype), **tile).latent[0]
+            lat = vae.encode(x_cthw[None].to(dtype), **tile).latent
+        lat = (lat.unsqueeze(2) if lat.ndim == 4 else lat)[0]          # infer.py:187 (a one-frame clip comes back as an image)
         return (lat.permute(1, 2, 3, 0) - vcfg.shifting_factor) * vcfg.scaling_factor
 
     def vae_decode(lat_thwc):                          # infer.py:203-278

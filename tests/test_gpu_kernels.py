@@ -1055,18 +1055,22 @@ def test_vae_attention_gemm_path_matches_fused_kernel(hip, T, H, W):
     assert (got - fused).abs().max() < 0.08
 
 
-def test_vae_attention_at_config2_shape_512_channels_65536_tokens(hip):
+@pytest.mark.parametrize("H,W", [(256, 256), (270, 480)], ids=["cfg2_65536_tokens", "untiled_4k_129600_tokens"])
+def test_vae_attention_at_config2_shape_512_channels_65536_tokens(hip, H, W):
     """BASELINE config 2's untiled 2048x2048 frames put 256 x 256 = 65536 tokens of 512 channels through the mid-block attention
     (attn_video_vae.py:615-665: one head, d = 512, softmax rows of 65536 columns): the engine runs it as four blocks of 16384 query
     rows of Q K^T GEMM (fp32 scores) -> svr_softmax_rows -> P V GEMM (vae.py::_attention).  Checked at exactly that shape against a
-    blocked fp32 torch restatement on the device, and against the fused d = 512 kernel."""
+    blocked fp32 torch restatement on the device, and against the fused d = 512 kernel.
+    Round 6: the same check on an UNTILED 4K frame (270 x 480 = 129 600 tokens) -- above 65 536 tokens _attention routes to
+    the fused d = 512 kernel whatever attn_as_gemm says; no test had run it there."""
     from conftest import sub
     vae_mod, weights, config = sub("vae"), sub("weights"), sub("config")
     cfg = config.VAE_V3
     sd = weights.synth_vae_state_dict(cfg, seed=3)
     eng = vae_mod.VideoVAEEngine(cfg, sd, hip)
     ab = eng.dec_mid[1]
-    C, H, W = 512, 256, 256
+    C = 512
+    n = H * W
     g = torch.Generator(device="cuda").manual_seed(11)
     x = (torch.randn(1, H, W, C, device="cuda", generator=g) * 0.7).bfloat16()
     assert eng.attn_as_gemm
@@ -1081,13 +1085,17 @@ def test_vae_attention_at_config2_shape_512_channels_65536_tokens(hip):
     y = y.permute(0, 2, 3, 1).reshape(-1, C)
     q, k, v = (y @ w[f"to_{c}.weight"].T + w[f"to_{c}.bias"] for c in "qkv")
     o = torch.empty_like(q)
-    for r0 in range(0, q.shape[0], 8192):                              # 8192 x 65536 fp32 scores = 2 GiB per block
-        o[r0:r0 + 8192] = torch.softmax(q[r0:r0 + 8192] @ k.T / C ** 0.5, -1) @ v
+    blk = 8192 if n <= 65536 else 4050                                 # 8192 x 65536 (4050 x 129600) fp32 scores = 2 GiB per block
+    for r0 in range(0, q.shape[0], blk):
+        o[r0:r0 + blk] = torch.softmax(q[r0:r0 + blk] @ k.T / C ** 0.5, -1) @ v
     want = (o @ w["to_out.0.weight"].T + w["to_out.0.bias"]).reshape(xf.shape) + xf
     err = (got - want).abs()
     e = float((got - want).norm() / want.norm())
-    print(f"VAE mid-block attention, 512 channels x 65536 tokens (config 2): rel-err {e:.3e}, max abs {float(err.max()):.3e}")
+    print(f"VAE mid-block attention, 512 channels x {n} tokens ({'GEMM-softmax-GEMM' if n <= 65536 else 'fused d = 512 kernel'}): "
+          f"rel-err {e:.3e}, max abs {float(err.max()):.3e}")
     assert e < 4e-3 and err.max() < 0.08
+    if n > 65536:
+        return
     eng.attn_as_gemm = False
     fused = h2f(eng._attention(ab, x))
     ef = float((fused - want).norm() / want.norm())
