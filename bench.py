@@ -593,7 +593,7 @@ def main():
         c_flops, c_sec, c_n = dom["flops"], dom["seconds"], dom["launches"]
         traffic, traffic_note = None, None
         shader_clock = None
-        for name in ("r5_cfg3_pmc_traffic.json", "r4_cfg3_pmc_traffic.json", "r3_cfg3_pmc_traffic.json", "r2_cfg3_pmc_traffic.json",
+        for name in ("r6_cfg3_pmc_traffic.json", "r5_cfg3_pmc_traffic.json", "r4_cfg3_pmc_traffic.json", "r3_cfg3_pmc_traffic.json", "r2_cfg3_pmc_traffic.json",
                      "r1_cfg3_pmc_traffic.json"):
             # HBM bytes per launch come from separate rocprofv3 --pmc passes of this workload (counters cannot be collected
             # inside the timed run); the file names the commit it was measured on

@@ -192,12 +192,7 @@ int svr_attn_varlen(const void* qkv, int64_t ld_qkv, void* out, int64_t ld_out, 
 }
 
 #ifdef SVR_ABLATIONS
-extern "C" int svr_debug_conv_timeline(void* dst_host, int64_t bytes) {     // measurement builds only (not in the public header)
-    return check(hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_conv_tl), (size_t)bytes), "svr_debug_conv_timeline");
-}
-extern "C" int svr_debug_conv_epilogue(void* dst_host, int64_t bytes) {
-    return check(hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_conv_ep), (size_t)bytes), "svr_debug_conv_epilogue");
-}
+#include "measure/svr_api_measure_1.inc"
 #endif
 
 int svr_conv_pack_frag_taps(const void* W, void* out, int32_t N, int32_t K, int32_t kt, int32_t kh, int32_t kw, int32_t Cin, void* stream) {

@@ -101,6 +101,9 @@ __device__ unsigned long long g_conv_ep[4096][16];      // DBG 256: stamps insid
 // 32 weights always from the same four (L1-hot) units, 64 halo-row fragments read from LDS in the first A step only, 128 halo re-staged every step but always from the same (cache-hot) addresses
 template <int TY, int MODE, int DBG = 0>
 __global__ __launch_bounds__((cg_geom<TY, MODE>::NT), (MODE == 3 ? 1 : 2)) void conv_halo2_kernel(const svr_gemm_args a, const int band_rows) {
+#ifndef SVR_ABLATIONS
+    static_assert(DBG == 0, "measurement variants (results invalid on purpose) exist only in -DSVR_ABLATIONS builds; the product library instantiates DBG = 0");
+#endif
     typedef cg_geom<TY, MODE> G;
     constexpr bool WREG = MODE == 1 || MODE == 3, W8 = MODE == 3, THIN = MODE == 2;
     constexpr int CG_TY = TY, CG_ROWS = G::ROWS, CG_ABUF = G::ABUF, CG_ACHUNKS = G::ACHUNKS, CG_PIECES = G::PIECES,
@@ -974,17 +977,7 @@ template <int TY, int MODE, int DBG = 0> static int launch_conv_halo2_t(const sv
 
 static int launch_conv_halo2(const svr_gemm_args& a, hipStream_t s) {
 #ifdef SVR_ABLATIONS
-    // measurement variants of the shipped kernel (round 2's ablations of the 4-row kernel and the combined variants are in the git
-    // history; every variant costs ~10 s of compile time in the measurement build)
-    if (conv_halo2_wreg(a) && g_conv_rows == 8) switch (g_pipe_abl) {
-        case 256: return launch_conv_halo2_t<16, 3, 256>(a, s);     // s_memtime timeline (tools/conv_timeline.py)
-        case 16: return launch_conv_halo2_t<16, 3, 16>(a, s);       // no halo staging in the K loop
-        case 1: return launch_conv_halo2_t<16, 3, 1>(a, s);         // no weight loads
-        case 64: return launch_conv_halo2_t<16, 3, 64>(a, s);       // no fragment reads
-        case 4: return launch_conv_halo2_t<16, 3, 4>(a, s);         // no global stores (the epilogue's read-out side is dead code then)
-        case 512: return launch_conv_halo2_t<16, 3, 512>(a, s);     // epilogue pass barriers as __syncthreads() (wait for the stores)
-        default: break;
-    }
+#include "measure/svr_conv_halo2_measure_1.inc"
 #endif
     if (conv_halo2_wreg(a)) return g_conv_rows == 8 ? launch_conv_halo2_t<16, 3>(a, s) : launch_conv_halo2_t<8, 1>(a, s);
     return launch_conv_halo2_t<16, 0>(a, s);

@@ -233,6 +233,10 @@ static_assert(C4_APIECES == 10 && C4_ABUF >= C4_AROWS * 64, "piece schedule: vmc
 // stores (2: no MFMAs -- not launched: the accumulators then travel through VGPRs around the empty asm and the time says nothing)
 template <int DBG = 0>
 __global__ __launch_bounds__(C4_NT, 1) void conv_thinout4_kernel(const svr_gemm_args a, const int frames_per_chunk, const int flush_off) {
+#ifndef SVR_ABLATIONS
+    static_assert(DBG == 0, "measurement variants (results invalid on purpose) exist only in -DSVR_ABLATIONS builds; the product library instantiates DBG = 0");
+#endif
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const svr_conv_geom& g = a.conv;
     const int tid = threadIdx.x;

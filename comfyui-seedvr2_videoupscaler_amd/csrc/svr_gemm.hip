@@ -869,52 +869,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const svr_gemm_args a) {
 }
 
 SVR_DEVICE float agpr_read(float a_elem) { float x; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a_elem)); return x; }
-#ifdef SVR_ABLATIONS      // (the 32x32x16 kernel and its epilogue live on in the measurement build: it carries the timeline instrumentation)
-// SwiGLU epilogue of the four-wave kernel (bf16 output): the gate and the "in" value of a hidden column sit in the SAME lane of a 32x32
-// accumulator tile (W rows are interleaved gate | in in blocks of 16: columns 8 g + 4 (l >> 5) + e with g = 0, 1 are gates, g = 2, 3 their
-// "in" partners), so silu(gate) * in is formed in registers -- the arithmetic of epilogue_plain_lds<SVR_EPI_SWIGLU>, on the same fp32
-// values -- and the bf16 RESULT is parked: 256 rows x 128 hidden columns x 2 B = 64 KiB (+ pad) in ONE pass instead of four passes of
-// fp32 (the generic form parks both halves in fp32 and lets half the threads idle on the way out).  Leaves row-contiguous, 16 bytes
-// per thread.  Bit-identical to the generic form.
-template <int NTHREADS, int LDS_BYTES, int EDBG, typename ACC>
-SVR_DEVICE void epilogue_swiglu_bf16_m32(const svr_gemm_args& a, const ACC& acc, char* smem, int m0, int n0, int tid, int lane, int wave) {
-    constexpr int PITCH = 128 * 2 + 16;                   // 128 hidden columns of bf16 + 16 B pad
-    static_assert(256 * PITCH <= LDS_BYTES && NTHREADS == 256, "one pass");
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        char* row = smem + (wm * 128 + i * 32 + l31) * PITCH + (wn * 64 + 4 * hi) * 2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // (the accumulators live in AGPRs -- the K loop's inline-asm MFMAs pin them there -- and are fetched HERE, one element at a time:
-            // left to itself hipcc copied all 256 to VGPRs at the top of the epilogue and spilled them)
-#define fetch(idx) agpr_read(acc[i][j][idx])
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = silu(fetch(4 * g + e)) * fetch(4 * (g + 2) + e);
-                uint2 pk;
-                pk.x = pack2bf(o[0], o[1]);
-                pk.y = pack2bf(o[2], o[3]);
-                *(uint2*)(row + (16 * j + 8 * g) * 2) = pk;
-            }
-#undef fetch
-            __builtin_amdgcn_sched_barrier(0);            // (one accumulator tile at a time: hipcc otherwise interleaves all 16 and spills)
-        }
-    }
-    lds_barrier();
-    const int c8 = tid & 15, r0 = tid >> 4;               // 16 chunks of 8 hidden columns per row, 16 rows per iteration
-    const int64_t hid0 = (n0 >> 1) + c8 * 8;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int r = it * 16 + r0;
-        const uint4 pk = *(const uint4*)(smem + r * PITCH + c8 * 16);
-        if (m0 + r < a.M && !(EDBG & 1)) *(uint4*)((bf16_t*)a.C + (int64_t)(m0 + r) * a.ldc + hid0) = pk;
-    }
-}
-
+#ifdef SVR_ABLATIONS
+#include "measure/svr_gemm_measure_1.inc"
 #endif
 // ---- shared pieces of the four-wave kernel below: 256 x 256 tile, 64 KiB per K-tile stage, inline-asm fragment reads / MFMAs / waits
 constexpr int W4_THREADS = 256, W4_T = 256, W4_STAGE = 2 * W4_T * BK * 2;                            // 64 KiB per stage
@@ -984,257 +940,7 @@ constexpr int W4P_LDS = W4P_S1 + W4_STAGE;                 // 160 KiB
 constexpr int W4P_EPI = W4P_S1;                            // the epilogue's parking area: the free stage + the gap (96 KiB)
 
 #ifdef SVR_ABLATIONS
-// TL (builds with -DSVR_ABLATIONS only): wave 0 stamps the 100 MHz clock at each tile's K-loop start / K-loop end / epilogue end
-template <bool TL, int EDBG = 0>
-__global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4p_kernel(const svr_gemm_args a, uint64_t* timeline) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_m = (a.M + W4_T - 1) / W4_T;
-    const int tiles_n = a.N / W4_T;
-    const int tiles = tiles_m * tiles_n;
-    const int nwg = gridDim.x;                             // (host: a multiple of 8, <= tiles)
-    constexpr int GM = 4;
-    const int group_size = GM * tiles_n;
-    auto tile_origin = [&](int t, int& m0, int& n0) {      // grouped order: 4 row panels x all column panels (as gemm_kernel)
-        const int group = t / group_size;
-        const int first_m = group * GM;
-        const int gm = min(tiles_m - first_m, GM);
-        m0 = (first_m + (t % group_size) % gm) * W4_T;
-        n0 = ((t % group_size) / gm) * W4_T;
-    };
-    int t = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);      // tile being computed
-    int m0, n0;
-    tile_origin(t, m0, n0);
-    // ---- staging roles : piece q = rows q * 32 + wave * 8 + (lane >> 3); the lane at position p = lane & 7 of
-    // its row loads SOURCE chunk p ^ key(row) and stores it lane-linearly
-    const int srow = wave * 8 + (lane >> 3);
-    const int chunk_src = (lane & 7) ^ ((srow >> 1) & 7);
-    // the load cursor: K tile kl of tile tl (two K tiles ahead of the MFMAs, across tile boundaries); bases are wave-uniform
-    int tl = t, kl = 0;
-    w4p_u32x4 Arsrc;
-    uint32_t Akoff = 0;                                    // byte offset of K tile kl in a row of A
-    const char* Bbase;
-    uint32_t aoff[8], boffq[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        aoff[q] = (uint32_t)((int64_t)(q * 32 + srow) * a.lda * 2) + chunk_src * 16;
-        boffq[q] = (uint32_t)((int64_t)(q * 32 + srow) * a.K * 2) + chunk_src * 16;
-    }
-    auto point_cursor = [&](int lm0, int ln0) {            // first K tile of the tile at (lm0, ln0)
-        const uint64_t base = (uint64_t)(uintptr_t)a.A + (uint64_t)lm0 * (uint64_t)a.lda * 2;
-        const uint64_t left = (uint64_t)(a.M - lm0) * (uint64_t)a.lda * 2;
-        Arsrc[0] = __builtin_amdgcn_readfirstlane((uint32_t)base);
-        Arsrc[1] = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32) & 0xffffu);
-        Arsrc[2] = __builtin_amdgcn_readfirstlane(left > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)left);
-        Arsrc[3] = 0x00020000u;
-        Akoff = 0;
-        Bbase = w4p_uniform((const char*)a.W + (int64_t)ln0 * a.K * 2);
-    };
-    const int nk = a.K / BK;
-    auto advance_cursor = [&]() {                          // after the 16 loads of (tl, kl); the common case is branch-free scalar code
-        ++kl;
-        const bool same = kl < nk;
-        Akoff = same ? Akoff + BK * 2 : Akoff;
-        Bbase = w4p_uniform(same ? Bbase + BK * 2 : Bbase);
-        if (__builtin_expect(!same, 0)) {
-            if (tl + nwg < tiles) {
-                tl += nwg; kl = 0;
-                int lm0, ln0;
-                tile_origin(tl, lm0, ln0);
-                point_cursor(lm0, ln0);
-            } else {
-                kl = nk - 1;                               // no tile left: keep re-loading the last K tile (written to a stage nobody reads)
-            }
-        }
-    };
-    point_cursor(m0, n0);
-
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    // write addresses of this lane's chunk in piece 0 of A / B of the stage being FILLED (flipped per K tile); piece q at + q * 4096
-    unsigned wrA = lds0 + (unsigned)(wave * 1024 + lane * 16), wrB = wrA + W4_T * BK * 2;
-
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const unsigned key = (unsigned)((l31 >> 1) & 7);
-    const unsigned rA = lds0 + (unsigned)((wm * 128 + l31) * 128), rB = lds0 + (unsigned)(W4_T * BK * 2 + (wn * 128 + l31) * 128);
-    unsigned rdA[4], rdB[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const unsigned po = (((unsigned)(2 * ks + hi)) ^ key) << 4;
-        rdA[ks] = rA + po;
-        rdB[ks] = rB + po;
-    }
-
-    f32x16 acc[4][4];
-    bf16x8 AX[4], BX[4], AY[4], BY[4];
-    w4p_u32x4 sa[8], sb[8];                                // the staging registers: 8 pieces of A, 8 of B
-
-#define W4_RD(DST, BASE, I) w4_rd<(I) * 4096>(DST[I], BASE)
-#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define w4_mfma w4_mfma_t<true>
-#define W4_LDA(Q) w4p_bload(sa[Q], Arsrc, aoff[Q], Akoff)
-#define W4_LDB(Q) w4p_gload(sb[Q], Bbase, boffq[Q])
-#define W4_LOAD_ALL() do { W4_LDA(0); W4_LDB(0); W4_LDA(1); W4_LDB(1); W4_LDA(2); W4_LDB(2); W4_LDA(3); W4_LDB(3); \
-                           W4_LDA(4); W4_LDB(4); W4_LDA(5); W4_LDB(5); W4_LDA(6); W4_LDB(6); W4_LDA(7); W4_LDB(7); } while (0)
-#define W4_LANDED() asm volatile("s_waitcnt vmcnt(0)" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sa[4]), "+v"(sa[5]), \
-                                 "+v"(sa[6]), "+v"(sa[7]), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), \
-                                 "+v"(sb[6]), "+v"(sb[7]))
-    // piece Q: its data (loaded one K tile ago; 15 younger loads may be in flight) -> LDS, then the same piece two K tiles ahead
-#define W4_MOVE_A(Q) do { w4p_wait_piece<15>(sa[Q]); w4p_swrite<(Q) * 4096>(wrA, sa[Q]); W4_FENCE(); W4_LDA(Q); } while (0)
-#define W4_MOVE_B(Q) do { w4p_wait_piece<15>(sb[Q]); w4p_swrite<(Q) * 4096>(wrB, sb[Q]); W4_FENCE(); W4_LDB(Q); } while (0)
-#define W4_READ_STEP0() do { W4_RD(BX, rdB[0], 0); W4_RD(BX, rdB[0], 1); W4_RD(BX, rdB[0], 2); W4_RD(BX, rdB[0], 3); \
-                             W4_RD(AX, rdA[0], 0); W4_RD(AX, rdA[0], 1); W4_RD(AX, rdA[0], 2); W4_RD(AX, rdA[0], 3); } while (0)
-
-    // ---- prologue (once per workgroup): K tile 0 -> registers -> stage 0; K tile 1 -> registers
-    W4_LOAD_ALL();
-    advance_cursor();
-    W4_FENCE();
-    W4_LANDED();
-    W4_FENCE();
-    w4p_swrite<0 * 4096>(wrA, sa[0]); w4p_swrite<0 * 4096>(wrB, sb[0]); w4p_swrite<1 * 4096>(wrA, sa[1]); w4p_swrite<1 * 4096>(wrB, sb[1]);
-    w4p_swrite<2 * 4096>(wrA, sa[2]); w4p_swrite<2 * 4096>(wrB, sb[2]); w4p_swrite<3 * 4096>(wrA, sa[3]); w4p_swrite<3 * 4096>(wrB, sb[3]);
-    w4p_swrite<4 * 4096>(wrA, sa[4]); w4p_swrite<4 * 4096>(wrB, sb[4]); w4p_swrite<5 * 4096>(wrA, sa[5]); w4p_swrite<5 * 4096>(wrB, sb[5]);
-    w4p_swrite<6 * 4096>(wrA, sa[6]); w4p_swrite<6 * 4096>(wrB, sb[6]); w4p_swrite<7 * 4096>(wrA, sa[7]); w4p_swrite<7 * 4096>(wrB, sb[7]);
-    W4_FENCE();
-    W4_LOAD_ALL();
-    advance_cursor();
-    wrA += W4P_S1; wrB += W4P_S1;                          // the loop fills stage 1 first
-    W4_FENCE();
-    w4_wait_lgkm_n<0>();                                   // this wave's writes of K tile 0 are in LDS
-    __builtin_amdgcn_s_barrier();                          // ... and everybody else's
-    W4_FENCE();
-    W4_READ_STEP0();
-    W4_FENCE();
-
-#define W4_STEP(AF, BF, S0, S1, S2, S3, S4, S5, S6, S7, S8, S9, S10, S11, S12, S13, S14, S15) \
-        w4_mfma(acc[0][0], BF[0], AF[0]); W4_FENCE(); S0;  W4_FENCE(); w4_mfma(acc[0][1], BF[1], AF[0]); W4_FENCE(); S1;  W4_FENCE(); \
-        w4_mfma(acc[0][2], BF[2], AF[0]); W4_FENCE(); S2;  W4_FENCE(); w4_mfma(acc[0][3], BF[3], AF[0]); W4_FENCE(); S3;  W4_FENCE(); \
-        w4_mfma(acc[1][0], BF[0], AF[1]); W4_FENCE(); S4;  W4_FENCE(); w4_mfma(acc[1][1], BF[1], AF[1]); W4_FENCE(); S5;  W4_FENCE(); \
-        w4_mfma(acc[1][2], BF[2], AF[1]); W4_FENCE(); S6;  W4_FENCE(); w4_mfma(acc[1][3], BF[3], AF[1]); W4_FENCE(); S7;  W4_FENCE(); \
-        w4_mfma(acc[2][0], BF[0], AF[2]); W4_FENCE(); S8;  W4_FENCE(); w4_mfma(acc[2][1], BF[1], AF[2]); W4_FENCE(); S9;  W4_FENCE(); \
-        w4_mfma(acc[2][2], BF[2], AF[2]); W4_FENCE(); S10; W4_FENCE(); w4_mfma(acc[2][3], BF[3], AF[2]); W4_FENCE(); S11; W4_FENCE(); \
-        w4_mfma(acc[3][0], BF[0], AF[3]); W4_FENCE(); S12; W4_FENCE(); w4_mfma(acc[3][1], BF[1], AF[3]); W4_FENCE(); S13; W4_FENCE(); \
-        w4_mfma(acc[3][2], BF[2], AF[3]); W4_FENCE(); S14; W4_FENCE(); w4_mfma(acc[3][3], BF[3], AF[3]); W4_FENCE(); S15; W4_FENCE()
-#define W4_NOP ((void)0)
-
-    int st = 0;                                            // the stage the MFMAs read
-    int tl_i = 0;
-    uint64_t cyc[5] = {0, 0, 0, 0, 0}, c_prev = 0;        // TL: shader cycles per K-tile phase, summed over a workgroup's K tiles
-    auto cstart = [&]() { if constexpr (TL) { c_prev = __builtin_amdgcn_s_memtime(); } };
-    auto clap = [&](int what) {
-        if constexpr (TL) { const uint64_t c = __builtin_amdgcn_s_memtime(); cyc[what] += c - c_prev; c_prev = c; }
-    };
-    auto stamp = [&](int what) {
-        if constexpr (TL) {
-            if (tid == 0 && tl_i < 64) timeline[((int64_t)blockIdx.x * 64 + tl_i) * 4 + what] = __builtin_amdgcn_s_memrealtime();
-        }
-    };
-    for (;;) {                                             // the output tiles of this workgroup
-        stamp(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        for (int kt = 0; kt < nk; ++kt) {
-            // (the eight fragment reads of the next step ride behind the FIRST eight MFMAs of a step, so the youngest has eight MFMAs
-            // = 256 cycles to land before the step-boundary wait; the moves take the last eight slots of steps 0 and 1 -- their
-            // ds_writes are long complete at the barrier --, and the waits are counted: lgkmcnt(8) = everything but the eight
-            // ds_writes behind the reads)
-            // ---- step 0 (set X); reads of step 1 -> Y; pieces 0..3: registers -> the other stage, reloaded two K tiles ahead
-            w4_wait_lgkm_n<0>();
-            cstart();
-            W4_STEP(AX, BX,
-                    W4_RD(BY, rdB[1], 0), W4_RD(BY, rdB[1], 1), W4_RD(BY, rdB[1], 2), W4_RD(BY, rdB[1], 3),
-                    W4_RD(AY, rdA[1], 0), W4_RD(AY, rdA[1], 1), W4_RD(AY, rdA[1], 2), W4_RD(AY, rdA[1], 3),
-                    W4_MOVE_A(0), W4_MOVE_B(0), W4_MOVE_A(1), W4_MOVE_B(1), W4_MOVE_A(2), W4_MOVE_B(2), W4_MOVE_A(3), W4_MOVE_B(3));
-            // ---- step 1 (set Y); reads of step 2 -> X; pieces 4..7
-            w4_wait_lgkm_n<8>();
-            clap(0);
-            W4_STEP(AY, BY,
-                    W4_RD(BX, rdB[2], 0), W4_RD(BX, rdB[2], 1), W4_RD(BX, rdB[2], 2), W4_RD(BX, rdB[2], 3),
-                    W4_RD(AX, rdA[2], 0), W4_RD(AX, rdA[2], 1), W4_RD(AX, rdA[2], 2), W4_RD(AX, rdA[2], 3),
-                    W4_MOVE_A(4), W4_MOVE_B(4), W4_MOVE_A(5), W4_MOVE_B(5), W4_MOVE_A(6), W4_MOVE_B(6), W4_MOVE_A(7), W4_MOVE_B(7));
-            // ---- step 2 (set X); reads of step 3 -> Y: the last reads of this stage
-            w4_wait_lgkm_n<8>();
-            clap(1);
-            W4_STEP(AX, BX,
-                    W4_RD(BY, rdB[3], 0), W4_RD(BY, rdB[3], 1), W4_RD(BY, rdB[3], 2), W4_RD(BY, rdB[3], 3),
-                    W4_RD(AY, rdA[3], 0), W4_RD(AY, rdA[3], 1), W4_RD(AY, rdA[3], 2), W4_RD(AY, rdA[3], 3),
-                    W4_NOP, W4_NOP, W4_NOP, W4_NOP, W4_NOP, W4_NOP, W4_NOP, W4_NOP);
-            // ---- the barrier of the K tile: this wave's reads of stage st and its writes of the next K tile are complete (lgkmcnt counts both)
-            w4_wait_lgkm_n<0>();
-            clap(2);
-            if constexpr (!(EDBG & 8)) __builtin_amdgcn_s_barrier();
-            clap(3);
-            W4_FENCE();
-            // The stage flip (ten VALU adds on address registers) and the load cursor (scalar code) cost 156 + 92 cycles per K tile when
-            // they sat here, in front of the step's first MFMA with the matrix pipe idle behind the barrier (measured by leaving each
-            // out).  Only the two addresses the step's own reads use are flipped here; the rest ride in its free slots behind MFMAs.
-            const unsigned d = st ? (unsigned)-W4P_S1 : (unsigned)W4P_S1;      // reads flip to the other stage, writes to this one
-            if constexpr (!(EDBG & 16)) { rdA[0] += d; rdB[0] += d; }
-#define W4_FLIP2(x, y) do { if constexpr (!(EDBG & 16)) { x += d; y += d; } } while (0)
-            // ---- step 3 (set Y); reads of the next K tile / step 0 -> X (other stage; at a tile's end they are re-read after the epilogue)
-            W4_STEP(AY, BY,
-                    W4_RD(BX, rdB[0], 0), W4_RD(BX, rdB[0], 1), W4_RD(BX, rdB[0], 2), W4_RD(BX, rdB[0], 3),
-                    W4_RD(AX, rdA[0], 0), W4_RD(AX, rdA[0], 1), W4_RD(AX, rdA[0], 2), W4_RD(AX, rdA[0], 3),
-                    W4_FLIP2(rdA[1], rdB[1]), W4_FLIP2(rdA[2], rdB[2]), W4_FLIP2(rdA[3], rdB[3]),
-                    do { if constexpr (!(EDBG & 16)) { wrA -= d; wrB -= d; st ^= 1; } } while (0),
-                    do { if constexpr (!(EDBG & 32)) advance_cursor(); } while (0), W4_NOP, W4_NOP,
-                    // (last K tile of a tile: the staged loads land INSIDE the loop, so that any register copies hipcc places on the loop's exit
-                    // edge -- live-range splits around the epilogue -- already see their data; W4_LANDED below then only names the registers)
-                    do { if (kt + 1 == nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0));
-#undef W4_FLIP2
-            if constexpr (TL) { w4_wait_lgkm_n<0>(); clap(4); }
-        }
-        // ---- tile end.  Stage st holds the next tile's K tile 0, the registers its K tile 1 (in flight); stage st ^ 1 + the gap are free
-        // (every wave passed the last barrier after its last read of it).
-        stamp(1);
-        W4_FENCE();
-        W4_LANDED();                                       // (the compiler may move the staging registers from here on: their data is there)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs retire before the accumulators are read
-        if (a.epilogue == SVR_EPI_SWIGLU && !a.out_f32)
-            epilogue_swiglu_bf16_m32<W4_THREADS, W4P_EPI, EDBG>(a, acc, smem + (st ? 0 : W4_STAGE), m0, n0, tid, lane, wave);
-        else
-            epilogue_through_lds<W4_T, W4_T, 128, 128, W4_THREADS, W4P_EPI, true, 2, 2, EDBG, true, 16>(a, acc, smem + (st ? 0 : W4_STAGE), m0, n0, tid, lane, wave);
-        if constexpr (TL) stamp(2);
-        // hipcc's own wait for the epilogue's loads and stores, HERE (a builtin: its waitcnt pass sees it; an asm wait it does not).
-        // Without it the pass carried "registers with loads pending" from the epilogue into the K loop's header -- the fragment
-        // registers are the epilogue's load destinations -- and put s_waitcnt vmcnt(0) behind the first MFMA of EVERY K tile,
-        // i.e. every K tile waited for all sixteen staged loads it had just issued (K loop 1.70 us per K tile instead of 1.47).
-        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), expcnt / lgkmcnt untouched
-        if constexpr (TL) { stamp(3); ++tl_i; }
-        t += nwg;
-        if (t >= tiles) break;
-        tile_origin(t, m0, n0);
-        __syncthreads();                                   // the parked tile has been read out: the free stage may be filled again
-        W4_FENCE();
-        W4_READ_STEP0();
-        W4_FENCE();
-    }
-    if constexpr (TL) {
-        if (tid == 0) {
-#pragma unroll
-            for (int q = 0; q < 5; ++q) timeline[(int64_t)gridDim.x * 64 * 4 + (int64_t)blockIdx.x * 5 + q] = cyc[q];
-        }
-    }
-#undef W4_RD
-#undef W4_FENCE
-#undef w4_mfma
-#undef W4_LDA
-#undef W4_LDB
-#undef W4_LOAD_ALL
-#undef W4_LANDED
-#undef W4_MOVE_A
-#undef W4_MOVE_B
-#undef W4_READ_STEP0
-#undef W4_STEP
-#undef W4_NOP
-}
-
+#include "measure/svr_gemm_measure_2.inc"
 #endif
 // ------------------------------------------------------------------------------------------------
 // gemm_w4q_kernel: gemm_w4p_kernel's structure (persistent workgroups, operands through registers, loads two K tiles ahead across
@@ -1554,115 +1260,14 @@ static int launch_gemm_w4(const svr_gemm_args& a, hipStream_t s) {
     const int tiles = ((a.M + W4_T - 1) / W4_T) * (a.N / W4_T);
     const int grid = std::min(device_cu_count(), tiles) & ~7;       // one workgroup per CU; a multiple of the XCD count
 #ifdef SVR_ABLATIONS
-    if (g_gemm_w4 == 2) {                                 // the 32x32x16 predecessor with its timeline instrumentation (measurement build)
-        static uint64_t lds_attr_done2 = 0;
-        const int e = set_max_dynamic_lds((const void*)gemm_w4p_kernel<false>, W4P_LDS, lds_attr_done2);
-        if (e != 0) return e;
-        if (g_pipe_abl >= 100 && g_pipe_abl <= 132) {     // timeline of the first 64 tiles of every workgroup -> stderr (synchronises);
-                                                          // 101: no global stores | 102: no parking writes | 104: no readout (results invalid)
-            static uint64_t* d_tl = nullptr;
-            const size_t n = (size_t)grid * 64 * 4 + (size_t)grid * 5;
-            if (!d_tl && hipMalloc(&d_tl, (256 * 64 * 4 + 256 * 5) * 8) != hipSuccess) return (int)hipErrorOutOfMemory;
-            (void)hipMemsetAsync(d_tl, 0, n * 8, s);
-            static uint64_t lds_attr_done3[7] = {0, 0, 0, 0, 0, 0, 0};
-            auto go = [&](auto kern, uint64_t& done) {
-                const int e3 = set_max_dynamic_lds((const void*)kern, W4P_LDS, done);
-                if (e3 != 0) return e3;
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, d_tl);
-                return 0;
-            };
-            int e3 = 0;
-            switch (g_pipe_abl) {
-                // (102 no parking writes, 104 no read-out, 116 no stage flip, 132 no load cursor: measured -- profiles/r3_gemm_w4_ablations.txt
-                // sections 7, 8 -- and dropped from the build again, ~15 s of compile time each; the template bits are still there)
-                case 101: e3 = go(gemm_w4p_kernel<true, 1>, lds_attr_done3[1]); break;       // no global stores
-                case 108: e3 = go(gemm_w4p_kernel<true, 8>, lds_attr_done3[4]); break;       // no K-loop barrier
-                default:  e3 = go(gemm_w4p_kernel<true, 0>, lds_attr_done3[0]); break;
-            }
-            if (e3 != 0) return e3;
-            std::vector<uint64_t> h(n);
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(h.data(), d_tl, n * 8, hipMemcpyDeviceToHost);
-            uint64_t t00 = ~0ull;
-            for (int w = 0; w < grid; ++w) if (h[(size_t)w * 256]) t00 = std::min(t00, h[(size_t)w * 256]);
-            fprintf(stderr, "[w4p timeline] M %d N %d K %d grid %d; ticks of 10 ns; per workgroup: tile: start(rel) kloop epilogue-issue store-drain\n", a.M, a.N, a.K, grid);
-            for (int w : {0, 1, 2, 7, 8, 9, 128, 255}) {
-                if (w >= grid) continue;
-                fprintf(stderr, "  wg %3d (xcd %d):", w, w & 7);
-                for (int i = 0; i < 6; ++i) {
-                    const uint64_t* r = &h[((size_t)w * 64 + i) * 4];
-                    if (!r[0]) break;
-                    fprintf(stderr, "  %lld %lld %lld %lld |", (long long)(r[0] - t00), (long long)(r[1] - r[0]), (long long)(r[2] - r[1]), (long long)(r[3] - r[2]));
-                }
-                fprintf(stderr, "\n");
-            }
-            for (int i : {1, 5, 20, 40}) {                 // spread of the epilogue starts of tile i over the workgroups, per XCD mean
-                double mean[8] = {0}; int cnt[8] = {0};
-                double ksum = 0, esum = 0, dsum = 0; int c2 = 0;
-                for (int w = 0; w < grid; ++w) {
-                    const uint64_t* r = &h[((size_t)w * 64 + i) * 4];
-                    if (!r[0] || !r[3]) continue;
-                    mean[w & 7] += (double)(r[1] - t00); ++cnt[w & 7];
-                    ksum += (double)(r[1] - r[0]); esum += (double)(r[2] - r[1]); dsum += (double)(r[3] - r[2]); ++c2;
-                }
-                fprintf(stderr, "  tile %2d: mean kloop %.0f epilogue issue %.0f drain %.0f; epilogue start per XCD:", i, c2 ? ksum / c2 : 0., c2 ? esum / c2 : 0., c2 ? dsum / c2 : 0.);
-                for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f", cnt[x] ? mean[x] / cnt[x] : 0.);
-                fprintf(stderr, "\n");
-            }
-            {                                              // shader cycles per K tile and phase (wave 0 of every workgroup)
-                double c5[5] = {0, 0, 0, 0, 0};
-                for (int w = 0; w < grid; ++w) for (int q = 0; q < 5; ++q) c5[q] += (double)h[(size_t)grid * 256 + (size_t)w * 5 + q];
-                const double kts = (double)tiles * (a.K / BK);
-                fprintf(stderr, "  shader cycles per K tile: step0 %.0f step1 %.0f step2 %.0f barrier %.0f step3 %.0f (MFMA time of a step: 512)\n",
-                        c5[0] / kts, c5[1] / kts, c5[2] / kts, c5[3] / kts, c5[4] / kts);
-            }
-            return (int)hipGetLastError();
-        }
-        hipLaunchKernelGGL(gemm_w4p_kernel<false>, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, (uint64_t*)nullptr);
-        return (int)hipGetLastError();
-    }
+#include "measure/svr_gemm_measure_3.inc"
 #endif
 #ifdef SVR_ABLATIONS
-    if (g_pipe_abl == 200) {                              // phase-level shader-clock counts of the default kernel -> stderr (synchronises)
-        static uint64_t* d_c = nullptr;
-        static uint64_t lds_attr_done_t = 0;
-        if (!d_c && hipMalloc(&d_c, 256 * 5 * 8) != hipSuccess) return (int)hipErrorOutOfMemory;
-        const int et = set_max_dynamic_lds((const void*)gemm_w4q_kernel<true>, W4P_LDS, lds_attr_done_t);
-        if (et != 0) return et;
-        (void)hipMemsetAsync(d_c, 0, 256 * 5 * 8, s);
-        hipLaunchKernelGGL(gemm_w4q_kernel<true>, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a, d_c);
-        std::vector<uint64_t> h((size_t)grid * 5);
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h.data(), d_c, h.size() * 8, hipMemcpyDeviceToHost);
-        double c5[5] = {0, 0, 0, 0, 0};
-        for (int w = 0; w < grid; ++w) for (int q = 0; q < 5; ++q) c5[q] += (double)h[(size_t)w * 5 + q];
-        const double kts = (double)tiles * (a.K / BK);
-        fprintf(stderr, "[w4q] M %d N %d K %d: counts per K tile: half0 slots 0-7 %.0f (MFMA time 128) | half0 slots 8-63 %.0f (896) | half1 slots 0-19 "
-                        "%.0f (320) | barrier %.0f | half1 slots 20-63 %.0f (704)\n", a.M, a.N, a.K, c5[0] / kts, c5[1] / kts, c5[2] / kts, c5[3] / kts, c5[4] / kts);
-        return (int)hipGetLastError();
-    }
+#include "measure/svr_gemm_measure_4.inc"
 #endif
     if (a.W_frag && g_gemm_w4r) {
 #ifdef SVR_ABLATIONS
-        if (g_pipe_abl >= 500 && g_pipe_abl < 628) {      // K-loop ablations of gemm_w4r_kernel (results invalid)
-            static uint64_t done_abl[128] = {0};
-            auto go = [&](auto kern, uint64_t& done) {
-                const int e3 = set_max_dynamic_lds((const void*)kern, W4P_LDS, done);
-                if (e3 != 0) return e3;
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_THREADS), W4P_LDS, s, a);
-                return (int)hipGetLastError();
-            };
-            switch (g_pipe_abl - 500) {
-                case 1: return go(gemm_w4r_kernel<1>, done_abl[1]);
-                case 2: return go(gemm_w4r_kernel<2>, done_abl[2]);
-                case 4: return go(gemm_w4r_kernel<4>, done_abl[4]);
-                case 8: return go(gemm_w4r_kernel<8>, done_abl[8]);
-                case 6: return go(gemm_w4r_kernel<6>, done_abl[6]);
-                case 32: return go(gemm_w4r_kernel<32>, done_abl[32]);
-                case 64: return go(gemm_w4r_kernel<64>, done_abl[64]);
-                default: break;
-            }
-        }
+#include "measure/svr_gemm_measure_5.inc"
 #endif
         static uint64_t lds_attr_done_s = 0;
         const int es = set_max_dynamic_lds((const void*)gemm_w4r_kernel<0>, W4P_LDS, lds_attr_done_s);

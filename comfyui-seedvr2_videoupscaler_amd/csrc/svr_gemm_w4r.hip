@@ -71,6 +71,9 @@ SVR_DEVICE void w4s_dma(unsigned lds_wave_base, const w4p_u32x4& rsrc, uint32_t 
 // behind it and the pieces in slots 20 .. 48 -- measured within +-0.5 % of this one: profiles/r4_gemm_w4r_ablations.txt section 4.)
 template <int DBG = 0>
 __global__ __launch_bounds__(W4_THREADS, 1) void gemm_w4r_kernel(const svr_gemm_args a) {
+#ifndef SVR_ABLATIONS
+    static_assert(DBG == 0, "measurement variants (results invalid on purpose) exist only in -DSVR_ABLATIONS builds; the product library instantiates DBG = 0");
+#endif
     constexpr int BAR_SLOT = 6;
     constexpr int S1 = 32768;                             // byte offset of stage 1
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -105,7 +105,13 @@ class HipLibraryError(RuntimeError):
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] + [INCLUDE]
+    """Every file the library is compiled from: csrc/*.hip|.h, the measurement-only pieces under csrc/measure/ (compiled only with
+    -DSVR_ABLATIONS; hashed always, so both kinds of build name the tree they came from) and the public header."""
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    measure = os.path.join(CSRC, "measure")
+    if os.path.isdir(measure):
+        files += [os.path.join(measure, f) for f in sorted(os.listdir(measure)) if f.endswith((".inc", ".hip", ".h"))]
+    return files + [INCLUDE]
 
 
 def _extra_defines():

@@ -1136,3 +1136,13 @@ def test_conv_thin_output_4_cout_kernel(hip, ref, T, H, W, Cin, N, hf, kt, out_f
         assert rel_err(out.float(), want) < (1e-3 if out_f32 else TOL_BF16), new
         outs.append(out.float())
     assert rel_err(outs[0], outs[1]) < (2e-4 if out_f32 else 4e-3)
+
+
+def test_mfma_calibrate_reports_a_plausible_rate(hip):
+    """svr_mfma_calibrate (ABI v9, measurement aid): a bare v_mfma_f32_32x32x16_bf16 loop timed with events on the launch stream must
+    land between the slowest sustained rate seen on the pool and the nominal dense bf16 peak -- bench.py divides the dominant kernel's
+    rate by it (roofline.frac_of_power_limited), so a broken FLOP count or a loop the compiler removed must fail here."""
+    rate = hip.mfma_calibrate(seconds=0.1)
+    print(f"bare-MFMA rate of this device right now: {rate:.0f} TFLOP/s")
+    assert 1200.0 < rate < 2500.0, rate
+    assert abs(hip.mfma_calibrate(seconds=0.1) - rate) < 0.08 * rate          # (repeatable within the box's clock noise)
