@@ -410,11 +410,30 @@ class NaDiTEngine:
         ops.unpatchify_euler(pred, None if x_t is None else x_t.contiguous(), out)
         return out
 
-    # reference-shaped call: NaDiT.forward(vid (L,33), txt (l,5120), vid_shape (1,3), txt_shape, timestep)
+    # reference-shaped call: NaDiT.forward(vid (L, 33), txt (l, 5120), vid_shape (B, 3), txt_shape (B, 1), timestep (B,)) -- a batch is the
+    # clips' rows concatenated (na.flatten, infer.py:355-357); clips never interact, so each runs on its own and the rows are re-joined
     def __call__(self, vid, txt, vid_shape, txt_shape=None, timestep=1000.0):
-        if vid_shape.shape[0] != 1:
-            raise NotImplementedError("one clip per call (the pipeline calls the DiT with a single-element batch)")
-        T, H, W = (int(v) for v in vid_shape[0].tolist())
-        ts = float(timestep.reshape(-1)[0]) if torch.is_tensor(timestep) else float(timestep)
-        out = self.forward(vid.reshape(T, H, W, -1).to(self.ops.act_dtype), txt.to(self.ops.act_dtype), ts)
-        return NaDiTOutput(vid_sample=out.reshape(T * H * W, -1))
+        B = int(vid_shape.shape[0])
+        if txt_shape is None:
+            if B != 1:
+                raise ValueError("txt_shape is required for a batch of clips")
+            txt_lens = [int(txt.shape[0])]
+        else:
+            txt_lens = [int(v) for v in txt_shape.reshape(B, -1).prod(dim=1).tolist()]
+        if torch.is_tensor(timestep):
+            tl = [float(v) for v in timestep.reshape(-1).tolist()]
+            tl = tl * B if len(tl) == 1 else tl
+        else:
+            tl = [float(timestep)] * B
+        if len(tl) != B or sum(txt_lens) != txt.shape[0]:
+            raise ValueError("timestep / txt_shape do not match the batch")
+        outs, v0, t0 = [], 0, 0
+        for b in range(B):
+            T, H, W = (int(v) for v in vid_shape[b].tolist())
+            n = T * H * W
+            out = self.forward(vid[v0:v0 + n].reshape(T, H, W, -1).to(self.ops.act_dtype), txt[t0:t0 + txt_lens[b]].to(self.ops.act_dtype), tl[b])
+            outs.append(out.reshape(n, -1))
+            v0, t0 = v0 + n, t0 + txt_lens[b]
+        if v0 != vid.shape[0]:
+            raise ValueError("vid_shape does not cover the rows of vid")
+        return NaDiTOutput(vid_sample=outs[0] if B == 1 else torch.cat(outs, dim=0))

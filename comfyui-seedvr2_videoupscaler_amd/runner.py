@@ -11,7 +11,8 @@ meaning, ownership and error behaviour -- with ``.dit`` / ``.vae`` backed by the
 
 The one-step sampler (EulerSampler with steps=1 => a single model call at t = T, x0 = x_t - pred:
 euler.py:36-66, schedules/base.py:108-110, lerp.py:44-48, trailing.py:39-48) is folded into the
-DiT's un-patchify kernel.  ``config`` is a light attribute tree standing in for the OmegaConf
+DiT's un-patchify kernel; several steps and classifier-free guidance (scale, partial, rescale:
+diffusion/utils.py:41-86) run as a host loop over the same engine (round 6).  ``config`` is a light attribute tree standing in for the OmegaConf
 object (omegaconf is not a dependency here); the keys callers touch are kept.
 """
 from typing import List, Optional, Sequence, Tuple, Union
@@ -105,13 +106,25 @@ class VideoDiffusionInfer:
 
     # ---- infer.py:80-113
     def configure_diffusion(self, device=None, dtype=torch.float32):
-        steps = self.config.diffusion.timesteps.sampling.steps
-        if steps != 1 or float(self.config.diffusion.cfg.scale) != 1.0:
-            raise NotImplementedError(
-                "SeedVR2 is a one-step distilled model: the pipeline forces steps=1, cfg=1.0 "
-                "(generation_phases.py:599-601); other settings are not part of this hot path")
-        self.schedule = LinearInterpolationSchedule(self.config.diffusion.schedule.T)
-        self.sampling_timesteps = torch.tensor([self.schedule.T], dtype=dtype)   # trailing.py with steps=1
+        """Schedule + sampling timesteps + sampler as diffusion/config.py:28-75 builds them from ``config.diffusion``: the lerp schedule,
+        uniform trailing timesteps (trailing.py:30-50: arange(1, 0, -1/steps), SD3 shift, scaled to T) and the Euler sampler on v_lerp
+        predictions -- the only combination the reference's configs use (configs_3b/main.yaml:65-85).  Any number of steps and any
+        cfg scale (round 6; the pipeline itself forces steps = 1, cfg = 1.0: generation_phases.py:599-601)."""
+        d = self.config.diffusion
+        if d.schedule.type != "lerp" or d.sampler.type != "euler" or d.sampler.prediction_type != "v_lerp" \
+                or d.timesteps.sampling.type != "uniform_trailing":
+            raise NotImplementedError("schedule 'lerp' + sampler 'euler' on 'v_lerp' predictions + 'uniform_trailing' timesteps is the "
+                                      "combination the reference's configs use; others are not built")
+        steps = int(d.timesteps.sampling.steps)
+        if steps < 1:
+            raise ValueError("diffusion.timesteps.sampling.steps must be >= 1")
+        shift = float(d.timesteps.sampling.get("shift", 1.0))
+        T = d.schedule.T
+        self.schedule = LinearInterpolationSchedule(T)
+        t = torch.arange(1.0, 0.0, -1.0 / steps)
+        t = shift * t / (1 + (shift - 1) * t)
+        t = t * T if isinstance(T, float) else t.mul(T + 1).sub(1).round().int()
+        self.sampling_timesteps = t.to(dtype) if isinstance(T, float) else t
 
     # ---- infer.py:281-310
     def timestep_transform(self, timesteps: torch.Tensor, latents_shapes: torch.Tensor) -> torch.Tensor:
@@ -161,13 +174,52 @@ class VideoDiffusionInfer:
             return []
         if cfg_scale is None:
             cfg_scale = self.config.diffusion.cfg.scale
-        if float(cfg_scale) != 1.0:
-            raise NotImplementedError("cfg_scale != 1.0 is outside the one-step SeedVR2 path")
+        cfg_scale = float(cfg_scale)
+        if getattr(self, "sampling_timesteps", None) is None:
+            self.configure_diffusion()
+        ts = [float(t) for t in self.sampling_timesteps.tolist()]
         T = float(self.config.diffusion.schedule.T)
-        outs = []
         dev, adt = self.dit.device, self.dit.ops.act_dtype
-        for noise, cond, txt in zip(noises, conditions, texts_pos):
-            x_t = noise.to(device=dev, dtype=adt).contiguous()
-            vid = torch.cat([x_t, cond.to(device=dev, dtype=adt)], dim=-1)              # concat only (infer.py:362)
-            outs.append(self.dit.forward(vid, txt.to(device=dev, dtype=adt), timestep=T, x_t=x_t))
+        outs = []
+        if len(ts) == 1 and cfg_scale == 1.0:
+            # the pipeline's case: one model call at t = T, the Euler endpoint x_0 = x_T - pred folded into the un-patchify kernel
+            for noise, cond, txt in zip(noises, conditions, texts_pos):
+                x_t = noise.to(device=dev, dtype=adt).contiguous()
+                vid = torch.cat([x_t, cond.to(device=dev, dtype=adt)], dim=-1)          # concat only (infer.py:362)
+                outs.append(self.dit.forward(vid, txt.to(device=dev, dtype=adt), timestep=ts[0], x_t=x_t))
+            return outs
+        # the general sampler (euler.py:36-102, schedules/base.py:82-114, diffusion/utils.py:41-86): every clip of the batch on its own --
+        # the reference flattens the batch into one NaDiT call (na.flatten), but clips never interact (windows, text and the timestep
+        # embedding are per clip), and classifier-free-guidance rescale takes its standard deviation per token (the flattened [L, C]
+        # tensor's dim 1), so the results are the same.  Sampler arithmetic in fp32 on the device; the model sees the activation dtype.
+        partial = float(self.config.diffusion.cfg.get("partial", 1))
+        rescale = float(self.config.diffusion.cfg.get("rescale", 0.0))
+        for noise, cond, tpos, tneg in zip(noises, conditions, texts_pos, texts_neg):
+            x = noise.to(device=dev, dtype=torch.float32)
+            cond_a = cond.to(device=dev, dtype=adt)
+            tpos_a, tneg_a = tpos.to(device=dev, dtype=adt), tneg.to(device=dev, dtype=adt)
+
+            def model(text, t):
+                vid = torch.cat([x.to(adt), cond_a], dim=-1)
+                return self.dit.forward(vid, text, timestep=t).float()
+
+            for i, t in enumerate(ts):
+                scale = cfg_scale if (i + 1) / len(ts) <= partial else 1.0
+                pred = model(tpos_a, t)
+                if scale != 1.0:                                       # classifier_free_guidance_dispatcher: neg only when needed
+                    neg = model(tneg_a, t)
+                    cfg = neg + scale * (pred - neg)
+                    if rescale != 0.0:                                 # (https://arxiv.org/pdf/2305.08891.pdf) per token, over channels
+                        factor = pred.std(dim=-1, keepdim=True) / cfg.std(dim=-1, keepdim=True)
+                        cfg = cfg * (rescale * factor + (1 - rescale))
+                    pred = cfg
+                # v_lerp on the lerp schedule (A + B = 1): x_0 = x_t - B_t pred, x_T = x_t + A_t pred
+                x0 = x - (t / T) * pred
+                if i + 1 < len(ts):
+                    s_ = min(max(ts[i + 1], 0.0), T)
+                    xT = x + (1 - t / T) * pred
+                    x = (1 - s_ / T) * x0 + (s_ / T) * xT              # step_to: schedule.forward(x_0, x_T, s)
+                else:
+                    x = x0                                             # return_endpoint: backward direction ends at x_0
+            outs.append(x.to(adt))
         return outs

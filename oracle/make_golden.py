@@ -526,11 +526,75 @@ def main_r6_heavy():
     torch.save(res, os.path.join(GOLD, "heavy_tail.pt"))
 
 
+# Round 6: the sampler beyond the pipeline's forced steps = 1 / cfg = 1 (generation_phases.py:599-601): the reference's own EulerSampler
+# over several trailing timesteps with classifier-free guidance (partial + rescale), wired exactly as VideoDiffusionInfer.inference wires
+# it (infer.py:315-395) -- what `runner.inference` refused with NotImplementedError until now.  Two clips of different sizes, each
+# sampled as a batch of ONE: the reference's batched NaDiT call is not a usable mode -- with more than one clip its window attention
+# hands the clips' text to the windows round-robin (na.py:381-387 `batch_idx = i % batch_size`, `len(vid_len) // batch_size` repeats), so
+# clip 0's output moves by 3.4 % when only clip 1's TEXT changes (measured with the imported reference, DIT_TINY) -- while
+# `NaDiTEngine.__call__` / `runner.inference` treat a batch as what it means: independent clips.
+SAMPLER_CASE = dict(latents=((3, 16, 24), (1, 12, 16)), steps=4, cfg_scale=2.5, cfg_partial=0.5, cfg_rescale=0.7, seed=71)
+
+
+def sampler_inputs():
+    """-> (noises, conditions, texts_pos, texts_neg): bf16-valued, rebuilt from the seed by tests."""
+    g = torch.Generator().manual_seed(SAMPLER_CASE["seed"])
+    noises, conds, tp, tn = [], [], [], []
+    for (T, H, W) in SAMPLER_CASE["latents"]:
+        noises.append(_bf16_values(torch.randn(T, H, W, 16, generator=g)))
+        lat = torch.randn(T, H, W, 16, generator=g) * 0.9152
+        conds.append(_bf16_values(torch.cat([lat, torch.ones(T, H, W, 1)], dim=-1)))
+        tp.append(_bf16_values(torch.randn(58, 5120, generator=g) * 0.5))
+        tn.append(_bf16_values(torch.randn(58, 5120, generator=g) * 0.5))
+    return noises, conds, tp, tn
+
+
+def main_r6_sampler():
+    from oracle import reference_loader as rl
+    assert rl.available(), "needs /root/reference"
+    config = importlib.import_module(PKG + ".config")
+    weights = importlib.import_module(PKG + ".weights")
+    sc = SAMPLER_CASE
+    cfg = config.DIT_TINY
+    dit = rl.build_reference_dit(cfg.as_dict(), {k: v.float() for k, v in weights.synth_dit_state_dict(cfg).items()})
+    st = rl.reference_sampler_stack(T=1000.0, steps=sc["steps"])
+    na, sampler, cfg_dispatch = st["na"], st["sampler"], st["cfg"]
+    noises, conds, tp, tn = (list(t.float() for t in ts) for ts in sampler_inputs())
+
+    def sample(idx, guided):                               # infer.py:334-386 for the one-clip batch [idx]
+        batch = 1
+        pos_e, pos_s = na.flatten(tp[idx:idx + 1])
+        neg_e, neg_s = na.flatten(tn[idx:idx + 1])
+        latents, shapes = na.flatten(noises[idx:idx + 1])
+        lat_cond, _ = na.flatten(conds[idx:idx + 1])
+        with torch.no_grad():
+            out = sampler.sample(
+                x=latents,
+                f=lambda args: cfg_dispatch(
+                    pos=lambda: dit(vid=torch.cat([args.x_t, lat_cond], dim=-1), txt=pos_e, vid_shape=shapes, txt_shape=pos_s,
+                                    timestep=args.t.repeat(batch)).vid_sample,
+                    neg=lambda: dit(vid=torch.cat([args.x_t, lat_cond], dim=-1), txt=neg_e, vid_shape=shapes, txt_shape=neg_s,
+                                    timestep=args.t.repeat(batch)).vid_sample,
+                    scale=((sc["cfg_scale"] if guided else 1.0) if (args.i + 1) / len(sampler.timesteps) <= sc["cfg_partial"] else 1.0),
+                    rescale=sc["cfg_rescale"]))
+        return na.unflatten(out, shapes)[0]
+
+    outs = [sample(0, True), sample(1, True)]
+    plain = sample(0, False)                               # several steps alone, guidance off
+    print("sampler_multistep", [tuple(o.shape) for o in outs], [float(o.std()) for o in outs], float(plain.std()))
+    torch.save({"outs": [o.clone() for o in outs], "plain": plain.clone(),
+                "timesteps": sampler.timesteps.timesteps.clone(), **sc}, os.path.join(GOLD, "sampler_multistep.pt"))
+
+
 def main_r6(which):
     import math
     if which in ("r6", "r6-heavy"):
         main_r6_heavy()
         if which == "r6-heavy":
+            return
+    if which in ("r6", "r6-sampler"):
+        main_r6_sampler()
+        if which == "r6-sampler":
             return
     from oracle import reference_loader as rl
     assert rl.available(), "needs /root/reference"

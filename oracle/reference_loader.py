@@ -124,6 +124,33 @@ def build_reference_dit(cfg: dict, state_dict=None, dtype=None):
     return m
 
 
+def reference_sampler_stack(T=1000.0, steps=1, shift=1.0, prediction_type="v_lerp"):
+    """The reference's diffusion stack as VideoDiffusionInfer.configure_diffusion builds it (infer.py:80-113, diffusion/config.py:28-75):
+    LinearInterpolationSchedule, UniformTrailingSamplingTimesteps, EulerSampler -- plus the classifier-free-guidance dispatcher
+    (diffusion/utils.py:41-86) and the na.flatten / na.unflatten pair inference() batches with (infer.py:355-386).
+    ``src/common/diffusion/config.py`` imports omegaconf for a type annotation only; where omegaconf is absent a module holding that
+    one name is registered so that the package imports (none of the factory functions that would read a DictConfig is called)."""
+    import types
+    _prepare()
+    try:
+        import omegaconf  # noqa: F401
+    except ImportError:
+        m = types.ModuleType("omegaconf")
+        m.DictConfig, m.ListConfig, m.OmegaConf = dict, list, object
+        sys.modules["omegaconf"] = m
+    with contextlib.redirect_stdout(io.StringIO()):
+        from src.common.diffusion.samplers.euler import EulerSampler
+        from src.common.diffusion.schedules.lerp import LinearInterpolationSchedule
+        from src.common.diffusion.timesteps.sampling.trailing import UniformTrailingSamplingTimesteps
+        from src.common.diffusion.utils import classifier_free_guidance_dispatcher
+        from src.models.dit_3b import na
+    schedule = LinearInterpolationSchedule(T=T)
+    timesteps = UniformTrailingSamplingTimesteps(T=T, steps=steps, shift=shift)
+    sampler = EulerSampler(schedule=schedule, timesteps=timesteps, prediction_type=prediction_type)
+    sampler.get_progress_bar = lambda: type("P", (), {"update": lambda self: None})()      # (tqdm console output only)
+    return {"schedule": schedule, "timesteps": timesteps, "sampler": sampler, "cfg": classifier_free_guidance_dispatcher, "na": na}
+
+
 VAE_CFG = dict(  # src/models/video_vae_v3/s8_c16_t4_inflation_sd3.yaml
     act_fn="silu", block_out_channels=[128, 256, 512, 512],
     down_block_types=["DownEncoderBlock3D"] * 4, in_channels=3, latent_channels=16,

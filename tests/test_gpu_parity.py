@@ -361,6 +361,17 @@ def test_heavy_tail_checkpoint_statistics_on_the_hip_path(hip, level):
     ht.vae_case(hip, level)
 
 
+def test_multistep_euler_with_classifier_free_guidance_on_the_hip_path(hip):
+    """Round 6: runner.inference beyond the pipeline's forced steps = 1 / cfg = 1 -- four trailing Euler steps, classifier-free guidance
+    (scale 2.5 on the first half of the steps, rescale 0.7), two clips of different sizes -- against the reference's own EulerSampler /
+    CFG dispatcher over its NaDiT (tests/golden/sampler_multistep.pt; euler.py:36-102, diffusion/utils.py:41-86, infer.py:315-395).
+    Body shared with the CPU-double test; six model calls per clip accumulate, the bound is 3x a single call's."""
+    import test_sampler_multistep as sm
+    errs = sm.run_case(hip) + sm.run_case(hip, plain=True)
+    print("multi-step Euler + CFG on the HIP path vs the reference's sampler:", ["%.2e" % e for e in errs])
+    assert max(errs) < 1.5e-2
+
+
 def test_vae_temporal_slicing_invariance(hip):
     """Size-independent property: slice size must not change the result (causal halos carry state).
     Every kernel on the path reduces in a fixed order (no atomics), so the property is checked BIT-EXACT:

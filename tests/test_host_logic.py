@@ -322,9 +322,20 @@ def test_runner_api_surface():
     assert abs(float(t) - 1000.0) < 1e-3                                   # t = T is a fixed point of the shift
     x = r.schedule.forward(torch.zeros(2, 2), torch.ones(2, 2), torch.tensor([250.0]))
     assert torch.allclose(x, torch.full((2, 2), 0.25))
-    r.config.diffusion.timesteps.sampling.steps = 50
+    r.config.diffusion.timesteps.sampling.steps = 50                        # (round 6: any number of steps, trailing.py:39-48)
+    r.configure_diffusion()
+    ts = r.sampling_timesteps
+    assert ts.shape == (50,) and float(ts[0]) == 1000.0 and abs(float(ts[1]) - 980.0) < 1e-3 and abs(float(ts[-1]) - 20.0) < 1e-3
+    r.config.diffusion.timesteps.sampling.shift = 3.0                       # SD3 shift: t -> s t / (1 + (s - 1) t)
+    r.configure_diffusion()
+    assert abs(float(r.sampling_timesteps[25]) - 1000.0 * 3 * 0.5 / (1 + 2 * 0.5)) < 1e-3
+    r.config.diffusion.sampler.prediction_type = "v_cos"                    # not a combination the reference's configs use
     with pytest.raises(NotImplementedError):
         r.configure_diffusion()
+    r.config.diffusion.sampler.prediction_type = "v_lerp"
+    r.config.diffusion.timesteps.sampling.steps = 1
+    r.config.diffusion.timesteps.sampling.shift = 1.0
+    r.configure_diffusion()
     assert r.inference([], [], [], []) == []
 
 
