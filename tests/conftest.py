@@ -64,6 +64,14 @@ def _start_measurement_build(config, items):
     config._svr_measurement_build = (subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
                                                       start_new_session=True), out)
     items[:] = [it for it in items if it.name != MEASUREMENT_TEST] + mine
+    # the compile keeps one core busy for ~5 minutes: with as many OpenMP threads as cores every parallel region of the tests running
+    # next to it waits for the thread that shares that core (measured: 5-15x per test, 12 instead of 7 minutes for the suite), so the
+    # tests leave it one core
+    try:
+        import torch
+        torch.set_num_threads(max(1, torch.get_num_threads() - 1))
+    except Exception:                                            # noqa: BLE001 (a thread-count hint must never fail a run)
+        pass
 
 
 def pytest_unconfigure(config):
