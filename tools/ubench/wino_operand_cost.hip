@@ -160,6 +160,12 @@ int main() {
     const size_t HBM = (hbytes / 16) - 1;
     run<0, 0, 0, 0>("bare MFMA loop, one wave per SIMD", HBM, 1.0);
     run<2, 3, 2, 0>("shipped blocking: direct, 8 rows x 64 couts per wave (2 W + 3 LDS + 2/3 DMA)", HBM, 1.0);
+    // where the staged halo comes from: the same mix with the LDS-DMA source confined to windows that fit the L2s (4 MiB per XCD),
+    // the memory-side cache (256 MiB MALL) or nothing
+    run<2, 3, 2, 0>("   shipped mix, halo source window  4 MiB (L2-resident)", ((size_t)4 << 20) / 16 - 1, 1.0);
+    run<2, 3, 2, 0>("   shipped mix, halo source window 16 MiB (half of all L2s together)", ((size_t)16 << 20) / 16 - 1, 1.0);
+    run<2, 3, 2, 0>("   shipped mix, halo source window 128 MiB (MALL-resident)", ((size_t)128 << 20) / 16 - 1, 1.0);
+    run<2, 3, 2, 0>("   shipped mix, halo source window 512 MiB (beyond the MALL)", ((size_t)512 << 20) / 16 - 1, 1.0);
     run<16, 16, 2, 0>("F(2x2,3x3) 16 positions x (32 tiles x 32 couts): operands only, no transform VALU", HBM, 2.25);
     run<16, 16, 2, 128>("F(2x2,3x3) 16 positions x (32 x 32) + the input transform's 128 packed adds", HBM, 2.25);
     run<8, 8, 2, 0>("F(2x2,3x3) 4 positions x (64 tiles x 64 couts) per wave: operands only", HBM, 2.25);
